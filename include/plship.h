@@ -1,0 +1,245 @@
+/*
+ * plship.h -- C ABI of libplship.so: the MI355X (gfx950) projected-Langevin-sampling hot path.
+ *
+ * The reference (jswu18/projected-langevin-sampling) is pure Python/torch and has no FFI; its
+ * boundary for this path is the Python plugin API (PLS / PLSBasis / PLSCost / PLSLinkFunction).
+ * The entry points below are what a ctypes binding for that API calls.  Each one cites the
+ * reference code it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every array pointer is a DEVICE pointer to float64 unless the name ends in _host;
+ *   - matrices are row-major with an explicit leading dimension (elements, not bytes);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work is
+ *     enqueued asynchronously, nothing synchronises, nothing allocates (callers hand in
+ *     workspaces), so every call may be captured into a hipGraph;
+ *   - return value: 0 = PLS_OK, otherwise a pls_status; pls_last_error() returns a
+ *     thread-local human readable message for the last failing call on this thread;
+ *   - no global mutable state: descriptor structs are plain data owned by the caller, the
+ *     library is thread-compatible (different threads may call with different streams).
+ *
+ * N = training points, M = inducing points, Mk = kept eigen-directions (<= M), J = particles
+ * (columns; a rank may own a J-shard and pass its global column offset), D = input dim.
+ */
+#ifndef PLSHIP_H
+#define PLSHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PLSHIP_ABI_VERSION 1
+
+typedef enum {
+  PLS_OK = 0,
+  PLS_ERR_INVALID_ARGUMENT = 1,
+  PLS_ERR_HIP = 2,
+  PLS_ERR_WORKSPACE_TOO_SMALL = 3,
+  PLS_ERR_UNSUPPORTED = 4
+} pls_status;
+
+/* base kernel k (third party gpytorch ScaleKernel(RBFKernel(ard)) in the reference,
+ * constructed at experiments/uci/regression/main.py:171-173; MockKernel = mockers/kernel.py:13-23) */
+typedef enum { PLS_KERNEL_RBF_ARD = 0, PLS_KERNEL_LINEAR = 1 } pls_kernel_kind;
+
+/* src/projected_langevin_sampling/costs/{gaussian,poisson,bernoulli,student_t,multimodal}.py */
+typedef enum {
+  PLS_COST_GAUSSIAN = 0,
+  PLS_COST_POISSON = 1,
+  PLS_COST_BERNOULLI = 2,
+  PLS_COST_STUDENT_T = 3,
+  PLS_COST_MULTIMODAL = 4
+} pls_cost_kind;
+
+/* src/projected_langevin_sampling/link_functions.py:30-80 */
+typedef enum {
+  PLS_LINK_IDENTITY = 0,
+  PLS_LINK_SQUARE = 1,
+  PLS_LINK_SIGMOID = 2,
+  PLS_LINK_PROBIT = 3
+} pls_link_kind;
+
+/* How d cost / d f is evaluated.
+ *   PLS_DERIV_REFERENCE: what the reference's calculate_cost_derivative dispatch does -- the closed
+ *     form when (cost, link) is one of its matched pairs (gaussian.py:103-106, poisson.py:97-100,
+ *     bernoulli.py:92-95, student_t.py:103-106), otherwise the autograd value.
+ *   PLS_DERIV_AUTOGRAD: the value costs/base.py:68-84 (vmap(jacfwd)) returns, evaluated analytically
+ *     by the chain rule (clip has zero slope outside its range), for every (cost, link) pair. */
+typedef enum { PLS_DERIV_REFERENCE = 0, PLS_DERIV_AUTOGRAD = 1 } pls_deriv_mode;
+
+typedef struct {
+  int32_t cost;       /* pls_cost_kind */
+  int32_t link;       /* pls_link_kind */
+  int32_t deriv_mode; /* pls_deriv_mode */
+  int32_t reserved;
+  /* p[0..3]: gaussian {observation_noise (a VARIANCE, gaussian.py:71,86)};
+   *          student_t {degrees_of_freedom, scale};
+   *          multimodal {observation_noise (a STD, multimodal.py:56), shift, bernoulli_noise};
+   *          poisson / bernoulli: unused */
+  double p[4];
+  double jitter; /* clip of sigmoid / probit links (link_functions.py:36, :64), default 1e-10 */
+} pls_cost_desc;
+
+/* Langevin noise source for one step. */
+typedef enum {
+  PLS_NOISE_NONE = 0,     /* drift only (tests) */
+  PLS_NOISE_INJECTED = 1, /* xi is read from memory: parity runs inject the oracle's noise */
+  PLS_NOISE_PHILOX = 2    /* in-kernel Philox4x32-10 + Box-Muller, counter = (row, global column, step) */
+} pls_noise_kind;
+
+typedef struct {
+  int32_t kind; /* pls_noise_kind */
+  int32_t reserved;
+  const double *xi; /* PLS_NOISE_INJECTED: (rows x J) standard-normal matrix */
+  int64_t ldxi;
+  uint64_t seed;    /* PLS_NOISE_PHILOX */
+  uint64_t step;    /* PLS_NOISE_PHILOX: step counter, so every step draws fresh noise */
+  int64_t j_offset; /* global index of local column 0 (J-sharding: results do not depend on the GPU count) */
+} pls_noise_desc;
+
+/* Orthonormal basis state (reference: basis/orthonormal.py:22-68), produced by the setup calls below.
+ *   A  = V~^T k(Z,X)      (Mk x N), lda   -- V~ = V diag(1/sqrt(Mk*lambda)) (orthonormal.py:63-68)
+ *   At = k(X,Z) V~        (N x Mk), ldat  -- the same matrix transposed, so both contractions stream
+ *                                            k-major operands (DESIGN.md "data layout")
+ *   lam = kept eigenvalues of k(Z,Z)/M (Mk)
+ * Optional Gaussian/identity fast path (paper's O(M^3 + J M^2) step): B = A A^T (Mk x Mk), c = A y (Mk). */
+typedef struct {
+  int64_t mk, n;
+  const double *A;
+  int64_t lda;
+  const double *At;
+  int64_t ldat;
+  const double *lam;
+  const double *B; /* may be NULL */
+  int64_t ldb;
+  const double *c; /* may be NULL */
+} pls_onb_desc;
+
+/* Inducing-point basis state (reference: basis/inducing_point.py:23-50).
+ *   Kzx = k(Z,X) (M x N), Kxz = its transpose (N x M), W = k(Z,Z)^{-1} (M x M, symmetric),
+ *   Lc = lower Cholesky factor of k(Z,Z) stored TRANSPOSED (Lc^T, upper, M x M) for noise colouring. */
+typedef struct {
+  int64_t m, n;
+  const double *Kzx;
+  int64_t ldkzx;
+  const double *Kxz;
+  int64_t ldkxz;
+  const double *W;
+  int64_t ldw;
+  const double *LcT; /* may be NULL when noise is injected already coloured */
+  int64_t ldlct;
+} pls_ipb_desc;
+
+const char *pls_last_error(void);
+int pls_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Primitive operators (un-fused entry points; a user-defined Python cost or basis composes these)
+ * ------------------------------------------------------------------------------------------- */
+
+/* out(n1 x n2) = k(x1, x2); x1 (n1 x d), x2 (n2 x d) row-major contiguous.
+ * Replaces kernel.base_kernel(x1=.., x2=..) at orthonormal.py:36-41, inducing_point.py:41-46.
+ * lengthscale: d values (RBF_ARD; ignored for LINEAR). */
+int pls_kernel_gram(int32_t kernel_kind, const double *x1, int64_t n1, const double *x2, int64_t n2,
+                    int64_t d, const double *lengthscale, double outputscale, double *out, int64_t ldout,
+                    void *stream);
+
+/* C(I x J) = alpha * L^T R + beta * C with L (K x I, ldl), R (K x J, ldr): the fp64 MFMA contraction.
+ * Replaces every `@` on the path: orthonormal.py:106-108, :152-155; inducing_point.py:89-93, :144. */
+int pls_gemm_tn(const double *L, int64_t ldl, const double *R, int64_t ldr, double *C, int64_t ldc, int64_t I,
+                int64_t J, int64_t K, double alpha, double beta, void *stream);
+
+/* G(N x J) = d cost / d f evaluated at F(N x J), y(N).  Replaces PLSCost.calculate_cost_derivative
+ * (costs/gaussian.py:86-88, poisson.py:76-82, bernoulli.py:64-77, student_t.py:82-88, base.py:68-84). */
+int pls_cost_derivative(const pls_cost_desc *cost, const double *F, int64_t ldf, const double *y, int64_t n,
+                        int64_t j, double *G, int64_t ldg, void *stream);
+
+/* c(J) = sum_n cost(y_n, F_nj).  Replaces PLSCost.calculate_cost (gaussian.py:63-73, poisson.py:59-66,
+ * bernoulli.py:57-62, student_t.py:57-72, multimodal.py:37-77).  Deterministic summation order.
+ * workspace: pls_cost_value_workspace_bytes(n, j) bytes. */
+size_t pls_cost_value_workspace_bytes(int64_t n, int64_t j);
+int pls_cost_value(const pls_cost_desc *cost, const double *F, int64_t ldf, const double *y, int64_t n, int64_t j,
+                   double *c, void *workspace, size_t workspace_bytes, void *stream);
+
+/* out(rows x J) standard normals from the library's counter-based generator (same stream the fused
+ * step uses).  Replaces torch.normal at basis/base.py:55-63 and samplers.py:30-35 for on-device runs. */
+int pls_normal_fill(double *out, int64_t ldout, int64_t rows, int64_t j, uint64_t seed, uint64_t step,
+                    int64_t j_offset, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Orthonormal basis: setup + step
+ * ------------------------------------------------------------------------------------------- */
+
+/* A = Vs^T Kzx and At = Kzx^T Vs from the scaled eigenvectors Vs (M x Mk) and Kzx (M x N).
+ * Replaces the per-step re-association `base_gram_induce_train.T @ scaled_eigenvectors`
+ * (orthonormal.py:106-108) and `scaled_eigenvectors.T @ base_gram_induce_train` (:152-154) by a one-time build. */
+int pls_onb_build_projection(const double *Vs, int64_t ldvs, const double *Kzx, int64_t ldkzx, int64_t m, int64_t mk,
+                             int64_t n, double *A, int64_t lda, double *At, int64_t ldat, void *stream);
+
+/* Gaussian/identity fast path constants: B = A A^T (Mk x Mk) and c = A y (Mk). */
+int pls_onb_build_gaussian(const pls_onb_desc *basis, const double *y, double *B, int64_t ldb, double *c,
+                           void *stream);
+
+/* F(N x J) = A^T U.  Replaces OrthonormalBasis.calculate_untransformed_train_prediction_samples
+ * (orthonormal.py:98-108). */
+int pls_onb_forward(const pls_onb_desc *basis, const double *U, int64_t ldu, int64_t j, double *F, int64_t ldf,
+                    void *stream);
+
+/* dU(Mk x J) = -eta * A G - eta * diag(1/lam) U + sqrt(2 eta) * xi.
+ * Replaces OrthonormalBasis._calculate_particle_update (orthonormal.py:128-159). */
+int pls_onb_particle_update(const pls_onb_desc *basis, const double *U, int64_t ldu, const double *G, int64_t ldg,
+                            int64_t j, double eta, const pls_noise_desc *noise, double *dU, int64_t lddu,
+                            void *stream);
+
+/* One fused Langevin step: PLS.calculate_particle_update(U, eta)
+ * (projected_langevin_sampling.py:107-123 -> orthonormal.py:98-108 -> costs/{*}.py -> orthonormal.py:128-159).
+ * Streams N in chunks: F chunk -> cost derivative in the GEMM epilogue -> back-projection; F and G are
+ * never materialised beyond one chunk.  If basis->B/c are set and the cost is Gaussian/identity the
+ * Mk x Mk x J fast path is taken unless force_generic != 0.
+ * out_mode 0: out = dU (the reference's return value);  out_mode 1: out = U + dU (the caller's
+ * `particles += update`, trainers.py:157, fused).  out must not alias U: other workgroups still read U as
+ * the GEMM operand, so callers ping-pong two particle buffers.
+ * workspace: pls_onb_step_workspace_bytes(...) bytes (any larger size lets it use bigger N chunks). */
+size_t pls_onb_step_workspace_bytes(const pls_onb_desc *basis, int64_t j, int64_t n_chunk);
+int pls_onb_step(const pls_onb_desc *basis, const pls_cost_desc *cost, const double *y, double *U, int64_t ldu,
+                 int64_t j, double eta, const pls_noise_desc *noise, double *out, int64_t ldo, int32_t out_mode,
+                 int32_t force_generic, void *workspace, size_t workspace_bytes, void *stream);
+
+/* e(J) = cost_j + 0.5 * sum_m U_mj^2 / lam_m  (per-particle energy; the caller takes the mean over all
+ * particles of all ranks).  Replaces PLS.calculate_energy_potential -> OrthonormalBasis.calculate_energy_potential
+ * (projected_langevin_sampling.py:125-138, orthonormal.py:110-126). */
+size_t pls_onb_energy_workspace_bytes(const pls_onb_desc *basis, int64_t j, int64_t n_chunk);
+int pls_onb_energy(const pls_onb_desc *basis, const pls_cost_desc *cost, const double *y, const double *U,
+                   int64_t ldu, int64_t j, double *e, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Inducing-point basis: step (setup = pls_kernel_gram + a host Cholesky)
+ * ------------------------------------------------------------------------------------------- */
+
+/* F = Kxz W U (inducing_point.py:81-93). workspace: m*j doubles. */
+int pls_ipb_forward(const pls_ipb_desc *basis, const double *U, int64_t ldu, int64_t j, double *F, int64_t ldf,
+                    void *workspace, size_t workspace_bytes, void *stream);
+
+/* dU = -eta Kzx G - eta M W U + sqrt(2 eta) e, e = Lc xi (inducing_point.py:117-150).
+ * PLS_NOISE_INJECTED: noise->xi is used AS e (already coloured).
+ * workspace: 4 * align256(m*j*8) bytes. */
+int pls_ipb_particle_update(const pls_ipb_desc *basis, const double *U, int64_t ldu, const double *G, int64_t ldg,
+                            int64_t j, double eta, const pls_noise_desc *noise, double *dU, int64_t lddu,
+                            void *workspace, size_t workspace_bytes, void *stream);
+
+size_t pls_ipb_step_workspace_bytes(const pls_ipb_desc *basis, int64_t j, int64_t n_chunk);
+int pls_ipb_step(const pls_ipb_desc *basis, const pls_cost_desc *cost, const double *y, double *U, int64_t ldu,
+                 int64_t j, double eta, const pls_noise_desc *noise, double *out, int64_t ldo, int32_t out_mode,
+                 void *workspace, size_t workspace_bytes, void *stream);
+
+/* e(J) = cost_j + (M/2) * ||W U_j||^2 (inducing_point.py:95-115). */
+size_t pls_ipb_energy_workspace_bytes(const pls_ipb_desc *basis, int64_t j, int64_t n_chunk);
+int pls_ipb_energy(const pls_ipb_desc *basis, const pls_cost_desc *cost, const double *y, const double *U,
+                   int64_t ldu, int64_t j, double *e, void *workspace, size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLSHIP_H */

@@ -1,0 +1,162 @@
+"""ctypes binding of libplship.so (include/plship.h).  The product path has no fallback: if the
+HIP library is missing or a call fails, this raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libplship.so")
+
+# enums (include/plship.h)
+KERNEL_RBF_ARD, KERNEL_LINEAR = 0, 1
+COST_GAUSSIAN, COST_POISSON, COST_BERNOULLI, COST_STUDENT_T, COST_MULTIMODAL = range(5)
+LINK_IDENTITY, LINK_SQUARE, LINK_SIGMOID, LINK_PROBIT = range(4)
+DERIV_REFERENCE, DERIV_AUTOGRAD = 0, 1
+NOISE_NONE, NOISE_INJECTED, NOISE_PHILOX = 0, 1, 2
+OUT_DELTA, OUT_NEW_STATE = 0, 1
+
+
+class PlsHipError(RuntimeError):
+    pass
+
+
+class CostDesc(C.Structure):
+    _fields_ = [
+        ("cost", C.c_int32),
+        ("link", C.c_int32),
+        ("deriv_mode", C.c_int32),
+        ("reserved", C.c_int32),
+        ("p", C.c_double * 4),
+        ("jitter", C.c_double),
+    ]
+
+
+class NoiseDesc(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("reserved", C.c_int32),
+        ("xi", C.c_void_p),
+        ("ldxi", C.c_int64),
+        ("seed", C.c_uint64),
+        ("step", C.c_uint64),
+        ("j_offset", C.c_int64),
+    ]
+
+
+class OnbDesc(C.Structure):
+    _fields_ = [
+        ("mk", C.c_int64),
+        ("n", C.c_int64),
+        ("A", C.c_void_p),
+        ("lda", C.c_int64),
+        ("At", C.c_void_p),
+        ("ldat", C.c_int64),
+        ("lam", C.c_void_p),
+        ("B", C.c_void_p),
+        ("ldb", C.c_int64),
+        ("c", C.c_void_p),
+    ]
+
+
+class IpbDesc(C.Structure):
+    _fields_ = [
+        ("m", C.c_int64),
+        ("n", C.c_int64),
+        ("Kzx", C.c_void_p),
+        ("ldkzx", C.c_int64),
+        ("Kxz", C.c_void_p),
+        ("ldkxz", C.c_int64),
+        ("W", C.c_void_p),
+        ("ldw", C.c_int64),
+        ("LcT", C.c_void_p),
+        ("ldlct", C.c_int64),
+    ]
+
+
+_P, _I64, _I32, _U64, _D, _SZ = C.c_void_p, C.c_int64, C.c_int32, C.c_uint64, C.c_double, C.c_size_t
+_CD, _ND, _OD, _ID = C.POINTER(CostDesc), C.POINTER(NoiseDesc), C.POINTER(OnbDesc), C.POINTER(IpbDesc)
+
+# name -> (restype, argtypes); every symbol include/plship.h declares
+SIGNATURES = {
+    "pls_last_error": (C.c_char_p, []),
+    "pls_abi_version": (C.c_int, []),
+    "pls_kernel_gram": (C.c_int, [_I32, _P, _I64, _P, _I64, _I64, _P, _D, _P, _I64, _P]),
+    "pls_gemm_tn": (C.c_int, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _D, _D, _P]),
+    "pls_cost_derivative": (C.c_int, [_CD, _P, _I64, _P, _I64, _I64, _P, _I64, _P]),
+    "pls_cost_value_workspace_bytes": (_SZ, [_I64, _I64]),
+    "pls_cost_value": (C.c_int, [_CD, _P, _I64, _P, _I64, _I64, _P, _P, _SZ, _P]),
+    "pls_normal_fill": (C.c_int, [_P, _I64, _I64, _I64, _U64, _U64, _I64, _P]),
+    "pls_onb_build_projection": (C.c_int, [_P, _I64, _P, _I64, _I64, _I64, _I64, _P, _I64, _P, _I64, _P]),
+    "pls_onb_build_gaussian": (C.c_int, [_OD, _P, _P, _I64, _P, _P]),
+    "pls_onb_forward": (C.c_int, [_OD, _P, _I64, _I64, _P, _I64, _P]),
+    "pls_onb_particle_update": (C.c_int, [_OD, _P, _I64, _P, _I64, _I64, _D, _ND, _P, _I64, _P]),
+    "pls_onb_step_workspace_bytes": (_SZ, [_OD, _I64, _I64]),
+    "pls_onb_step": (C.c_int, [_OD, _CD, _P, _P, _I64, _I64, _D, _ND, _P, _I64, _I32, _I32, _P, _SZ, _P]),
+    "pls_onb_energy_workspace_bytes": (_SZ, [_OD, _I64, _I64]),
+    "pls_onb_energy": (C.c_int, [_OD, _CD, _P, _P, _I64, _I64, _P, _P, _SZ, _P]),
+    "pls_ipb_forward": (C.c_int, [_ID, _P, _I64, _I64, _P, _I64, _P, _SZ, _P]),
+    "pls_ipb_particle_update": (C.c_int, [_ID, _P, _I64, _P, _I64, _I64, _D, _ND, _P, _I64, _P, _SZ, _P]),
+    "pls_ipb_step_workspace_bytes": (_SZ, [_ID, _I64, _I64]),
+    "pls_ipb_step": (C.c_int, [_ID, _CD, _P, _P, _I64, _I64, _D, _ND, _P, _I64, _I32, _P, _SZ, _P]),
+    "pls_ipb_energy_workspace_bytes": (_SZ, [_ID, _I64, _I64]),
+    "pls_ipb_energy": (C.c_int, [_ID, _CD, _P, _P, _I64, _I64, _P, _P, _SZ, _P]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libplship.so (built in-tree by __graft_entry__.build() / csrc/Makefile)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PlsHipError(
+            f"{LIB_PATH} not found: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
+            "(or __graft_entry__.build()).  There is no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.pls_abi_version() != 1:
+        raise PlsHipError(f"libplship ABI {lib.pls_abi_version()} != 1")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().pls_last_error().decode()
+        raise PlsHipError(f"{what or 'libplship'} failed (status {rc}): {msg}")
+
+
+def require_gpu_tensor(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if t.device.type != "cuda":
+        raise PlsHipError(
+            f"{name} lives on {t.device}: the projected-Langevin hot path runs on the MI355X only "
+            "(no CPU fallback); move it with .cuda()"
+        )
+    if t.dtype != torch.float64:
+        raise PlsHipError(f"{name} must be float64 on the device, got {t.dtype}")
+    return t
+
+
+def ptr(t: torch.Tensor | None) -> int | None:
+    return None if t is None else t.data_ptr()
+
+
+def ld(t: torch.Tensor) -> int:
+    """Leading dimension (elements) of a row-major 2-D tensor whose rows are contiguous."""
+    assert t.dim() == 2 and t.stride(1) == 1, "matrix rows must be contiguous"
+    return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,113 @@
+// Cost functions, their derivatives and the link functions, evaluated per element on the device.
+// Reference: src/projected_langevin_sampling/costs/*.py and link_functions.py (lines cited per branch).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/plship.h"
+
+namespace plship {
+
+struct CostP {
+  int cost, link, mode;
+  double p0, p1, p2, p3, jitter;
+};
+
+__host__ inline CostP make_costp(const pls_cost_desc *d) {
+  CostP c;
+  c.cost = d->cost;
+  c.link = d->link;
+  c.mode = d->deriv_mode;
+  c.p0 = d->p[0];
+  c.p1 = d->p[1];
+  c.p2 = d->p[2];
+  c.p3 = d->p[3];
+  c.jitter = d->jitter;
+  return c;
+}
+
+__device__ inline double clipd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
+
+// link_functions.py:30-80.  *slope receives d link / d f as torch autograd sees it (0 outside the clip).
+__device__ inline double link_eval(int link, double f, double jit, double *slope) {
+  switch (link) {
+    case PLS_LINK_IDENTITY:  // :54-55
+      *slope = 1.0;
+      return f;
+    case PLS_LINK_SQUARE:  // :79-80
+      *slope = 2.0 * f;
+      return f * f;
+    case PLS_LINK_SIGMOID: {  // :67-70
+      double raw = 1.0 / (1.0 + exp(-f));
+      bool inside = (raw >= jit) && (raw <= 1.0 - jit);
+      *slope = inside ? raw * (1.0 - raw) : 0.0;
+      return clipd(raw, jit, 1.0 - jit);
+    }
+    default: {  // PLS_LINK_PROBIT :39-45
+      double raw = 0.5 * (1.0 + erf(f * 0.70710678118654752440));
+      bool inside = (raw >= jit) && (raw <= 1.0 - jit);
+      *slope = inside ? 0.39894228040143267794 * exp(-0.5 * f * f) : 0.0;
+      return clipd(raw, jit, 1.0 - jit);
+    }
+  }
+}
+
+// cost(y, f) for one (n, j) entry; summed over n by the callers.
+__device__ inline double cost_value(const CostP &c, double y, double f) {
+  double slope;
+  double p = link_eval(c.link, f, c.jitter, &slope);
+  switch (c.cost) {
+    case PLS_COST_GAUSSIAN: {  // gaussian.py:63-73 (observation_noise is a variance here)
+      double e = p - y;
+      return e * e / (2.0 * c.p0);
+    }
+    case PLS_COST_POISSON:  // poisson.py:59-66
+      return -2.0 * y * log(fabs(f)) + p;
+    case PLS_COST_BERNOULLI:  // bernoulli.py:57-62
+      return -log(p) * y - log(1.0 - p) * (1.0 - y);
+    case PLS_COST_STUDENT_T: {  // student_t.py:57-72, p0 = dof, p1 = scale
+      double e = p - y;
+      return 0.5 * (c.p0 + 1.0) * log(1.0 + e * e / (c.p0 * c.p1 * c.p1));
+    }
+    default: {  // PLS_COST_MULTIMODAL multimodal.py:37-77, p0 = sigma (std), p1 = shift, p2 = bernoulli_noise
+      double s2 = c.p0 * c.p0;
+      double e1 = y - p + c.p1, e2 = y - p;
+      double norm = 0.5 * log(2.0 * 3.14159265358979323846 * s2);
+      double a1 = log(c.p2) - 0.5 * e1 * e1 / s2 - norm;
+      double a2 = log(1.0 - c.p2) - 0.5 * e2 * e2 / s2 - norm;
+      double m = fmax(a1, a2);
+      return -(m + log(exp(a1 - m) + exp(a2 - m)));
+    }
+  }
+}
+
+// d cost / d f for one entry.
+__device__ inline double cost_deriv(const CostP &c, double y, double f) {
+  double slope;
+  double p = link_eval(c.link, f, c.jitter, &slope);
+  const bool ref = (c.mode == PLS_DERIV_REFERENCE);
+  switch (c.cost) {
+    case PLS_COST_GAUSSIAN:  // gaussian.py:86-88 closed form == chain rule for the identity link
+      return (p - y) / c.p0 * slope;
+    case PLS_COST_POISSON:  // poisson.py:76-82 (square link closed form == chain rule); else autograd value
+      return -2.0 * y / f + slope;
+    case PLS_COST_BERNOULLI:
+      if (ref && c.link == PLS_LINK_SIGMOID)  // bernoulli.py:64-77, uses the CLIPPED p
+        return -y * (1.0 - p) + (1.0 - y) * p;
+      return (-y / p + (1.0 - y) / (1.0 - p)) * slope;
+    case PLS_COST_STUDENT_T: {  // student_t.py:82-88
+      double e = p - y;
+      return (c.p0 + 1.0) * e / (c.p0 * c.p1 * c.p1 + e * e) * slope;
+    }
+    default: {  // multimodal.py:79-91: always the autograd value
+      double s2 = c.p0 * c.p0;
+      double e1 = y - p + c.p1, e2 = y - p;
+      double a1 = log(c.p2) - 0.5 * e1 * e1 / s2;
+      double a2 = log(1.0 - c.p2) - 0.5 * e2 * e2 / s2;
+      double m = fmax(a1, a2);
+      double w1 = exp(a1 - m), w2 = exp(a2 - m);
+      return -(w1 * e1 + w2 * e2) / ((w1 + w2) * s2) * slope;
+    }
+  }
+}
+
+}  // namespace plship

@@ -1,0 +1,879 @@
+// libplship.so -- C ABI (include/plship.h) over the gfx950 kernels of the projected-Langevin-sampling hot path.
+// Everything here enqueues work on the caller's stream; nothing allocates or synchronises.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+
+#include "../../include/plship.h"
+#include "cost_device.h"
+#include "gemm_tn_f64.h"
+#include "philox.h"
+
+namespace plship {
+
+// ---------------------------------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+static int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+#define PLS_REQUIRE(cond, ...) \
+  do {                         \
+    if (!(cond)) return fail(PLS_ERR_INVALID_ARGUMENT, __VA_ARGS__); \
+  } while (0)
+
+static int check_launch(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(PLS_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+  return PLS_OK;
+}
+
+static inline hipStream_t S(void *stream) { return reinterpret_cast<hipStream_t>(stream); }
+__host__ __device__ static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// GEMM epilogues that need the cost functions / the noise generator
+// ---------------------------------------------------------------------------------------------------------------
+
+// G = d cost / d f (acc = F tile); rows of this launch are rows [row0, row0 + I) of y.
+struct EpiCostDeriv {
+  double *G;
+  int64_t ldg;
+  const double *y;
+  CostP cp;
+  template <int TI, int TJ>
+  __device__ void apply(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int, int64_t I, int64_t J, int,
+                        double *) const {
+    PLS_FOR_EACH_ACC(G[i * ldg + j] = cost_deriv(cp, y[i], v);)
+  }
+};
+
+// partial[tile_i][j] = sum over the tile's rows of cost(y_i, acc_ij); deterministic order.
+template <int BI, int BJ, int WI, int WJ>
+struct EpiCostValue {
+  double *partial;
+  int64_t ldp;
+  const double *y;
+  CostP cp;
+  template <int TI, int TJ>
+  __device__ void apply(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int wave, int64_t I, int64_t J,
+                        int tile_i, double *lds) const {
+    double s[TJ];
+#pragma unroll
+    for (int tb = 0; tb < TJ; ++tb) s[tb] = 0.0;
+#pragma unroll
+    for (int ta = 0; ta < TI; ++ta)
+#pragma unroll
+      for (int tb = 0; tb < TJ; ++tb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t i = iw + ta * 16 + r * 4 + (lane >> 4);
+          const int64_t j = jw + tb * 16 + (lane & 15);
+          if (i < I && j < J) s[tb] += cost_value(cp, y[i], acc.v[ta][tb][r]);
+        }
+#pragma unroll
+    for (int tb = 0; tb < TJ; ++tb) {
+      s[tb] += __shfl_xor(s[tb], 16);
+      s[tb] += __shfl_xor(s[tb], 32);
+    }
+    constexpr int NWJ = BJ / WJ, NWI = BI / WI;
+    const int wrow = wave / NWJ, wcol = wave % NWJ;
+    // lds[wrow][BJ]
+    if (lane < 16) {
+#pragma unroll
+      for (int tb = 0; tb < TJ; ++tb) lds[wrow * BJ + wcol * WJ + tb * 16 + lane] = s[tb];
+    }
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < BJ) {
+      double tot = 0.0;
+#pragma unroll
+      for (int w = 0; w < NWI; ++w) tot += lds[w * BJ + t];
+      const int64_t j = (jw - wcol * WJ) + t;
+      if (j < J) partial[(int64_t)tile_i * ldp + j] = tot;
+    }
+  }
+};
+
+struct NoiseP {
+  int kind;
+  const double *xi;
+  int64_t ldxi;
+  uint64_t seed, step;
+  int64_t j_offset;
+};
+
+static NoiseP make_noisep(const pls_noise_desc *n) {
+  NoiseP p;
+  if (!n) {
+    p.kind = PLS_NOISE_NONE;
+    p.xi = nullptr;
+    p.ldxi = 0;
+    p.seed = p.step = 0;
+    p.j_offset = 0;
+    return p;
+  }
+  p.kind = n->kind;
+  p.xi = n->xi;
+  p.ldxi = n->ldxi;
+  p.seed = n->seed;
+  p.step = n->step;
+  p.j_offset = n->j_offset;
+  return p;
+}
+
+// Gaussian/identity fast path: acc = (B U)_ij;  out = [U +] -eta*(acc - c_i)/sigma2 - eta*U_ij/lam_i + sqrt(2 eta)*xi_ij
+struct EpiLangevinGaussian {
+  double *out;
+  int64_t ldo;
+  const double *U;
+  int64_t ldu;
+  const double *c, *lam;
+  double eta, inv_noise, sq2eta;
+  int add_u;
+  NoiseP nz;
+  template <int TI, int TJ>
+  __device__ void apply(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int, int64_t I, int64_t J, int,
+                        double *) const {
+#pragma unroll
+    for (int ta = 0; ta < TI; ++ta)
+#pragma unroll
+      for (int tb = 0; tb < TJ; ++tb) {
+        const int64_t j = jw + tb * 16 + (lane & 15);
+#pragma unroll
+        for (int rp = 0; rp < 2; ++rp) {  // rows (r = 2rp, 2rp+1) differ by 4: one Philox pair
+          const int64_t ib = iw + ta * 16 + rp * 8 + (lane >> 4);
+          double z0 = 0.0, z1 = 0.0;
+          if (nz.kind == PLS_NOISE_PHILOX) {
+            if (ib < I && j < J) normal_pair(nz.seed, nz.step, ib, nz.j_offset + j, z0, z1);
+          } else if (nz.kind == PLS_NOISE_INJECTED) {
+            if (ib < I && j < J) z0 = nz.xi[ib * nz.ldxi + j];
+            if (ib + 4 < I && j < J) z1 = nz.xi[(ib + 4) * nz.ldxi + j];
+          }
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int64_t i = ib + 4 * h;
+            if (i < I && j < J) {
+              const double u = U[i * ldu + j];
+              const double v = acc.v[ta][tb][2 * rp + h];
+              double d = -eta * inv_noise * (v - c[i]) - eta * u / lam[i] + sq2eta * (h ? z1 : z0);
+              out[i * ldo + j] = add_u ? u + d : d;
+            }
+          }
+        }
+      }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// GEMM launcher
+// ---------------------------------------------------------------------------------------------------------------
+template <int BI, int BJ, int WI, int WJ, class Epi>
+static int launch_gemm_cfg(GemmShape g, const Epi &epi, hipStream_t st) {
+  constexpr int BK = 16;
+  constexpr int NT = (BI / WI) * (BJ / WJ) * 64;
+  constexpr size_t lds_bytes = (size_t)2 * BK * ((BI + 16) + (BJ + 16)) * sizeof(double);
+  auto kern = gemm_tn_f64_kernel<BI, BJ, WI, WJ, BK, Epi>;
+  static bool attr_set = false;  // benign race: idempotent
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return fail(PLS_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  g.nti = (int)cdiv(g.I, BI);
+  g.ntj = (int)cdiv(g.J, BJ);
+  const int64_t nwg = (int64_t)g.nti * g.ntj;
+  if (nwg <= 0) return PLS_OK;
+  if (nwg > 0x7fffffff) return fail(PLS_ERR_INVALID_ARGUMENT, "gemm: too many tiles");
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(NT), lds_bytes, st, g, epi);
+  return check_launch("gemm_tn_f64");
+}
+
+static bool use_big_tiles(int64_t I, int64_t J) { return cdiv(I, 128) * cdiv(J, 128) >= 256; }
+
+template <class Epi>
+static int launch_gemm(const double *L, int64_t ldl, const double *R, int64_t ldr, int64_t I, int64_t J, int64_t K,
+                       const Epi &epi, hipStream_t st) {
+  GemmShape g{L, ldl, R, ldr, I, J, K, 0, 0};
+  if (use_big_tiles(I, J)) return launch_gemm_cfg<128, 128, 64, 64>(g, epi, st);
+  return launch_gemm_cfg<64, 64, 32, 32>(g, epi, st);
+}
+
+// cost-value GEMM (tile geometry is part of the epilogue type); returns the number of partial rows written
+static int64_t cost_value_partial_rows(int64_t I, int64_t J) { return use_big_tiles(I, J) ? cdiv(I, 128) : cdiv(I, 64); }
+
+static int launch_gemm_cost_value(const double *L, int64_t ldl, const double *R, int64_t ldr, int64_t I, int64_t J,
+                                  int64_t K, double *partial, int64_t ldp, const double *y, const CostP &cp,
+                                  hipStream_t st) {
+  GemmShape g{L, ldl, R, ldr, I, J, K, 0, 0};
+  if (use_big_tiles(I, J)) {
+    EpiCostValue<128, 128, 64, 64> e{partial, ldp, y, cp};
+    return launch_gemm_cfg<128, 128, 64, 64>(g, e, st);
+  }
+  EpiCostValue<64, 64, 32, 32> e{partial, ldp, y, cp};
+  return launch_gemm_cfg<64, 64, 32, 32>(g, e, st);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// HBM-bound kernels
+// ---------------------------------------------------------------------------------------------------------------
+
+// k(x1, x2): one thread per output pair of columns; x1 row and the inverse lengthscales live in registers / LDS.
+// Writes are 16-B per lane, coalesced along n2 (the kernel is bound by the 8*n1*n2 bytes it writes).
+template <int D_MAX>
+__global__ __launch_bounds__(256) void kernel_gram_kernel(int kind, const double *__restrict__ x1, int64_t n1,
+                                                           const double *__restrict__ x2, int64_t n2, int d,
+                                                           const double *__restrict__ lengthscale, double outputscale,
+                                                           double *__restrict__ out, int64_t ldout) {
+  __shared__ double inv_ls[D_MAX];
+  __shared__ double a_s[8][D_MAX];  // 8 rows of x1 per block (pre-scaled)
+  const int t = threadIdx.x;
+  const int64_t row0 = (int64_t)blockIdx.y * 8;
+  if (t < d) inv_ls[t] = (kind == PLS_KERNEL_RBF_ARD) ? 1.0 / lengthscale[t] : 1.0;
+  __syncthreads();
+  for (int e = t; e < 8 * d; e += 256) {
+    const int r = e / d, k = e % d;
+    a_s[r][k] = (row0 + r < n1) ? x1[(row0 + r) * d + k] * inv_ls[k] : 0.0;
+  }
+  __syncthreads();
+  const int64_t col = ((int64_t)blockIdx.x * 256 + t) * 2;
+  if (col >= n2) return;
+  const bool two = col + 1 < n2;
+  double b0[D_MAX], b1[D_MAX];
+#pragma unroll
+  for (int k = 0; k < D_MAX; ++k) {
+    b0[k] = (k < d) ? x2[col * d + k] * inv_ls[k] : 0.0;
+    b1[k] = (k < d && two) ? x2[(col + 1) * d + k] * inv_ls[k] : 0.0;
+  }
+  const bool vec = two && ((ldout & 1) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    if (row0 + r >= n1) break;
+    double s0 = 0.0, s1 = 0.0;
+    if (kind == PLS_KERNEL_RBF_ARD) {
+#pragma unroll
+      for (int k = 0; k < D_MAX; ++k) {
+        if (k < d) {
+          const double e0 = a_s[r][k] - b0[k], e1 = a_s[r][k] - b1[k];
+          s0 = fma(e0, e0, s0);
+          s1 = fma(e1, e1, s1);
+        }
+      }
+      s0 = outputscale * exp(-0.5 * s0);
+      s1 = outputscale * exp(-0.5 * s1);
+    } else {
+#pragma unroll
+      for (int k = 0; k < D_MAX; ++k) {
+        if (k < d) {
+          s0 = fma(a_s[r][k], b0[k], s0);
+          s1 = fma(a_s[r][k], b1[k], s1);
+        }
+      }
+    }
+    double *dst = out + (row0 + r) * ldout + col;
+    if (vec) {
+      *reinterpret_cast<double2_t *>(dst) = double2_t{s0, s1};
+    } else {
+      dst[0] = s0;
+      if (two) dst[1] = s1;
+    }
+  }
+}
+
+// elementwise cost derivative (un-fused entry point)
+__global__ __launch_bounds__(256) void cost_deriv_kernel(CostP cp, const double *__restrict__ F, int64_t ldf,
+                                                          const double *__restrict__ y, int64_t n, int64_t j,
+                                                          double *__restrict__ G, int64_t ldg) {
+  const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (col >= j) return;
+  for (int64_t row = blockIdx.y; row < n; row += gridDim.y) G[row * ldg + col] = cost_deriv(cp, y[row], F[row * ldf + col]);
+}
+
+// stage 1 of the column sums: partial[rb][col] = sum over rows [rb*RB, rb*RB + RB) of cost(y, F)
+constexpr int COST_RB = 256;
+__global__ __launch_bounds__(256) void cost_value_partial_kernel(CostP cp, const double *__restrict__ F, int64_t ldf,
+                                                                  const double *__restrict__ y, int64_t n, int64_t j,
+                                                                  double *__restrict__ partial, int64_t ldp) {
+  __shared__ double red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int64_t col = (int64_t)blockIdx.x * 64 + tx;
+  const int64_t r0 = (int64_t)blockIdx.y * COST_RB;
+  double s = 0.0;
+  if (col < j) {
+    for (int rr = ty; rr < COST_RB; rr += 4) {
+      const int64_t row = r0 + rr;
+      if (row < n) s += cost_value(cp, y[row], F[row * ldf + col]);
+    }
+  }
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && col < j) partial[(int64_t)blockIdx.y * ldp + col] = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+}
+
+// stage 2: out[col] = (accumulate ? out[col] : 0) + sum_rb partial[rb][col]  (+ prior energy term)
+//   prior_kind 0: none; 1: + 0.5 * sum_m P[m][col]^2 * scale_vec[m]  (ONB: P = U, scale_vec = 1/lam  -> pass lam, inverted here)
+//              2: + scale * sum_m P[m][col]^2                       (IPB: P = W U, scale = M/2)
+__global__ __launch_bounds__(256) void column_reduce_kernel(const double *__restrict__ partial, int64_t ldp,
+                                                             int64_t nparts, int64_t j, double *__restrict__ out,
+                                                             int accumulate, int prior_kind,
+                                                             const double *__restrict__ P, int64_t ldpp, int64_t m,
+                                                             const double *__restrict__ lam, double scale) {
+  const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (col >= j) return;
+  double s = accumulate ? out[col] : 0.0;
+  for (int64_t p = 0; p < nparts; ++p) s += partial[p * ldp + col];
+  if (prior_kind == 1) {
+    double e = 0.0;
+    for (int64_t r = 0; r < m; ++r) {
+      const double u = P[r * ldpp + col];
+      e += u * u / lam[r];
+    }
+    s += 0.5 * e;
+  } else if (prior_kind == 2) {
+    double e = 0.0;
+    for (int64_t r = 0; r < m; ++r) {
+      const double u = P[r * ldpp + col];
+      e += u * u;
+    }
+    s += scale * e;
+  }
+  out[col] = s;
+}
+
+// out = [U +] -eta * D - eta * pscale_i * P + sq2eta * noise     (rows x J)
+//   ONB: P = U, pscale_i = 1/lam_i (pass lam, lam_is_vec = 1);  IPB: P = W U, pscale = M (lam = NULL, pconst = M)
+// One thread per (row pair {ib, ib+4}, column): the pair shares one Philox call (philox.h).
+// (out may alias D element for element: each thread reads D[i][col] before it writes out[i][col].)
+__global__ __launch_bounds__(256) void langevin_update_kernel(double *out, int64_t ldo,
+                                                               const double *__restrict__ U, int64_t ldu,
+                                                               const double *D, int64_t ldd,
+                                                               const double *__restrict__ P, int64_t ldp,
+                                                               const double *__restrict__ lam, double pconst,
+                                                               int64_t rows, int64_t j, double eta, double sq2eta,
+                                                               int add_u, NoiseP nz) {
+  const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (col >= j) return;
+  const int64_t npairs = cdiv(rows, 8) * 4;
+  for (int64_t pr = blockIdx.y; pr < npairs; pr += gridDim.y) {
+    const int64_t ib = (pr >> 2) * 8 + (pr & 3);
+    if (ib >= rows) continue;
+    double z0 = 0.0, z1 = 0.0;
+    if (nz.kind == PLS_NOISE_PHILOX) {
+      normal_pair(nz.seed, nz.step, ib, nz.j_offset + col, z0, z1);
+    } else if (nz.kind == PLS_NOISE_INJECTED) {
+      z0 = nz.xi[ib * nz.ldxi + col];
+      if (ib + 4 < rows) z1 = nz.xi[(ib + 4) * nz.ldxi + col];
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int64_t i = ib + 4 * h;
+      if (i < rows) {
+        const double ps = lam ? 1.0 / lam[i] : pconst;
+        const double d = -eta * D[i * ldd + col] - eta * ps * P[i * ldp + col] + sq2eta * (h ? z1 : z0);
+        out[i * ldo + col] = add_u ? U[i * ldu + col] + d : d;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void normal_fill_kernel(double *__restrict__ out, int64_t ldo, int64_t rows,
+                                                           int64_t j, uint64_t seed, uint64_t step, int64_t j_offset) {
+  const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (col >= j) return;
+  const int64_t npairs = cdiv(rows, 8) * 4;
+  for (int64_t pr = blockIdx.y; pr < npairs; pr += gridDim.y) {
+    const int64_t ib = (pr >> 2) * 8 + (pr & 3);
+    if (ib >= rows) continue;
+    double z0, z1;
+    normal_pair(seed, step, ib, j_offset + col, z0, z1);
+    out[ib * ldo + col] = z0;
+    if (ib + 4 < rows) out[(ib + 4) * ldo + col] = z1;
+  }
+}
+
+// c = A y  (Mk rows, N long): one block per row, deterministic tree reduction
+__global__ __launch_bounds__(256) void matvec_rows_kernel(const double *__restrict__ A, int64_t lda, int64_t n,
+                                                           const double *__restrict__ y, double *__restrict__ c) {
+  __shared__ double red[256];
+  const double *row = A + (int64_t)blockIdx.x * lda;
+  double s = 0.0;
+  for (int64_t k = threadIdx.x; k < n; k += 256) s = fma(row[k], y[k], s);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) c[blockIdx.x] = red[0];
+}
+
+static unsigned rows_grid(int64_t items) { return (unsigned)(items < 1 ? 1 : (items > 1024 ? 1024 : items)); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// shared host helpers for the fused paths
+// ---------------------------------------------------------------------------------------------------------------
+static int validate_cost(const pls_cost_desc *c) {
+  PLS_REQUIRE(c != nullptr, "cost descriptor is NULL");
+  PLS_REQUIRE(c->cost >= PLS_COST_GAUSSIAN && c->cost <= PLS_COST_MULTIMODAL, "unknown cost kind %d", c->cost);
+  PLS_REQUIRE(c->link >= PLS_LINK_IDENTITY && c->link <= PLS_LINK_PROBIT, "unknown link kind %d", c->link);
+  PLS_REQUIRE(c->deriv_mode == PLS_DERIV_REFERENCE || c->deriv_mode == PLS_DERIV_AUTOGRAD, "unknown deriv_mode %d",
+              c->deriv_mode);
+  if (c->cost == PLS_COST_GAUSSIAN) PLS_REQUIRE(c->p[0] > 0.0, "gaussian cost needs observation_noise > 0");
+  if (c->cost == PLS_COST_STUDENT_T)
+    PLS_REQUIRE(c->p[0] > 0.0 && c->p[1] > 0.0, "student-t cost needs degrees_of_freedom > 0 and scale > 0");
+  if (c->cost == PLS_COST_MULTIMODAL)
+    PLS_REQUIRE(c->p[0] > 0.0 && c->p[2] > 0.0 && c->p[2] < 1.0, "multimodal cost needs sigma > 0, 0 < bernoulli_noise < 1");
+  return PLS_OK;
+}
+
+static int validate_noise(const pls_noise_desc *n, int64_t rows) {
+  if (!n) return PLS_OK;
+  PLS_REQUIRE(n->kind >= PLS_NOISE_NONE && n->kind <= PLS_NOISE_PHILOX, "unknown noise kind %d", n->kind);
+  if (n->kind == PLS_NOISE_INJECTED) PLS_REQUIRE(n->xi != nullptr && n->ldxi > 0, "injected noise needs xi and ldxi");
+  (void)rows;
+  return PLS_OK;
+}
+
+// Streams N in chunks:  G_c = cost'(Lf[:, chunk]^T V)  ->  D (+)= Lb[chunk, :]^T G_c.
+//   Lf (K x N, ldlf): forward operand (A or Kzx), V (K x J) particles in the basis the forward map expects
+//   Lb (N x K, ldlb): back-projection operand (At or Kxz)
+//   D  (K x J): receives the drift  Lb^T cost'(...)
+static int stream_drift(const double *Lf, int64_t ldlf, const double *Lb, int64_t ldlb, int64_t kdim, int64_t n,
+                        const double *V, int64_t ldv, int64_t j, const CostP &cp, const double *y, double *D,
+                        int64_t ldd, double *Gbuf, int64_t n_chunk, hipStream_t st) {
+  for (int64_t r0 = 0, c = 0; r0 < n; r0 += n_chunk, ++c) {
+    const int64_t rows = (n - r0 < n_chunk) ? (n - r0) : n_chunk;
+    EpiCostDeriv e1{Gbuf, j, y + r0, cp};
+    int rc = launch_gemm(Lf + r0, ldlf, V, ldv, rows, j, kdim, e1, st);
+    if (rc) return rc;
+    EpiStore e2{D, ldd, 1.0, c == 0 ? 0.0 : 1.0};
+    rc = launch_gemm(Lb + r0 * ldlb, ldlb, Gbuf, j, kdim, j, rows, e2, st);
+    if (rc) return rc;
+  }
+  return PLS_OK;
+}
+
+// c_j partials over N chunks -> cost_out[j] (deterministic)
+static int stream_cost(const double *Lf, int64_t ldlf, int64_t kdim, int64_t n, const double *V, int64_t ldv,
+                       int64_t j, const CostP &cp, const double *y, double *partial, int64_t n_chunk, double *e_out,
+                       int prior_kind, const double *P, int64_t ldp, int64_t m, const double *lam, double scale,
+                       hipStream_t st) {
+  int64_t nchunks = cdiv(n, n_chunk);
+  for (int64_t r0 = 0, c = 0; r0 < n; r0 += n_chunk, ++c) {
+    const int64_t rows = (n - r0 < n_chunk) ? (n - r0) : n_chunk;
+    int rc = launch_gemm_cost_value(Lf + r0, ldlf, V, ldv, rows, j, kdim, partial, j, y + r0, cp, st);
+    if (rc) return rc;
+    const bool last = (c == nchunks - 1);
+    hipLaunchKernelGGL(column_reduce_kernel, dim3((unsigned)cdiv(j, 256)), dim3(256), 0, st, partial, j,
+                       cost_value_partial_rows(rows, j), j, e_out, c == 0 ? 0 : 1, last ? prior_kind : 0, P, ldp, m,
+                       lam, scale);
+    rc = check_launch("column_reduce");
+    if (rc) return rc;
+  }
+  return PLS_OK;
+}
+
+static int64_t pick_chunk(int64_t n, size_t avail_bytes, int64_t j, size_t per_row_extra_bytes) {
+  // rows of G (j doubles each) that fit; at least 128-row granularity
+  const size_t per_row = (size_t)j * sizeof(double) + per_row_extra_bytes;
+  int64_t rows = (int64_t)(avail_bytes / per_row);
+  if (rows >= n) return n;
+  rows = rows / 128 * 128;
+  return rows;
+}
+
+}  // namespace plship
+
+using namespace plship;
+
+// =================================================================================================================
+// C ABI
+// =================================================================================================================
+extern "C" {
+
+const char *pls_last_error(void) { return g_last_error.c_str(); }
+int pls_abi_version(void) { return PLSHIP_ABI_VERSION; }
+
+int pls_kernel_gram(int32_t kernel_kind, const double *x1, int64_t n1, const double *x2, int64_t n2, int64_t d,
+                    const double *lengthscale, double outputscale, double *out, int64_t ldout, void *stream) {
+  PLS_REQUIRE(kernel_kind == PLS_KERNEL_RBF_ARD || kernel_kind == PLS_KERNEL_LINEAR, "unknown kernel kind %d", kernel_kind);
+  PLS_REQUIRE(x1 && x2 && out, "kernel_gram: NULL pointer");
+  PLS_REQUIRE(n1 >= 0 && n2 >= 0 && d >= 1, "kernel_gram: bad sizes n1=%lld n2=%lld d=%lld", (long long)n1, (long long)n2, (long long)d);
+  PLS_REQUIRE(d <= 64, "kernel_gram: input dimension %lld > 64 is not supported", (long long)d);
+  PLS_REQUIRE(ldout >= n2, "kernel_gram: ldout < n2");
+  PLS_REQUIRE(kernel_kind != PLS_KERNEL_RBF_ARD || lengthscale, "kernel_gram: RBF needs lengthscale");
+  if (n1 == 0 || n2 == 0) return PLS_OK;
+  dim3 grid((unsigned)cdiv(n2, 512), (unsigned)cdiv(n1, 8));
+  PLS_REQUIRE(cdiv(n1, 8) <= 65535 * 1024LL, "kernel_gram: n1 too large");
+  // gridDim.y limit is 65535: loop over slabs of rows if needed
+  const int64_t max_rows = 65535LL * 8;
+  for (int64_t r0 = 0; r0 < n1; r0 += max_rows) {
+    const int64_t rows = (n1 - r0 < max_rows) ? n1 - r0 : max_rows;
+    dim3 g2((unsigned)cdiv(n2, 512), (unsigned)cdiv(rows, 8));
+    if (d <= 8)
+      hipLaunchKernelGGL(kernel_gram_kernel<8>, g2, dim3(256), 0, S(stream), kernel_kind, x1 + r0 * d, rows, x2, n2, (int)d,
+                         lengthscale, outputscale, out + r0 * ldout, ldout);
+    else if (d <= 16)
+      hipLaunchKernelGGL(kernel_gram_kernel<16>, g2, dim3(256), 0, S(stream), kernel_kind, x1 + r0 * d, rows, x2, n2, (int)d,
+                         lengthscale, outputscale, out + r0 * ldout, ldout);
+    else
+      hipLaunchKernelGGL(kernel_gram_kernel<64>, g2, dim3(256), 0, S(stream), kernel_kind, x1 + r0 * d, rows, x2, n2, (int)d,
+                         lengthscale, outputscale, out + r0 * ldout, ldout);
+    int rc = check_launch("kernel_gram");
+    if (rc) return rc;
+  }
+  (void)grid;
+  return PLS_OK;
+}
+
+int pls_gemm_tn(const double *L, int64_t ldl, const double *R, int64_t ldr, double *C, int64_t ldc, int64_t I, int64_t J,
+                int64_t K, double alpha, double beta, void *stream) {
+  PLS_REQUIRE(L && R && C, "gemm_tn: NULL pointer");
+  PLS_REQUIRE(I >= 0 && J >= 0 && K >= 0, "gemm_tn: negative size");
+  PLS_REQUIRE(ldl >= I && ldr >= J && ldc >= J, "gemm_tn: leading dimension too small (ldl=%lld I=%lld ldr=%lld J=%lld ldc=%lld)",
+              (long long)ldl, (long long)I, (long long)ldr, (long long)J, (long long)ldc);
+  if (I == 0 || J == 0) return PLS_OK;
+  EpiStore e{C, ldc, alpha, beta};
+  return launch_gemm(L, ldl, R, ldr, I, J, K, e, S(stream));
+}
+
+int pls_cost_derivative(const pls_cost_desc *cost, const double *F, int64_t ldf, const double *y, int64_t n, int64_t j,
+                        double *G, int64_t ldg, void *stream) {
+  int rc = validate_cost(cost);
+  if (rc) return rc;
+  PLS_REQUIRE(F && y && G, "cost_derivative: NULL pointer");
+  PLS_REQUIRE(n >= 0 && j >= 0 && ldf >= j && ldg >= j, "cost_derivative: bad sizes");
+  if (n == 0 || j == 0) return PLS_OK;
+  hipLaunchKernelGGL(cost_deriv_kernel, dim3((unsigned)cdiv(j, 256), rows_grid(n)), dim3(256), 0, S(stream),
+                     make_costp(cost), F, ldf, y, n, j, G, ldg);
+  return check_launch("cost_derivative");
+}
+
+size_t pls_cost_value_workspace_bytes(int64_t n, int64_t j) {
+  if (n <= 0 || j <= 0) return 0;
+  return (size_t)cdiv(n, COST_RB) * (size_t)j * sizeof(double);
+}
+
+int pls_cost_value(const pls_cost_desc *cost, const double *F, int64_t ldf, const double *y, int64_t n, int64_t j,
+                   double *c, void *workspace, size_t workspace_bytes, void *stream) {
+  int rc = validate_cost(cost);
+  if (rc) return rc;
+  PLS_REQUIRE(F && y && c, "cost_value: NULL pointer");
+  PLS_REQUIRE(n >= 0 && j >= 0 && ldf >= j, "cost_value: bad sizes");
+  if (j == 0) return PLS_OK;
+  const size_t need = pls_cost_value_workspace_bytes(n, j);
+  if (workspace_bytes < need || (need && !workspace))
+    return fail(PLS_ERR_WORKSPACE_TOO_SMALL, "cost_value: workspace %zu < %zu bytes", workspace_bytes, need);
+  double *partial = static_cast<double *>(workspace);
+  const int64_t nparts = cdiv(n, COST_RB);
+  if (nparts > 0) {
+    PLS_REQUIRE(nparts <= 65535, "cost_value: n too large for one call");
+    hipLaunchKernelGGL(cost_value_partial_kernel, dim3((unsigned)cdiv(j, 64), (unsigned)nparts), dim3(256), 0, S(stream),
+                       make_costp(cost), F, ldf, y, n, j, partial, j);
+    rc = check_launch("cost_value_partial");
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(column_reduce_kernel, dim3((unsigned)cdiv(j, 256)), dim3(256), 0, S(stream), partial, j, nparts, j, c,
+                     0, 0, (const double *)nullptr, (int64_t)0, (int64_t)0, (const double *)nullptr, 0.0);
+  return check_launch("column_reduce");
+}
+
+int pls_normal_fill(double *out, int64_t ldout, int64_t rows, int64_t j, uint64_t seed, uint64_t step, int64_t j_offset,
+                    void *stream) {
+  PLS_REQUIRE(out, "normal_fill: NULL pointer");
+  PLS_REQUIRE(rows >= 0 && j >= 0 && ldout >= j, "normal_fill: bad sizes");
+  if (rows == 0 || j == 0) return PLS_OK;
+  hipLaunchKernelGGL(normal_fill_kernel, dim3((unsigned)cdiv(j, 256), rows_grid(cdiv(rows, 8) * 4)), dim3(256), 0,
+                     S(stream), out, ldout, rows, j, seed, step, j_offset);
+  return check_launch("normal_fill");
+}
+
+// ---- orthonormal basis -----------------------------------------------------------------------------------------
+
+static int validate_onb(const pls_onb_desc *b) {
+  PLS_REQUIRE(b != nullptr, "onb descriptor is NULL");
+  PLS_REQUIRE(b->mk > 0 && b->n > 0, "onb: mk and n must be positive");
+  PLS_REQUIRE(b->A && b->At && b->lam, "onb: A, At and lam must be set");
+  PLS_REQUIRE(b->lda >= b->n && b->ldat >= b->mk, "onb: leading dimension too small");
+  if (b->B) PLS_REQUIRE(b->ldb >= b->mk && b->c, "onb: B needs ldb >= mk and c");
+  return PLS_OK;
+}
+
+int pls_onb_build_projection(const double *Vs, int64_t ldvs, const double *Kzx, int64_t ldkzx, int64_t m, int64_t mk,
+                             int64_t n, double *A, int64_t lda, double *At, int64_t ldat, void *stream) {
+  PLS_REQUIRE(Vs && Kzx && A && At, "onb_build_projection: NULL pointer");
+  PLS_REQUIRE(m > 0 && mk > 0 && n > 0 && mk <= m, "onb_build_projection: bad sizes");
+  PLS_REQUIRE(ldvs >= mk && ldkzx >= n && lda >= n && ldat >= mk, "onb_build_projection: leading dimension too small");
+  // A (mk x n) = Vs^T Kzx : L = Vs (m x mk), R = Kzx (m x n)
+  int rc = pls_gemm_tn(Vs, ldvs, Kzx, ldkzx, A, lda, mk, n, m, 1.0, 0.0, stream);
+  if (rc) return rc;
+  // At (n x mk) = Kzx^T Vs : L = Kzx (m x n), R = Vs (m x mk)
+  return pls_gemm_tn(Kzx, ldkzx, Vs, ldvs, At, ldat, n, mk, m, 1.0, 0.0, stream);
+}
+
+int pls_onb_build_gaussian(const pls_onb_desc *basis, const double *y, double *B, int64_t ldb, double *c, void *stream) {
+  int rc = validate_onb(basis);
+  if (rc) return rc;
+  PLS_REQUIRE(y && B && c && ldb >= basis->mk, "onb_build_gaussian: bad arguments");
+  // B = A A^T = At^T At : L = R = At (n x mk)
+  rc = pls_gemm_tn(basis->At, basis->ldat, basis->At, basis->ldat, B, ldb, basis->mk, basis->mk, basis->n, 1.0, 0.0, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(matvec_rows_kernel, dim3((unsigned)basis->mk), dim3(256), 0, S(stream), basis->A, basis->lda,
+                     basis->n, y, c);
+  return check_launch("matvec_rows");
+}
+
+int pls_onb_forward(const pls_onb_desc *basis, const double *U, int64_t ldu, int64_t j, double *F, int64_t ldf,
+                    void *stream) {
+  int rc = validate_onb(basis);
+  if (rc) return rc;
+  PLS_REQUIRE(U && F && j >= 0 && ldu >= j && ldf >= j, "onb_forward: bad arguments");
+  return pls_gemm_tn(basis->A, basis->lda, U, ldu, F, ldf, basis->n, j, basis->mk, 1.0, 0.0, stream);
+}
+
+int pls_onb_particle_update(const pls_onb_desc *basis, const double *U, int64_t ldu, const double *G, int64_t ldg,
+                            int64_t j, double eta, const pls_noise_desc *noise, double *dU, int64_t lddu, void *stream) {
+  int rc = validate_onb(basis);
+  if (rc) return rc;
+  rc = validate_noise(noise, basis->mk);
+  if (rc) return rc;
+  PLS_REQUIRE(U && G && dU && j >= 0 && ldu >= j && ldg >= j && lddu >= j, "onb_particle_update: bad arguments");
+  PLS_REQUIRE(eta >= 0.0, "onb_particle_update: step size must be >= 0");
+  if (j == 0) return PLS_OK;
+  // D = A G into dU, then dU = -eta*D - eta*U/lam + sqrt(2 eta) xi in place (element-wise, race free)
+  rc = pls_gemm_tn(basis->At, basis->ldat, G, ldg, dU, lddu, basis->mk, j, basis->n, 1.0, 0.0, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(langevin_update_kernel, dim3((unsigned)cdiv(j, 256), rows_grid(cdiv(basis->mk, 8) * 4)), dim3(256), 0,
+                     S(stream), dU, lddu, U, ldu, dU, lddu, U, ldu, basis->lam, 0.0, basis->mk, j, eta, sqrt(2.0 * eta), 0,
+                     make_noisep(noise));
+  return check_launch("langevin_update");
+}
+
+static bool onb_fast_path(const pls_onb_desc *b, const pls_cost_desc *c, int force_generic) {
+  return !force_generic && b->B && b->c && c->cost == PLS_COST_GAUSSIAN && c->link == PLS_LINK_IDENTITY;
+}
+
+size_t pls_onb_step_workspace_bytes(const pls_onb_desc *basis, int64_t j, int64_t n_chunk) {
+  if (!basis || j <= 0) return 0;
+  if (n_chunk <= 0 || n_chunk > basis->n) n_chunk = basis->n;
+  // D (mk x j) + G chunk (n_chunk x j)
+  return align_up((size_t)basis->mk * j * sizeof(double), 256) + (size_t)n_chunk * j * sizeof(double);
+}
+
+int pls_onb_step(const pls_onb_desc *basis, const pls_cost_desc *cost, const double *y, double *U, int64_t ldu,
+                 int64_t j, double eta, const pls_noise_desc *noise, double *out, int64_t ldo, int32_t out_mode,
+                 int32_t force_generic, void *workspace, size_t workspace_bytes, void *stream) {
+  int rc = validate_onb(basis);
+  if (rc) return rc;
+  rc = validate_cost(cost);
+  if (rc) return rc;
+  rc = validate_noise(noise, basis->mk);
+  if (rc) return rc;
+  PLS_REQUIRE(U && out && y, "onb_step: NULL pointer");
+  PLS_REQUIRE(out != U, "onb_step: out must not alias U (ping-pong the particle buffers)");
+  PLS_REQUIRE(j >= 0 && ldu >= j && ldo >= j, "onb_step: bad sizes");
+  PLS_REQUIRE(eta >= 0.0, "onb_step: step size must be >= 0");
+  PLS_REQUIRE(out_mode == 0 || out_mode == 1, "onb_step: out_mode must be 0 (delta) or 1 (new state)");
+  if (j == 0) return PLS_OK;
+  const CostP cp = make_costp(cost);
+  const NoiseP nz = make_noisep(noise);
+  hipStream_t st = S(stream);
+  if (onb_fast_path(basis, cost, force_generic)) {
+    EpiLangevinGaussian e{out, ldo, U, ldu, basis->c, basis->lam, eta, 1.0 / cost->p[0], sqrt(2.0 * eta), out_mode, nz};
+    return launch_gemm(basis->B, basis->ldb, U, ldu, basis->mk, j, basis->mk, e, st);
+  }
+  const size_t d_bytes = align_up((size_t)basis->mk * j * sizeof(double), 256);
+  if (!workspace || workspace_bytes < d_bytes + (size_t)128 * j * sizeof(double))
+    return fail(PLS_ERR_WORKSPACE_TOO_SMALL, "onb_step: workspace %zu bytes, need at least %zu", workspace_bytes,
+                pls_onb_step_workspace_bytes(basis, j, 128));
+  double *D = static_cast<double *>(workspace);
+  double *Gbuf = reinterpret_cast<double *>(static_cast<char *>(workspace) + d_bytes);
+  const int64_t n_chunk = pick_chunk(basis->n, workspace_bytes - d_bytes, j, 0);
+  rc = stream_drift(basis->A, basis->lda, basis->At, basis->ldat, basis->mk, basis->n, U, ldu, j, cp, y, D, j, Gbuf,
+                    n_chunk, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(langevin_update_kernel, dim3((unsigned)cdiv(j, 256), rows_grid(cdiv(basis->mk, 8) * 4)), dim3(256), 0,
+                     st, out, ldo, U, ldu, D, j, U, ldu, basis->lam, 0.0, basis->mk, j, eta, sqrt(2.0 * eta), out_mode, nz);
+  return check_launch("langevin_update");
+}
+
+size_t pls_onb_energy_workspace_bytes(const pls_onb_desc *basis, int64_t j, int64_t n_chunk) {
+  if (!basis || j <= 0) return 0;
+  if (n_chunk <= 0 || n_chunk > basis->n) n_chunk = basis->n;
+  return (size_t)cdiv(n_chunk, 64) * j * sizeof(double);
+}
+
+int pls_onb_energy(const pls_onb_desc *basis, const pls_cost_desc *cost, const double *y, const double *U, int64_t ldu,
+                   int64_t j, double *e, void *workspace, size_t workspace_bytes, void *stream) {
+  int rc = validate_onb(basis);
+  if (rc) return rc;
+  rc = validate_cost(cost);
+  if (rc) return rc;
+  PLS_REQUIRE(U && e && y && j >= 0 && ldu >= j, "onb_energy: bad arguments");
+  if (j == 0) return PLS_OK;
+  // rows per chunk such that the partial buffer ((chunk/64) x j doubles) fits
+  const int64_t max_parts = (int64_t)(workspace_bytes / ((size_t)j * sizeof(double)));
+  if (!workspace || max_parts < 2)
+    return fail(PLS_ERR_WORKSPACE_TOO_SMALL, "onb_energy: workspace %zu bytes too small", workspace_bytes);
+  int64_t n_chunk = max_parts * 64;
+  if (n_chunk > basis->n) n_chunk = basis->n;
+  else n_chunk = n_chunk / 128 * 128;
+  return stream_cost(basis->A, basis->lda, basis->mk, basis->n, U, ldu, j, make_costp(cost), y,
+                     static_cast<double *>(workspace), n_chunk, e, 1, U, ldu, basis->mk, basis->lam, 0.0, S(stream));
+}
+
+// ---- inducing-point basis ---------------------------------------------------------------------------------------
+
+static int validate_ipb(const pls_ipb_desc *b) {
+  PLS_REQUIRE(b != nullptr, "ipb descriptor is NULL");
+  PLS_REQUIRE(b->m > 0 && b->n > 0, "ipb: m and n must be positive");
+  PLS_REQUIRE(b->Kzx && b->Kxz && b->W, "ipb: Kzx, Kxz and W must be set");
+  PLS_REQUIRE(b->ldkzx >= b->n && b->ldkxz >= b->m && b->ldw >= b->m, "ipb: leading dimension too small");
+  if (b->LcT) PLS_REQUIRE(b->ldlct >= b->m, "ipb: ldlct < m");
+  return PLS_OK;
+}
+
+int pls_ipb_forward(const pls_ipb_desc *basis, const double *U, int64_t ldu, int64_t j, double *F, int64_t ldf,
+                    void *workspace, size_t workspace_bytes, void *stream) {
+  int rc = validate_ipb(basis);
+  if (rc) return rc;
+  PLS_REQUIRE(U && F && j >= 0 && ldu >= j && ldf >= j, "ipb_forward: bad arguments");
+  if (j == 0) return PLS_OK;
+  const size_t need = (size_t)basis->m * j * sizeof(double);
+  if (!workspace || workspace_bytes < need)
+    return fail(PLS_ERR_WORKSPACE_TOO_SMALL, "ipb_forward: workspace %zu < %zu bytes", workspace_bytes, need);
+  double *V = static_cast<double *>(workspace);
+  rc = pls_gemm_tn(basis->W, basis->ldw, U, ldu, V, j, basis->m, j, basis->m, 1.0, 0.0, stream);  // W symmetric
+  if (rc) return rc;
+  return pls_gemm_tn(basis->Kzx, basis->ldkzx, V, j, F, ldf, basis->n, j, basis->m, 1.0, 0.0, stream);
+}
+
+// shared tail of the IPB update: out = [U +] -eta*D - eta*M*V + sqrt(2 eta) e
+static int ipb_finish(const pls_ipb_desc *basis, const double *U, int64_t ldu, const double *D, const double *V,
+                      int64_t j, double eta, const pls_noise_desc *noise, double *out, int64_t ldo, int add_u,
+                      double *xi_buf, double *e_buf, hipStream_t st) {
+  NoiseP nz = make_noisep(noise);
+  if (nz.kind == PLS_NOISE_PHILOX) {
+    if (!basis->LcT) return fail(PLS_ERR_INVALID_ARGUMENT, "ipb: Philox noise needs the Cholesky factor LcT");
+    hipLaunchKernelGGL(normal_fill_kernel, dim3((unsigned)cdiv(j, 256), rows_grid(cdiv(basis->m, 8) * 4)), dim3(256), 0, st,
+                       xi_buf, j, basis->m, j, nz.seed, nz.step, nz.j_offset);
+    int rc = check_launch("normal_fill");
+    if (rc) return rc;
+    // e = Lc xi :  L[k][i] = LcT[k][i] = Lc[i][k]
+    rc = pls_gemm_tn(basis->LcT, basis->ldlct, xi_buf, j, e_buf, j, basis->m, j, basis->m, 1.0, 0.0, st);
+    if (rc) return rc;
+    nz.kind = PLS_NOISE_INJECTED;
+    nz.xi = e_buf;
+    nz.ldxi = j;
+  }
+  hipLaunchKernelGGL(langevin_update_kernel, dim3((unsigned)cdiv(j, 256), rows_grid(cdiv(basis->m, 8) * 4)), dim3(256), 0, st,
+                     out, ldo, U, ldu, D, j, V, j, (const double *)nullptr, (double)basis->m, basis->m, j, eta,
+                     sqrt(2.0 * eta), add_u, nz);
+  return check_launch("langevin_update");
+}
+
+int pls_ipb_particle_update(const pls_ipb_desc *basis, const double *U, int64_t ldu, const double *G, int64_t ldg,
+                            int64_t j, double eta, const pls_noise_desc *noise, double *dU, int64_t lddu,
+                            void *workspace, size_t workspace_bytes, void *stream) {
+  int rc = validate_ipb(basis);
+  if (rc) return rc;
+  rc = validate_noise(noise, basis->m);
+  if (rc) return rc;
+  PLS_REQUIRE(U && G && dU && j >= 0 && ldu >= j && ldg >= j && lddu >= j, "ipb_particle_update: bad arguments");
+  PLS_REQUIRE(eta >= 0.0, "ipb_particle_update: step size must be >= 0");
+  if (j == 0) return PLS_OK;
+  const size_t mj = align_up((size_t)basis->m * j * sizeof(double), 256);
+  if (!workspace || workspace_bytes < 4 * mj)
+    return fail(PLS_ERR_WORKSPACE_TOO_SMALL, "ipb_particle_update: workspace %zu < %zu bytes", workspace_bytes, 4 * mj);
+  char *w = static_cast<char *>(workspace);
+  double *V = reinterpret_cast<double *>(w), *D = reinterpret_cast<double *>(w + mj);
+  double *xi = reinterpret_cast<double *>(w + 2 * mj), *e = reinterpret_cast<double *>(w + 3 * mj);
+  rc = pls_gemm_tn(basis->W, basis->ldw, U, ldu, V, j, basis->m, j, basis->m, 1.0, 0.0, stream);
+  if (rc) return rc;
+  rc = pls_gemm_tn(basis->Kxz, basis->ldkxz, G, ldg, D, j, basis->m, j, basis->n, 1.0, 0.0, stream);
+  if (rc) return rc;
+  return ipb_finish(basis, U, ldu, D, V, j, eta, noise, dU, lddu, 0, xi, e, S(stream));
+}
+
+size_t pls_ipb_step_workspace_bytes(const pls_ipb_desc *basis, int64_t j, int64_t n_chunk) {
+  if (!basis || j <= 0) return 0;
+  if (n_chunk <= 0 || n_chunk > basis->n) n_chunk = basis->n;
+  return 4 * align_up((size_t)basis->m * j * sizeof(double), 256) + (size_t)n_chunk * j * sizeof(double);
+}
+
+int pls_ipb_step(const pls_ipb_desc *basis, const pls_cost_desc *cost, const double *y, double *U, int64_t ldu, int64_t j,
+                 double eta, const pls_noise_desc *noise, double *out, int64_t ldo, int32_t out_mode, void *workspace,
+                 size_t workspace_bytes, void *stream) {
+  int rc = validate_ipb(basis);
+  if (rc) return rc;
+  rc = validate_cost(cost);
+  if (rc) return rc;
+  rc = validate_noise(noise, basis->m);
+  if (rc) return rc;
+  PLS_REQUIRE(U && out && y, "ipb_step: NULL pointer");
+  PLS_REQUIRE(out != U, "ipb_step: out must not alias U");
+  PLS_REQUIRE(j >= 0 && ldu >= j && ldo >= j && eta >= 0.0, "ipb_step: bad sizes");
+  PLS_REQUIRE(out_mode == 0 || out_mode == 1, "ipb_step: out_mode must be 0 or 1");
+  if (j == 0) return PLS_OK;
+  const size_t mj = align_up((size_t)basis->m * j * sizeof(double), 256);
+  if (!workspace || workspace_bytes < 4 * mj + (size_t)128 * j * sizeof(double))
+    return fail(PLS_ERR_WORKSPACE_TOO_SMALL, "ipb_step: workspace %zu bytes, need at least %zu", workspace_bytes,
+                pls_ipb_step_workspace_bytes(basis, j, 128));
+  char *w = static_cast<char *>(workspace);
+  double *V = reinterpret_cast<double *>(w), *D = reinterpret_cast<double *>(w + mj);
+  double *xi = reinterpret_cast<double *>(w + 2 * mj), *e = reinterpret_cast<double *>(w + 3 * mj);
+  double *Gbuf = reinterpret_cast<double *>(w + 4 * mj);
+  const int64_t n_chunk = pick_chunk(basis->n, workspace_bytes - 4 * mj, j, 0);
+  hipStream_t st = S(stream);
+  rc = pls_gemm_tn(basis->W, basis->ldw, U, ldu, V, j, basis->m, j, basis->m, 1.0, 0.0, stream);
+  if (rc) return rc;
+  rc = stream_drift(basis->Kzx, basis->ldkzx, basis->Kxz, basis->ldkxz, basis->m, basis->n, V, j, j, make_costp(cost), y,
+                    D, j, Gbuf, n_chunk, st);
+  if (rc) return rc;
+  return ipb_finish(basis, U, ldu, D, V, j, eta, noise, out, ldo, out_mode, xi, e, st);
+}
+
+size_t pls_ipb_energy_workspace_bytes(const pls_ipb_desc *basis, int64_t j, int64_t n_chunk) {
+  if (!basis || j <= 0) return 0;
+  if (n_chunk <= 0 || n_chunk > basis->n) n_chunk = basis->n;
+  return align_up((size_t)basis->m * j * sizeof(double), 256) + (size_t)cdiv(n_chunk, 64) * j * sizeof(double);
+}
+
+int pls_ipb_energy(const pls_ipb_desc *basis, const pls_cost_desc *cost, const double *y, const double *U, int64_t ldu,
+                   int64_t j, double *e, void *workspace, size_t workspace_bytes, void *stream) {
+  int rc = validate_ipb(basis);
+  if (rc) return rc;
+  rc = validate_cost(cost);
+  if (rc) return rc;
+  PLS_REQUIRE(U && e && y && j >= 0 && ldu >= j, "ipb_energy: bad arguments");
+  if (j == 0) return PLS_OK;
+  const size_t mj = align_up((size_t)basis->m * j * sizeof(double), 256);
+  if (!workspace || workspace_bytes < mj + 2 * (size_t)j * sizeof(double))
+    return fail(PLS_ERR_WORKSPACE_TOO_SMALL, "ipb_energy: workspace %zu bytes too small", workspace_bytes);
+  double *V = static_cast<double *>(workspace);
+  double *partial = reinterpret_cast<double *>(static_cast<char *>(workspace) + mj);
+  const int64_t max_parts = (int64_t)((workspace_bytes - mj) / ((size_t)j * sizeof(double)));
+  int64_t n_chunk = max_parts * 64;
+  if (n_chunk > basis->n) n_chunk = basis->n;
+  else n_chunk = n_chunk / 128 * 128;
+  rc = pls_gemm_tn(basis->W, basis->ldw, U, ldu, V, j, basis->m, j, basis->m, 1.0, 0.0, stream);
+  if (rc) return rc;
+  return stream_cost(basis->Kzx, basis->ldkzx, basis->m, basis->n, V, j, j, make_costp(cost), y, partial, n_chunk, e, 2, V,
+                     j, basis->m, nullptr, 0.5 * (double)basis->m, S(stream));
+}
+
+}  // extern "C"
