@@ -1,0 +1,288 @@
+#!/usr/bin/env python3
+"""Langevin steps/sec of the MI355X hot path on BASELINE.json's headline configuration
+(configs[1]: synthetic UCI-style regression, N=1e5, M=1024, J=8192, RBF/ARD kernel, Gaussian cost, fp64).
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+One "step" = particles <- particles + PLS.calculate_particle_update(particles, eta) for ALL J particles
+(the loop body of the reference's experiments/profiler/main.py:77-82).  The particle axis is sharded over the
+ranks (strong scaling: J is fixed); the step has no collective.
+
+Rank 0 prints ONE JSON line.  `value` is the like-for-like path: the same 4*N*M*J flop per step the reference
+performs (F = A^T U, d cost/d f, A G), i.e. the kernel that also serves the Poisson / Bernoulli / Student-t costs.
+The Gaussian/identity algebraic shortcut (B = A A^T precomputed, 2*M^2*J flop per step; README.md:9's O(M^3 + J M^2))
+is measured in the same run and reported under "gaussian_fast_path" -- never mixed into `value`.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix (= vector) peak, AMD datasheet; MI355X_MICROARCH.md has no fp64 row
+HBM_PEAK_GBS = 8000.0
+
+CONFIGS = {
+    # name: (N, M, J, D, cost)
+    "c2": dict(n=100_000, m=1024, j=8192, d=8, cost="gaussian", eta=1e-5, obs=0.01,
+               workload="configs[1]: synthetic regression N=1e5 M=1024 J=8192 D=8, RBF/ARD, ONB + Gaussian/identity, fp64"),
+    "c3": dict(n=50_000, m=512, j=16384, d=1, cost="poisson", eta=1e-6, obs=None,
+               workload="configs[2]: Poisson (f^2 link) regression N=5e4 M=512 J=16384 D=1, ONB, fp64"),
+    "small": dict(n=4096, m=128, j=512, d=4, cost="gaussian", eta=1e-4, obs=0.01,
+                  workload="smoke-sized regression N=4096 M=128 J=512"),
+}
+
+
+T0 = time.perf_counter()
+
+
+def log(msg):
+    print(f"[bench +{time.perf_counter() - T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def make_data(cfg, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    n, m, d = cfg["n"], cfg["m"], cfg["d"]
+    if d == 1:
+        x = torch.linspace(-3, 3, n, dtype=torch.float64).reshape(-1, 1)
+    else:
+        x = torch.rand(n, d, generator=g, dtype=torch.float64) * 2 - 1
+    z = x[torch.randperm(n, generator=g)[:m]].clone()
+    w = torch.randn(d, generator=g, dtype=torch.float64)
+    fstar = torch.sin(2.0 * (x @ w))
+    if cfg["cost"] == "poisson":
+        y = torch.poisson((2.0 * fstar) ** 2 + 0.1, generator=g)
+    else:
+        y = fstar + 0.1 * torch.randn(n, generator=g, dtype=torch.float64)
+    ls = 0.5 + torch.rand(d, generator=torch.Generator().manual_seed(1), dtype=torch.float64)
+    if d == 1:
+        ls = ls * 0.2
+    return x, z, y, ls
+
+
+def cpu_baseline(cfg, x, z, y, ls, lam_all, vec_all):
+    """The oracle ("port": faithful torch-CPU restatement of the reference's step, oracle/pls_oracle.py) timed on this
+    box's host cores on a bounded sample: two particle-subset sizes, linear in J, extrapolated to the full J."""
+    from oracle import pls_oracle as O
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        ob = O.OrthonormalBasis.__new__(O.OrthonormalBasis)  # reuse the spectrum already computed for the GPU basis
+        kern = O.RBFARDKernel(ls, 1.0)
+        ob.base_kernel, ob.x_induce = kern, z
+        ob.base_gram_induce = None
+        ob.base_gram_induce_train = torch.empty(z.shape[0], x.shape[0])
+        for r0 in range(0, x.shape[0], 8192):  # chunked k(Z,X): the broadcasted build would need N*M*D doubles
+            ob.base_gram_induce_train[:, r0:r0 + 8192] = kern(z, x[r0:r0 + 8192])
+        ob.eigenvalues, ob.eigenvectors = lam_all, vec_all
+        ob.scaled_eigenvectors = vec_all / torch.sqrt(lam_all.shape[0] * lam_all)[None, :]
+        if cfg["cost"] == "poisson":
+            oc = O.PoissonCost(y, O.SquareLink())
+        else:
+            oc = O.GaussianCost(cfg["obs"], y, O.IdentityLink())
+        pls = O.PLS(ob, oc)
+        mk = lam_all.shape[0]
+        times = {}
+        j_full = cfg["j"]
+        j_samples = sorted({max(64, j_full // 16), max(128, j_full // 8)})
+        log(f"cpu baseline: k(Z,X) built on the host, {cores} threads")
+        for js in j_samples:
+            log(f"cpu baseline: timing oracle steps at J={js}")
+            u = torch.randn(mk, js, generator=torch.Generator().manual_seed(3))
+            u += pls.calculate_particle_update(u, cfg["eta"])  # warm-up
+            t0 = time.perf_counter()
+            reps = 2
+            for _ in range(reps):
+                u += pls.calculate_particle_update(u, cfg["eta"])  # faithful: eigh(I) noise, dense diag @ U, full F and G
+            times[js] = (time.perf_counter() - t0) / reps
+        (j1, t1), (j2, t2) = sorted(times.items())
+        slope = (t2 - t1) / (j2 - j1)
+        t_full = t1 + slope * (j_full - j1)
+        return {
+            "value": 1.0 / t_full,
+            "unit": "steps/s",
+            "cores": cores,
+            "kind": "port",
+            "sample": f"oracle step (reference op order incl. per-step eigh(I) noise) at J={j1} ({t1:.2f} s/step) and J={j2} "
+                      f"({t2:.2f} s/step) of {j_full}, 1 warm-up + 2 timed steps each, linear-in-J extrapolation to J={j_full} "
+                      f"({t_full:.2f} s/step)",
+        }
+    finally:
+        torch.set_default_dtype(prev)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workspace-gb", type=float, default=8.0, help="cap of the per-step G-chunk workspace")
+    args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    import torch.distributed as dist
+
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world)  # RCCL; used for the barrier / max-time only
+
+    import projected_langevin_sampling_amd as pkg
+    from projected_langevin_sampling_amd import distributed as D
+    from projected_langevin_sampling_amd.basis import NoiseSpec, OrthonormalBasis
+    from projected_langevin_sampling_amd.costs import GaussianCost, PoissonCost
+    from projected_langevin_sampling_amd.link_functions import IdentityLinkFunction, SquareLinkFunction
+
+    L = pkg._lib
+    x, z, y, ls = make_data(cfg)
+    log("synthetic data ready")
+    t_setup = time.perf_counter()
+    kernel = pkg.PLSKernel(pkg.ARDKernel(ls, 1.0), z)
+    basis = OrthonormalBasis(kernel, z, x, eigenvalue_threshold=0.0, verbose=False, keep_gram=False)
+    basis.workspace_bytes = int(args.workspace_gb * (1 << 30))
+    mk = basis.approximation_dimension
+    cost = (PoissonCost(y, SquareLinkFunction()) if cfg["cost"] == "poisson"
+            else GaussianCost(cfg["obs"], y, IdentityLinkFunction()))
+    j_total = cfg["j"]
+    j0, j1 = D.attach_shard(basis, j_total, rank, world)
+    j_loc = j1 - j0
+    eta = cfg["eta"]
+    assert eta / basis.eigenvalues.min().item() < 2.0, "step size too large for the kept spectrum (SURVEY H5)"
+    # identical initial particles for any GPU count: one seeded (Mk, J) draw, every rank keeps its columns
+    u_full = torch.normal(0.0, 1.0, size=(mk, j_total), generator=torch.Generator().manual_seed(0), dtype=torch.float64)
+    ping = u_full[:, j0:j1].contiguous().cuda()
+    pong = torch.empty_like(ping)
+    del u_full
+    if cfg["cost"] == "gaussian":
+        basis.prepare_gaussian(cost.y_device())
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t_setup
+    log(f"basis ready (M_k = {mk}), setup {t_setup:.2f} s")
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run(force_generic: bool, steps: int, warmup: int, timeline: bool):
+        nonlocal ping, pong
+        step_id = [0]
+
+        def one():
+            nonlocal ping, pong
+            basis.fused_step(cost, ping, eta, out=pong, new_state=True, force_generic=force_generic,
+                             noise=NoiseSpec(seed=1234, step=step_id[0], j_offset=j0))
+            step_id[0] += 1
+            ping, pong = pong, ping
+
+        for _ in range(warmup):
+            one()
+        barrier()
+        tl = L.Timeline(capacity=max(64, steps * 64)) if timeline else None
+        if tl:
+            tl.__enter__()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one()
+        barrier()
+        dt = time.perf_counter() - t0
+        if tl:
+            tl.__exit__(None, None, None)
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = t.item()
+        assert torch.isfinite(ping).all().item(), "particles diverged"
+        return dt, (tl.summary() if tl else {})
+
+    n, m = cfg["n"], mk
+    # ---- like-for-like path (headline) ----
+    dt, tl = run(force_generic=True, steps=args.steps, warmup=args.warmup, timeline=True)
+    ms_per_step = dt / args.steps * 1e3
+    value = args.steps / dt
+    log(f"like-for-like path: {ms_per_step:.2f} ms/step")
+    gemm_ms = sum(tl[k]["total_ms"] for k in ("gemm_cost_deriv", "gemm_store") if k in tl)
+    gemm_launches = sum(tl[k]["launches"] for k in ("gemm_cost_deriv", "gemm_store") if k in tl)
+    flop_per_step_rank = 4.0 * n * m * j_loc
+    achieved = flop_per_step_rank * args.steps / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    roofline = {
+        "kernel": "gemm_tn_f64_kernel<128,128,64,64,16,*> (cost-derivative + back-projection launches of the step)",
+        "bound": "mfma",
+        "achieved": achieved,
+        "peak": FP64_MFMA_PEAK_TFLOPS,
+        "unit": "TFLOP/s",
+        "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+        "traffic": None,
+        "flop_per_launch": flop_per_step_rank / max(gemm_launches / args.steps, 1),
+        "avg_launch_ms": gemm_ms / max(gemm_launches, 1),
+        "launches_per_step": gemm_launches / args.steps,
+        "per_kernel_ms": {k: round(v["avg_ms"], 4) for k, v in tl.items()},
+    }
+    out = {
+        "metric": "Langevin steps/sec",
+        "value": value,
+        "unit": "steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": cfg["workload"], "N": n, "M": cfg["m"], "M_k": mk, "J": j_total, "J_per_gpu": j_loc,
+                   "path": "like-for-like: F=A^T U -> d cost/d f -> A G, 4*N*M*J flop/step", "step_size": eta,
+                   "parallelism": f"J-sharded x{world}, no per-step collective", "setup_s": round(t_setup, 2)},
+        "roofline": roofline,
+    }
+    # ---- Gaussian algebraic fast path, same run ----
+    if cfg["cost"] == "gaussian":
+        fsteps = max(args.steps * 10, 50)
+        dtf, tlf = run(force_generic=False, steps=fsteps, warmup=max(args.warmup, 5), timeline=True)
+        log(f"gaussian fast path: {dtf / fsteps * 1e3:.3f} ms/step")
+        k = tlf.get("gemm_langevin_gaussian", {"total_ms": 0.0, "launches": 0, "avg_ms": 0.0})
+        fl = 2.0 * m * m * j_loc
+        ach = fl / (k["avg_ms"] * 1e-3) / 1e12 if k["avg_ms"] else 0.0
+        out["gaussian_fast_path"] = {
+            "value": fsteps / dtf, "unit": "steps/s", "steps": fsteps, "ms_per_step": dtf / fsteps * 1e3,
+            "note": "B = A A^T, c = A y precomputed once (setup); per step 2*Mk^2*J flop in ONE fused kernel "
+                    "(contraction + prior drift + Philox noise + axpy)",
+            "roofline": {"kernel": "gemm_tn_f64_kernel<...,EpiLangevinGaussian>", "bound": "mfma", "achieved": ach,
+                         "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
+                         "traffic": None, "avg_launch_ms": k["avg_ms"]},
+        }
+    # ---- CPU baseline (rank 0, N=1 only) ----
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        lam_all, vec_all = basis.eigenvalues.cpu(), basis.eigenvectors.cpu()
+        out["cpu_baseline"] = cpu_baseline(cfg, x, z, y, ls, lam_all, vec_all)
+        out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -135,6 +135,22 @@ typedef struct {
 const char *pls_last_error(void);
 int pls_abi_version(void);
 
+/* Per-launch timeline (measurement only; off by default, zero cost when off).  Between begin and end, every
+ * kernel the calling thread launches through this library is bracketed by two HIP events recorded on the
+ * launch's own stream.  pls_timeline_end synchronises on them and returns, per launch, its duration in
+ * milliseconds and a pls_kernel_tag; it returns the number of launches seen (<= capacity recorded). */
+typedef enum {
+  PLS_TAG_GEMM_STORE = 1,            /* gemm_tn_f64, plain / accumulate epilogue (back-projection A G, setup GEMMs) */
+  PLS_TAG_GEMM_COST_DERIV = 2,       /* gemm_tn_f64, F tile -> d cost / d f epilogue */
+  PLS_TAG_GEMM_COST_VALUE = 3,       /* gemm_tn_f64, F tile -> per-column cost partial sums */
+  PLS_TAG_GEMM_LANGEVIN_GAUSSIAN = 4,/* gemm_tn_f64, B U with the whole Langevin update in the epilogue */
+  PLS_TAG_LANGEVIN_UPDATE = 5,
+  PLS_TAG_KERNEL_GRAM = 6,
+  PLS_TAG_OTHER = 7
+} pls_kernel_tag;
+int pls_timeline_begin(int32_t capacity);
+int pls_timeline_end(float *ms, int32_t *tags, int32_t capacity, int32_t *count);
+
 /* ---------------------------------------------------------------------------------------------
  * Primitive operators (un-fused entry points; a user-defined Python cost or basis composes these)
  * ------------------------------------------------------------------------------------------- */
@@ -162,6 +178,10 @@ int pls_cost_derivative(const pls_cost_desc *cost, const double *F, int64_t ldf,
 size_t pls_cost_value_workspace_bytes(int64_t n, int64_t j);
 int pls_cost_value(const pls_cost_desc *cost, const double *F, int64_t ldf, const double *y, int64_t n, int64_t j,
                    double *c, void *workspace, size_t workspace_bytes, void *stream);
+
+/* out = link(in) element-wise (rows x cols).  Replaces PLSLinkFunction.transform (link_functions.py:30-80). */
+int pls_link_transform(int32_t link, double jitter, const double *in, int64_t ldin, int64_t rows, int64_t cols,
+                       double *out, int64_t ldout, void *stream);
 
 /* out(rows x J) standard normals from the library's counter-based generator (same stream the fused
  * step uses).  Replaces torch.normal at basis/base.py:55-63 and samplers.py:30-35 for on-device runs. */
@@ -214,6 +234,12 @@ size_t pls_onb_energy_workspace_bytes(const pls_onb_desc *basis, int64_t j, int6
 int pls_onb_energy(const pls_onb_desc *basis, const pls_cost_desc *cost, const double *y, const double *U,
                    int64_t ldu, int64_t j, double *e, void *workspace, size_t workspace_bytes, void *stream);
 
+/* e(J) = cost_j + 0.5 * sum_m U_mj^2 / lam_m with the cost vector handed in (cost may be NULL = zeros).
+ * Replaces OrthonormalBasis.calculate_energy_potential(particles, cost) (orthonormal.py:110-126) before its
+ * .mean().item(). */
+int pls_onb_prior_energy(const pls_onb_desc *basis, const double *U, int64_t ldu, int64_t j, const double *cost,
+                         double *e, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Inducing-point basis: step (setup = pls_kernel_gram + a host Cholesky)
  * ------------------------------------------------------------------------------------------- */
@@ -238,6 +264,11 @@ int pls_ipb_step(const pls_ipb_desc *basis, const pls_cost_desc *cost, const dou
 size_t pls_ipb_energy_workspace_bytes(const pls_ipb_desc *basis, int64_t j, int64_t n_chunk);
 int pls_ipb_energy(const pls_ipb_desc *basis, const pls_cost_desc *cost, const double *y, const double *U,
                    int64_t ldu, int64_t j, double *e, void *workspace, size_t workspace_bytes, void *stream);
+
+/* e(J) = cost_j + (M/2) * ||W U_j||^2 with the cost vector handed in (inducing_point.py:95-115).
+ * workspace: m*j doubles. */
+int pls_ipb_prior_energy(const pls_ipb_desc *basis, const double *U, int64_t ldu, int64_t j, const double *cost,
+                         double *e, void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -83,11 +83,14 @@ _CD, _ND, _OD, _ID = C.POINTER(CostDesc), C.POINTER(NoiseDesc), C.POINTER(OnbDes
 SIGNATURES = {
     "pls_last_error": (C.c_char_p, []),
     "pls_abi_version": (C.c_int, []),
+    "pls_timeline_begin": (C.c_int, [_I32]),
+    "pls_timeline_end": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_int32), _I32, C.POINTER(C.c_int32)]),
     "pls_kernel_gram": (C.c_int, [_I32, _P, _I64, _P, _I64, _I64, _P, _D, _P, _I64, _P]),
     "pls_gemm_tn": (C.c_int, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _D, _D, _P]),
     "pls_cost_derivative": (C.c_int, [_CD, _P, _I64, _P, _I64, _I64, _P, _I64, _P]),
     "pls_cost_value_workspace_bytes": (_SZ, [_I64, _I64]),
     "pls_cost_value": (C.c_int, [_CD, _P, _I64, _P, _I64, _I64, _P, _P, _SZ, _P]),
+    "pls_link_transform": (C.c_int, [_I32, _D, _P, _I64, _I64, _I64, _P, _I64, _P]),
     "pls_normal_fill": (C.c_int, [_P, _I64, _I64, _I64, _U64, _U64, _I64, _P]),
     "pls_onb_build_projection": (C.c_int, [_P, _I64, _P, _I64, _I64, _I64, _I64, _P, _I64, _P, _I64, _P]),
     "pls_onb_build_gaussian": (C.c_int, [_OD, _P, _P, _I64, _P, _P]),
@@ -97,6 +100,8 @@ SIGNATURES = {
     "pls_onb_step": (C.c_int, [_OD, _CD, _P, _P, _I64, _I64, _D, _ND, _P, _I64, _I32, _I32, _P, _SZ, _P]),
     "pls_onb_energy_workspace_bytes": (_SZ, [_OD, _I64, _I64]),
     "pls_onb_energy": (C.c_int, [_OD, _CD, _P, _P, _I64, _I64, _P, _P, _SZ, _P]),
+    "pls_onb_prior_energy": (C.c_int, [_OD, _P, _I64, _I64, _P, _P, _P]),
+    "pls_ipb_prior_energy": (C.c_int, [_ID, _P, _I64, _I64, _P, _P, _P, _SZ, _P]),
     "pls_ipb_forward": (C.c_int, [_ID, _P, _I64, _I64, _P, _I64, _P, _SZ, _P]),
     "pls_ipb_particle_update": (C.c_int, [_ID, _P, _I64, _P, _I64, _I64, _D, _ND, _P, _I64, _P, _SZ, _P]),
     "pls_ipb_step_workspace_bytes": (_SZ, [_ID, _I64, _I64]),
@@ -127,6 +132,44 @@ def load() -> C.CDLL:
         raise PlsHipError(f"libplship ABI {lib.pls_abi_version()} != 1")
     _lib = lib
     return lib
+
+
+TAG_NAMES = {1: "gemm_store", 2: "gemm_cost_deriv", 3: "gemm_cost_value", 4: "gemm_langevin_gaussian",
+             5: "langevin_update", 6: "kernel_gram", 7: "other"}
+
+
+class Timeline:
+    """with Timeline(capacity) as tl: ...launches...; tl.records -> [(tag_name, ms), ...] measured with HIP events
+    recorded on the launch stream around every libplship kernel launch of this thread."""
+
+    def __init__(self, capacity: int = 4096):
+        self.capacity = capacity
+        self.records: list[tuple[str, float]] = []
+        self.launches = 0
+
+    def __enter__(self):
+        check(load().pls_timeline_begin(self.capacity), "pls_timeline_begin")
+        return self
+
+    def __exit__(self, *exc):
+        ms = (C.c_float * self.capacity)()
+        tags = (C.c_int32 * self.capacity)()
+        count = C.c_int32(0)
+        check(load().pls_timeline_end(ms, tags, self.capacity, C.byref(count)), "pls_timeline_end")
+        self.launches = count.value
+        n = min(count.value, self.capacity)
+        self.records = [(TAG_NAMES.get(tags[i], "other"), float(ms[i])) for i in range(n)]
+        return False
+
+    def summary(self) -> dict:
+        out: dict[str, dict] = {}
+        for name, t in self.records:
+            d = out.setdefault(name, {"launches": 0, "total_ms": 0.0})
+            d["launches"] += 1
+            d["total_ms"] += t
+        for d in out.values():
+            d["avg_ms"] = d["total_ms"] / d["launches"]
+        return out
 
 
 def check(rc: int, what: str = "") -> None:

@@ -1,0 +1,134 @@
+"""Basis base class (drop-in for src/projected_langevin_sampling/basis/base.py:7-193)."""
+from __future__ import annotations
+
+from abc import ABC, abstractmethod
+from typing import Optional
+
+import torch
+
+from .. import _lib as L
+from ..kernel import _dev
+
+#: default cap of the per-step G-chunk workspace (bytes); bigger = fewer, larger GEMM launches
+DEFAULT_WORKSPACE_BYTES = 2 << 30
+
+
+class NoiseSpec:
+    """How one Langevin step gets its noise.
+    injected: a (M, J) device tensor used as-is (parity runs inject the oracle's noise);
+    philox:   libplship's counter-based stream keyed by (seed, step, row, j_offset + column)."""
+
+    def __init__(self, injected: torch.Tensor | None = None, seed: int | None = None, step: int = 0, j_offset: int = 0,
+                 none: bool = False):
+        self.injected, self.seed, self.step, self.j_offset, self.none = injected, seed, step, j_offset, none
+
+    def desc(self) -> L.NoiseDesc:
+        d = L.NoiseDesc()
+        if self.none:
+            d.kind = L.NOISE_NONE
+        elif self.injected is not None:
+            xi = L.require_gpu_tensor(self.injected, "noise")
+            assert xi.stride(-1) == 1
+            d.kind, d.xi, d.ldxi = L.NOISE_INJECTED, xi.data_ptr(), L.ld(xi)
+        else:
+            d.kind, d.seed, d.step, d.j_offset = L.NOISE_PHILOX, int(self.seed) & (2**64 - 1), int(self.step), int(self.j_offset)
+        return d
+
+
+class PLSBasis(ABC):
+    """Function-space basis: initialise particles, energy potential, particle update, predictive samples."""
+
+    def __init__(self, additional_predictive_noise_distribution: Optional[torch.distributions.Distribution] = None):
+        self.additional_predictive_noise_distribution = additional_predictive_noise_distribution
+        #: global column index of this rank's first particle (J-sharding, see distributed.py)
+        self.j_offset = 0
+        self._ws: dict = {}
+        self.workspace_bytes = DEFAULT_WORKSPACE_BYTES
+
+    @property
+    def approximation_dimension(self) -> int:
+        raise NotImplementedError
+
+    # ---- noise -------------------------------------------------------------------------------------------------
+    def _draw_noise_spec(self, noise: torch.Tensor | None) -> NoiseSpec:
+        """The reference draws the step noise from torch's GLOBAL CPU generator (samplers.py:30-35 with
+        generator=None), so callers make runs reproducible with set_seed() before the loop (runners.py:364).
+        Same contract here: one 63-bit draw from that generator keys the on-device Philox stream of this step."""
+        if noise is not None:
+            return NoiseSpec(injected=noise)
+        seed = int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())
+        return NoiseSpec(seed=seed, step=0, j_offset=self.j_offset)
+
+    def _workspace(self, nbytes: int, device) -> torch.Tensor:
+        key = str(device)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() * 8 < nbytes:
+            ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=device)
+            self._ws[key] = ws
+        return ws
+
+    # ---- particles ---------------------------------------------------------------------------------------------
+    def _initialise_particles_noise(self, number_of_particles: int, seed: int | None = None, mean: float = 0.0,
+                                    stdev: float = 1.0) -> torch.Tensor:
+        """basis/base.py:39-63: torch.normal on a CPU generator, size (M, J)."""
+        generator = None
+        if seed is not None:
+            generator = torch.Generator().manual_seed(seed)
+        return torch.normal(
+            mean=mean, std=stdev, size=(self.approximation_dimension, number_of_particles), generator=generator
+        )
+
+    @abstractmethod
+    def _initialise_particles(self, number_of_particles: int, noise_only: bool = True, seed: int | None = None) -> torch.Tensor:
+        raise NotImplementedError
+
+    def initialise_particles(self, number_of_particles: int, noise_only: bool = True, seed: int | None = None) -> torch.Tensor:
+        """basis/base.py:81-102; the particles always live on the MI355X as float64."""
+        return _dev(self._initialise_particles(number_of_particles=number_of_particles, noise_only=noise_only, seed=seed))
+
+    @abstractmethod
+    def calculate_untransformed_train_prediction_samples(self, particles: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError
+
+    @abstractmethod
+    def calculate_energy_potential(self, particles: torch.Tensor, cost: torch.Tensor) -> float:
+        raise NotImplementedError
+
+    @abstractmethod
+    def _calculate_particle_update(self, particles: torch.Tensor, cost_derivative: torch.Tensor, step_size: float,
+                                   noise: torch.Tensor | None = None) -> torch.Tensor:
+        raise NotImplementedError
+
+    def calculate_particle_update(self, particles: torch.Tensor, cost_derivative: torch.Tensor, step_size: float,
+                                  noise: torch.Tensor | None = None) -> torch.Tensor:
+        """basis/base.py:143-163 (same assertion and message)."""
+        assert (
+            particles.shape[0] == self.approximation_dimension
+        ), f"Particles have shape {particles.shape} but requires ({self.approximation_dimension}, J) dimension."
+        return self._calculate_particle_update(
+            particles=particles, cost_derivative=cost_derivative, step_size=step_size, noise=noise
+        )
+
+    @abstractmethod
+    def sample_predictive_noise(self, particles: torch.Tensor, x: torch.Tensor):
+        raise NotImplementedError
+
+    @abstractmethod
+    def predict_untransformed_samples(self, particles: torch.Tensor, x: torch.Tensor,
+                                      noise: torch.Tensor | None = None) -> torch.Tensor:
+        raise NotImplementedError
+
+    # ---- fused native path (used by PLS when the cost is native) -------------------------------------------------
+    def supports_fused_step(self) -> bool:
+        return False
+
+
+def padded_ld(cols: int) -> int:
+    """Leading dimension rounded up to 16 doubles (128 B): every row of a library-owned matrix starts on a full line."""
+    return (cols + 15) // 16 * 16
+
+
+def alloc_matrix(rows: int, cols: int, device) -> torch.Tensor:
+    """(rows, cols) float64 view with a padded leading dimension."""
+    ldm = padded_ld(cols)
+    return torch.empty((rows, ldm), dtype=torch.float64, device=device)[:, :cols]

@@ -1,0 +1,190 @@
+"""Inducing-point basis (drop-in for src/projected_langevin_sampling/basis/inducing_point.py:11-240)."""
+from __future__ import annotations
+
+import torch
+
+from .. import _lib as L
+from ..kernel import PLSKernel, _dev
+from ..samplers import sample_multivariate_normal
+from .base import NoiseSpec, PLSBasis, alloc_matrix
+from .orthonormal import _rows_contiguous
+
+
+class InducingPointBasis(PLSBasis):
+    """Particles are function values at the M inducing points (inducing_point.py:23-50).
+
+    The reference calls gpytorch.solve(k(Z,Z), .) twice per step and eigh(k(Z,Z)) once per step for the noise
+    (:130-137).  Here k(Z,Z) is factorised ONCE (host LAPACK Cholesky, fp64): W = k(Z,Z)^-1 and the factor L_c
+    are uploaded, the per-step solves become the fp64 MFMA contraction W U, and the noise is e = L_c xi
+    (same distribution N(0, k(Z,Z)) as the reference's Q sqrt(Lambda) xi; injected noise is used as-is)."""
+
+    def __init__(
+        self,
+        kernel: PLSKernel,
+        x_induce: torch.Tensor,
+        y_induce: torch.Tensor,
+        x_train: torch.Tensor,
+        additional_predictive_noise_distribution: torch.distributions.Distribution | None = None,
+    ):
+        super().__init__(additional_predictive_noise_distribution=additional_predictive_noise_distribution)
+        self.kernel = kernel
+        self.x_induce = x_induce  # (M, D)
+        self.y_induce = y_induce  # (M,)
+        self.gram_induce = self.kernel.forward(x1=x_induce, x2=x_induce)  # r(Z,Z)  :38-40
+        self.base_gram_induce = self.kernel.base_kernel(x1=x_induce, x2=x_induce)  # k(Z,Z)  :41-43
+        self.base_gram_induce_train = self.kernel.base_kernel(x1=x_induce, x2=x_train)  # k(Z,X) (M,N) :44-46
+        dev = self.base_gram_induce.device
+        m, n = self.base_gram_induce_train.shape
+        self._n = n
+        k_host = self.base_gram_induce.cpu()
+        chol = torch.linalg.cholesky(k_host)  # what gpytorch.solve does for M <= 800
+        self._W = _dev(torch.cholesky_inverse(chol))
+        self._LcT = _dev(chol.T)
+        # k(X,Z) as its own k-major operand for the back-projection k(Z,X) G
+        self._Kxz = alloc_matrix(n, m, dev)
+        self._Kxz.copy_(self.base_gram_induce_train.T)
+
+    @property
+    def approximation_dimension(self) -> int:
+        return self.x_induce.shape[0]  # :52-58
+
+    def _desc(self) -> L.IpbDesc:
+        d = L.IpbDesc()
+        d.m, d.n = self.approximation_dimension, self._n
+        d.Kzx, d.ldkzx = self.base_gram_induce_train.data_ptr(), L.ld(self.base_gram_induce_train)
+        d.Kxz, d.ldkxz = self._Kxz.data_ptr(), L.ld(self._Kxz)
+        d.W, d.ldw = self._W.data_ptr(), L.ld(self._W)
+        d.LcT, d.ldlct = self._LcT.data_ptr(), L.ld(self._LcT)
+        return d
+
+    def _initialise_particles(self, number_of_particles: int, noise_only: bool = True, seed: int | None = None) -> torch.Tensor:
+        particle_noise = self._initialise_particles_noise(number_of_particles=number_of_particles, seed=seed)
+        return particle_noise if noise_only else (self.y_induce.cpu()[:, None] + particle_noise)  # :77-79
+
+    def calculate_untransformed_train_prediction_samples(self, particles: torch.Tensor) -> torch.Tensor:
+        """F = k(X,Z) k(Z,Z)^-1 U  (:81-93)."""
+        u = _rows_contiguous(L.require_gpu_tensor(particles, "particles"))
+        j = u.shape[1]
+        m = self.approximation_dimension
+        f = torch.empty((self._n, j), dtype=torch.float64, device=u.device)
+        ws = self._workspace(m * j * 8, u.device)
+        L.check(
+            L.load().pls_ipb_forward(self._desc(), u.data_ptr(), L.ld(u), j, f.data_ptr(), max(j, 1), ws.data_ptr(),
+                                     ws.numel() * 8, L.stream_ptr()),
+            "pls_ipb_forward",
+        )
+        return f
+
+    def particle_energy_potential(self, particles: torch.Tensor, cost: torch.Tensor | None) -> torch.Tensor:
+        """e_j = cost_j + M/2 ||k(Z,Z)^-1 U_j||^2  (:95-114)."""
+        u = _rows_contiguous(L.require_gpu_tensor(particles, "particles"))
+        j = u.shape[1]
+        c = None if cost is None else L.require_gpu_tensor(cost, "cost").contiguous()
+        e = torch.empty(j, dtype=torch.float64, device=u.device)
+        ws = self._workspace(self.approximation_dimension * j * 8, u.device)
+        L.check(
+            L.load().pls_ipb_prior_energy(self._desc(), u.data_ptr(), L.ld(u), j, L.ptr(c), e.data_ptr(), ws.data_ptr(),
+                                          ws.numel() * 8, L.stream_ptr()),
+            "pls_ipb_prior_energy",
+        )
+        return e
+
+    def calculate_energy_potential(self, particles: torch.Tensor, cost: torch.Tensor) -> float:
+        return self.particle_energy_potential(particles, cost).mean().item()  # :115
+
+    def _calculate_particle_update(self, particles: torch.Tensor, cost_derivative: torch.Tensor, step_size: float,
+                                   noise: torch.Tensor | None = None) -> torch.Tensor:
+        """dU = -eta k(Z,X) G - eta M k(Z,Z)^-1 U + sqrt(2 eta) e  (:117-150); ``noise`` is e itself."""
+        u = _rows_contiguous(L.require_gpu_tensor(particles, "particles"))
+        g = _rows_contiguous(L.require_gpu_tensor(cost_derivative, "cost_derivative"))
+        j = u.shape[1]
+        assert g.shape == (self._n, j), f"cost_derivative has shape {tuple(g.shape)}, expected ({self._n}, {j})"
+        du = torch.empty_like(u, memory_format=torch.contiguous_format)
+        m = self.approximation_dimension
+        ws_bytes = 4 * ((m * j * 8 + 255) // 256 * 256)
+        ws = self._workspace(ws_bytes, u.device)
+        nd = self._draw_noise_spec(noise).desc()
+        L.check(
+            L.load().pls_ipb_particle_update(self._desc(), u.data_ptr(), L.ld(u), g.data_ptr(), L.ld(g), j, float(step_size), nd,
+                                             du.data_ptr(), L.ld(du), ws.data_ptr(), ws_bytes, L.stream_ptr()),
+            "pls_ipb_particle_update",
+        )
+        return du
+
+    def supports_fused_step(self) -> bool:
+        return True
+
+    def fused_step(self, cost, particles: torch.Tensor, step_size: float, out: torch.Tensor | None = None,
+                   new_state: bool = False, noise: NoiseSpec | None = None, force_generic: bool = False) -> torch.Tensor:
+        u = _rows_contiguous(L.require_gpu_tensor(particles, "particles"))
+        j = u.shape[1]
+        if out is None:
+            out = torch.empty_like(u, memory_format=torch.contiguous_format)
+        if j == 0:
+            return out
+        assert out.data_ptr() != u.data_ptr(), "fused_step: out must not alias particles"
+        lib = L.load()
+        desc = self._desc()
+        need_min = lib.pls_ipb_step_workspace_bytes(desc, j, 128)
+        need_full = lib.pls_ipb_step_workspace_bytes(desc, j, self._n)
+        ws_bytes = max(need_min, min(need_full, self.workspace_bytes))
+        ws = self._workspace(ws_bytes, u.device)
+        nd = (noise if noise is not None else self._draw_noise_spec(None)).desc()
+        L.check(
+            lib.pls_ipb_step(desc, cost.desc(), cost.y_device().data_ptr(), u.data_ptr(), L.ld(u), j, float(step_size), nd,
+                             out.data_ptr(), L.ld(out), L.OUT_NEW_STATE if new_state else L.OUT_DELTA, ws.data_ptr(), ws_bytes,
+                             L.stream_ptr()),
+            "pls_ipb_step",
+        )
+        return out
+
+    def fused_particle_energy(self, cost, particles: torch.Tensor) -> torch.Tensor:
+        u = _rows_contiguous(L.require_gpu_tensor(particles, "particles"))
+        j = u.shape[1]
+        lib = L.load()
+        desc = self._desc()
+        ws_bytes = lib.pls_ipb_energy_workspace_bytes(desc, j, self._n)
+        ws = self._workspace(ws_bytes, u.device)
+        e = torch.empty(j, dtype=torch.float64, device=u.device)
+        L.check(
+            lib.pls_ipb_energy(desc, cost.desc(), cost.y_device().data_ptr(), u.data_ptr(), L.ld(u), j, e.data_ptr(),
+                               ws.data_ptr(), ws_bytes, L.stream_ptr()),
+            "pls_ipb_energy",
+        )
+        return e
+
+    # ---- prediction ---------------------------------------------------------------------------------
+    def sample_predictive_noise(self, particles: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+        """G([Z, x]) ~ N(0, r([Z,x],[Z,x]))  (:152-202)."""
+        gram_x = self.kernel.forward(x1=x, x2=x, additional_approximation_samples=x)
+        gram_induce_x = self.kernel.forward(x1=self.x_induce, x2=x, additional_approximation_samples=x)
+        noise_covariance = torch.cat(
+            [torch.cat([self.gram_induce, gram_induce_x], dim=1), torch.cat([gram_induce_x.T, gram_x], dim=1)], dim=0
+        )
+        predictive_noise = sample_multivariate_normal(
+            mean=torch.zeros(noise_covariance.shape[0]), cov=noise_covariance, size=(particles.shape[1],)
+        ).T
+        if self.additional_predictive_noise_distribution is not None:
+            extra = self.additional_predictive_noise_distribution.sample(predictive_noise.shape).reshape(predictive_noise.shape)
+            predictive_noise = predictive_noise + _dev(extra)
+        return predictive_noise
+
+    def predict_untransformed_samples(self, particles: torch.Tensor, x: torch.Tensor,
+                                      noise: torch.Tensor | None = None) -> torch.Tensor:
+        """G(x) + r(x,Z) r(Z,Z)^-1 (U - G(Z))  (:204-240); the M x M solve is a host Cholesky (one-time per call)."""
+        gram_induce_x = self.kernel.forward(x1=self.x_induce, x2=x, additional_approximation_samples=x)  # r(Z,x) (M,N*)
+        gram_induce = self.kernel.forward(x1=self.x_induce, x2=self.x_induce, additional_approximation_samples=x)
+        if noise is None:
+            noise = self.sample_predictive_noise(particles=particles, x=x)
+        m = self.approximation_dimension
+        delta = (L.require_gpu_tensor(particles, "particles") - noise[:m, :]).contiguous()
+        w = _dev(torch.cholesky_inverse(torch.linalg.cholesky(gram_induce.cpu())))
+        j, nstar = delta.shape[1], gram_induce_x.shape[1]
+        lib = L.load()
+        v = torch.empty((m, j), dtype=torch.float64, device=delta.device)
+        L.check(lib.pls_gemm_tn(w.data_ptr(), m, delta.data_ptr(), L.ld(delta), v.data_ptr(), max(j, 1), m, j, m, 1.0, 0.0,
+                                L.stream_ptr()), "pls_gemm_tn")
+        out = noise[m:, :].contiguous().clone()
+        L.check(lib.pls_gemm_tn(gram_induce_x.data_ptr(), L.ld(gram_induce_x), v.data_ptr(), max(j, 1), out.data_ptr(), L.ld(out),
+                                nstar, j, m, 1.0, 1.0, L.stream_ptr()), "pls_gemm_tn")
+        return out

@@ -1,0 +1,248 @@
+"""Orthonormal basis (drop-in for src/projected_langevin_sampling/basis/orthonormal.py:10-244)."""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from .. import _lib as L
+from ..kernel import PLSKernel, _dev
+from ..samplers import sample_multivariate_normal
+from .base import NoiseSpec, PLSBasis, alloc_matrix
+
+
+class OrthonormalBasis(PLSBasis):
+    """Particles live in the eigenbasis of k(Z,Z)/M (orthonormal.py:22-68).
+
+    Setup (once): k(Z,Z), k(Z,X) on the GPU; eigh on the host LAPACK like the reference (the eigenvector gauge is
+    implementation defined, so parity runs may pass ``spectrum=(eigenvalues, eigenvectors)``); then the projection
+    A = V~^T k(Z,X) and its transpose are built once on the GPU instead of re-associating three matrices per step
+    (orthonormal.py:106-108, :151-155)."""
+
+    def __init__(
+        self,
+        kernel: PLSKernel,
+        x_induce: torch.Tensor,
+        x_train: torch.Tensor,
+        eigenvalue_threshold: float = 0.0,
+        additional_predictive_noise_distribution: torch.distributions.Distribution | None = None,
+        spectrum: tuple[torch.Tensor, torch.Tensor] | None = None,
+        keep_gram: bool = True,
+        verbose: bool = True,
+    ):
+        super().__init__(additional_predictive_noise_distribution=additional_predictive_noise_distribution)
+        self.kernel = kernel
+        self.x_induce = x_induce  # (M, D)
+        m = x_induce.shape[0]
+        self.base_gram_induce = self.kernel.base_kernel(x1=x_induce, x2=x_induce)  # k(Z,Z) (M, M)   :36-38
+        base_gram_induce_train = self.kernel.base_kernel(x1=x_induce, x2=x_train)  # k(Z,X) (M, N)   :39-41
+        dev = self.base_gram_induce.device
+        if spectrum is None:
+            eigenvalues, eigenvectors = torch.linalg.eigh((1 / m) * self.base_gram_induce.cpu())  # :46-48
+        else:
+            eigenvalues, eigenvectors = (t.detach().cpu().to(torch.float64) for t in spectrum)
+        idx = torch.where(eigenvalues > eigenvalue_threshold)[0]  # :52
+        eigenvalues = eigenvalues[idx].real
+        eigenvectors = eigenvectors[:, idx].real
+        if verbose:
+            print(f"Number of eigenvalues kept: {eigenvalues.shape[0]} out of {m}")  # :58-60
+        mk = eigenvalues.shape[0]
+        scaled = torch.multiply(torch.reciprocal(torch.sqrt(mk * eigenvalues))[None, :], eigenvectors)  # :63-68
+        self.eigenvalues = _dev(eigenvalues)
+        self.eigenvectors = _dev(eigenvectors)
+        self.scaled_eigenvectors = _dev(scaled)  # (M, Mk)
+        n = base_gram_induce_train.shape[1]
+        self._n = n
+        self._A = alloc_matrix(mk, n, dev)
+        self._At = alloc_matrix(n, mk, dev)
+        if mk > 0:
+            L.check(
+                L.load().pls_onb_build_projection(
+                    self.scaled_eigenvectors.data_ptr(), L.ld(self.scaled_eigenvectors), base_gram_induce_train.data_ptr(),
+                    L.ld(base_gram_induce_train), m, mk, n, self._A.data_ptr(), L.ld(self._A), self._At.data_ptr(),
+                    L.ld(self._At), L.stream_ptr(),
+                ),
+                "pls_onb_build_projection",
+            )
+        self.base_gram_induce_train = base_gram_induce_train if keep_gram else None
+        self._B = None  # Gaussian fast path constants, keyed by the y they were built from
+        self._c = None
+        self._gauss_key = None
+
+    @property
+    def approximation_dimension(self) -> int:
+        return self.eigenvalues.shape[0]  # :70-76
+
+    # ---- descriptors ---------------------------------------------------------------------------------------------
+    def _desc(self, with_gaussian: bool = False) -> L.OnbDesc:
+        d = L.OnbDesc()
+        d.mk, d.n = self.approximation_dimension, self._n
+        d.A, d.lda = self._A.data_ptr(), L.ld(self._A)
+        d.At, d.ldat = self._At.data_ptr(), L.ld(self._At)
+        d.lam = self.eigenvalues.data_ptr()
+        if with_gaussian and self._B is not None:
+            d.B, d.ldb, d.c = self._B.data_ptr(), L.ld(self._B), self._c.data_ptr()
+        return d
+
+    def prepare_gaussian(self, y_dev: torch.Tensor) -> None:
+        """B = A A^T, c = A y: turns the Gaussian/identity step into the M_k x M_k x J contraction (README.md:9)."""
+        key = (y_dev.data_ptr(), y_dev._version)
+        if self._gauss_key == key:
+            return
+        mk = self.approximation_dimension
+        self._B = alloc_matrix(mk, mk, y_dev.device)
+        self._c = torch.empty(mk, dtype=torch.float64, device=y_dev.device)
+        L.check(
+            L.load().pls_onb_build_gaussian(self._desc(), y_dev.data_ptr(), self._B.data_ptr(), L.ld(self._B),
+                                            self._c.data_ptr(), L.stream_ptr()),
+            "pls_onb_build_gaussian",
+        )
+        self._gauss_key = key
+
+    # ---- reference API ---------------------------------------------------------------------------------------------
+    def _initialise_particles(self, number_of_particles: int, noise_only: bool = True, seed: int | None = None) -> torch.Tensor:
+        if not noise_only:
+            raise ValueError("For ONB base, noise_only must be True.")  # :91-92
+        return self._initialise_particles_noise(number_of_particles=number_of_particles, seed=seed)
+
+    def calculate_untransformed_train_prediction_samples(self, particles: torch.Tensor) -> torch.Tensor:
+        """F = k(X,Z) V~ U = A^T U  (N, J)  (:98-108)."""
+        u = _rows_contiguous(L.require_gpu_tensor(particles, "particles"))
+        j = u.shape[1]
+        f = torch.empty((self._n, j), dtype=torch.float64, device=u.device)
+        L.check(
+            L.load().pls_onb_forward(self._desc(), u.data_ptr(), L.ld(u), j, f.data_ptr(), max(j, 1), L.stream_ptr()),
+            "pls_onb_forward",
+        )
+        return f
+
+    def particle_energy_potential(self, particles: torch.Tensor, cost: torch.Tensor | None) -> torch.Tensor:
+        """Per-particle energy e_j = cost_j + 1/2 sum_m U_mj^2 / lambda_m  (J,)  (:120-125)."""
+        u = _rows_contiguous(L.require_gpu_tensor(particles, "particles"))
+        j = u.shape[1]
+        c = None if cost is None else L.require_gpu_tensor(cost, "cost").contiguous()
+        e = torch.empty(j, dtype=torch.float64, device=u.device)
+        L.check(
+            L.load().pls_onb_prior_energy(self._desc(), u.data_ptr(), L.ld(u), j, L.ptr(c), e.data_ptr(), L.stream_ptr()),
+            "pls_onb_prior_energy",
+        )
+        return e
+
+    def calculate_energy_potential(self, particles: torch.Tensor, cost: torch.Tensor) -> float:
+        return self.particle_energy_potential(particles, cost).mean().item()  # :126 (host sync)
+
+    def _calculate_particle_update(self, particles: torch.Tensor, cost_derivative: torch.Tensor, step_size: float,
+                                   noise: torch.Tensor | None = None) -> torch.Tensor:
+        """dU = -eta V~^T k(Z,X) G - eta Lambda^-1 U + sqrt(2 eta) xi  (:128-159)."""
+        u = _rows_contiguous(L.require_gpu_tensor(particles, "particles"))
+        g = _rows_contiguous(L.require_gpu_tensor(cost_derivative, "cost_derivative"))
+        j = u.shape[1]
+        assert g.shape == (self._n, j), f"cost_derivative has shape {tuple(g.shape)}, expected ({self._n}, {j})"
+        du = torch.empty_like(u, memory_format=torch.contiguous_format)
+        nd = self._draw_noise_spec(noise).desc()
+        L.check(
+            L.load().pls_onb_particle_update(self._desc(), u.data_ptr(), L.ld(u), g.data_ptr(), L.ld(g), j, float(step_size),
+                                             nd, du.data_ptr(), L.ld(du), L.stream_ptr()),
+            "pls_onb_particle_update",
+        )
+        return du
+
+    # ---- fused native step ------------------------------------------------------------------------------------------
+    def supports_fused_step(self) -> bool:
+        return True
+
+    def fused_step(self, cost, particles: torch.Tensor, step_size: float, out: torch.Tensor | None = None,
+                   new_state: bool = False, noise: NoiseSpec | None = None, force_generic: bool = False) -> torch.Tensor:
+        """One whole Langevin step in libplship (pls_onb_step): returns dU, or U + dU when new_state."""
+        u = _rows_contiguous(L.require_gpu_tensor(particles, "particles"))
+        j = u.shape[1]
+        if out is None:
+            out = torch.empty_like(u, memory_format=torch.contiguous_format)
+        if j == 0:
+            return out
+        assert out.data_ptr() != u.data_ptr(), "fused_step: out must not alias particles"
+        y = cost.y_device()
+        cd = cost.desc()
+        gaussian = cd.cost == L.COST_GAUSSIAN and cd.link == L.LINK_IDENTITY and not force_generic
+        if gaussian:
+            self.prepare_gaussian(y)
+        lib = L.load()
+        desc = self._desc(with_gaussian=gaussian)
+        if gaussian:
+            ws, ws_bytes = None, 0
+        else:
+            need_min = lib.pls_onb_step_workspace_bytes(desc, j, 128)
+            need_full = lib.pls_onb_step_workspace_bytes(desc, j, self._n)
+            ws_bytes = max(need_min, min(need_full, self.workspace_bytes))
+            ws = self._workspace(ws_bytes, u.device)
+        nd = (noise if noise is not None else self._draw_noise_spec(None)).desc()
+        L.check(
+            lib.pls_onb_step(desc, cd, y.data_ptr(), u.data_ptr(), L.ld(u), j, float(step_size), nd, out.data_ptr(), L.ld(out),
+                             L.OUT_NEW_STATE if new_state else L.OUT_DELTA, 1 if force_generic else 0, L.ptr(ws), ws_bytes,
+                             L.stream_ptr()),
+            "pls_onb_step",
+        )
+        return out
+
+    def fused_particle_energy(self, cost, particles: torch.Tensor) -> torch.Tensor:
+        """Per-particle energy with the cost evaluated inside the F GEMM's epilogue (pls_onb_energy)."""
+        u = _rows_contiguous(L.require_gpu_tensor(particles, "particles"))
+        j = u.shape[1]
+        lib = L.load()
+        desc = self._desc()
+        ws_bytes = min(lib.pls_onb_energy_workspace_bytes(desc, j, self._n), max(self.workspace_bytes, 4 * j * 8))
+        ws = self._workspace(ws_bytes, u.device)
+        e = torch.empty(j, dtype=torch.float64, device=u.device)
+        L.check(
+            lib.pls_onb_energy(desc, cost.desc(), cost.y_device().data_ptr(), u.data_ptr(), L.ld(u), j, e.data_ptr(),
+                               ws.data_ptr(), ws_bytes, L.stream_ptr()),
+            "pls_onb_energy",
+        )
+        return e
+
+    # ---- prediction (one-time, not on the step path) -----------------------------------------------
+    def sample_predictive_noise(self, particles: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+        """(M_k + N*, J) joint Gaussian noise (:161-214); the (M_k+N*) eigh runs on the host like the reference."""
+        gram_x = self.kernel.forward(x1=x, x2=x, additional_approximation_samples=x)
+        base_gram_x_induce = self.kernel.base_kernel(x1=x, x2=self.x_induce)
+        off_diagonal_block = base_gram_x_induce @ self.scaled_eigenvectors @ torch.diag(self.eigenvalues)
+        noise_covariance = torch.cat(
+            [
+                torch.cat([torch.diag(self.eigenvalues), off_diagonal_block.T], dim=1),
+                torch.cat([off_diagonal_block, gram_x], dim=1),
+            ],
+            dim=0,
+        )
+        predictive_noise = sample_multivariate_normal(
+            mean=torch.zeros(noise_covariance.shape[0]), cov=noise_covariance, size=(particles.shape[1],)
+        ).T
+        if self.additional_predictive_noise_distribution is not None:
+            extra = self.additional_predictive_noise_distribution.sample(predictive_noise.shape).reshape(predictive_noise.shape)
+            predictive_noise = predictive_noise + _dev(extra)
+        return predictive_noise
+
+    def predict_untransformed_samples(self, particles: torch.Tensor, x: torch.Tensor,
+                                      noise: torch.Tensor | None = None) -> torch.Tensor:
+        """G(x) + k(x,Z) V~ (U - G(Z))  (:216-244)."""
+        base_gram_induce_x = self.kernel.base_kernel(x1=self.x_induce, x2=x)  # k(Z, x) (M, N*): k-major operand
+        if noise is None:
+            noise = self.sample_predictive_noise(particles=particles, x=x)
+        mk = self.approximation_dimension
+        delta = (L.require_gpu_tensor(particles, "particles") - noise[:mk, :]).contiguous()
+        j = delta.shape[1]
+        nstar = base_gram_induce_x.shape[1]
+        lib = L.load()
+        # P (N* x Mk) = k(x,Z) V~ ; then P delta via the k-major form with L = P^T = V~^T k(Z,x)
+        pt = torch.empty((mk, nstar), dtype=torch.float64, device=delta.device)
+        L.check(lib.pls_gemm_tn(self.scaled_eigenvectors.data_ptr(), L.ld(self.scaled_eigenvectors), base_gram_induce_x.data_ptr(),
+                                L.ld(base_gram_induce_x), pt.data_ptr(), max(nstar, 1), mk, nstar, self.x_induce.shape[0], 1.0, 0.0,
+                                L.stream_ptr()), "pls_gemm_tn")
+        out = noise[mk:, :].contiguous().clone()
+        L.check(lib.pls_gemm_tn(pt.data_ptr(), max(nstar, 1), delta.data_ptr(), L.ld(delta), out.data_ptr(), L.ld(out), nstar, j, mk,
+                                1.0, 1.0, L.stream_ptr()), "pls_gemm_tn")
+        return out
+
+
+def _rows_contiguous(t: torch.Tensor) -> torch.Tensor:
+    assert t.dim() == 2, "expected a 2-D tensor"
+    return t if t.stride(1) == 1 or t.shape[1] <= 1 and t.is_contiguous() else t.contiguous()

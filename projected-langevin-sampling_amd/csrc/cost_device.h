@@ -37,9 +37,11 @@ __device__ inline double link_eval(int link, double f, double jit, double *slope
       *slope = 2.0 * f;
       return f * f;
     case PLS_LINK_SIGMOID: {  // :67-70
-      double raw = 1.0 / (1.0 + exp(-f));
+      const double ex = exp(-f);
+      double raw = 1.0 / (1.0 + ex);
       bool inside = (raw >= jit) && (raw <= 1.0 - jit);
-      *slope = inside ? raw * (1.0 - raw) : 0.0;
+      // d/df 1/(1+e^-f) = e^-f / (1+e^-f)^2, the form autograd differentiates (raw*(1-raw) cancels near raw = 1)
+      *slope = inside ? ex * raw * raw : 0.0;
       return clipd(raw, jit, 1.0 - jit);
     }
     default: {  // PLS_LINK_PROBIT :39-45

@@ -21,6 +21,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace plship {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -57,100 +59,100 @@ struct AccFrag {
   double4_t v[TI][TJ];
 };
 
-template <int BI, int BJ, int WI, int WJ, int BK, class Epilogue>
-__global__ __launch_bounds__((BI / WI) * (BJ / WJ) * 64) void gemm_tn_f64_kernel(GemmShape g, Epilogue epi) {
+// The k-loop, specialised at compile time on
+//   VEC : operands are 16-B aligned with even leading dimensions -> one global_load_dwordx4 per pair
+//   EDGE: the tile overhangs I or J -> overhanging lanes read column 0 of their row (always inside the matrix)
+//         and are zeroed when the pair is written to LDS (after the MFMAs, so the loads stay in flight)
+// so that the steady-state loop contains no branch and no use of a loaded value before the MFMAs of the step.
+template <int BI, int BJ, int WI, int WJ, int BK, bool VEC, bool EDGE, int TI, int TJ>
+__device__ __forceinline__ void gemm_tn_mainloop(const GemmShape &g, int64_t i0, int64_t j0, double *lds,
+                                                 AccFrag<TI, TJ> &acc) {
   constexpr int NW = (BI / WI) * (BJ / WJ);
   constexpr int NT = NW * 64;
-  constexpr int TI = WI / 16, TJ = WJ / 16;
   constexpr int PAD = 16;
   constexpr int SL = BI + PAD, SR = BJ + PAD;
   constexpr int LROWS = NT / (BI / 2);  // k-rows of the L tile covered by one pass of all threads
   constexpr int RROWS = NT / (BJ / 2);
   constexpr int LPASS = BK / LROWS, RPASS = BK / RROWS;
   static_assert(BK % LROWS == 0 && BK % RROWS == 0 && BK % 4 == 0, "tile/thread mismatch");
-
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  double *Ls = lds;                 // [2][BK][SL]
-  double *Rs = lds + 2 * BK * SL;   // [2][BK][SR]
-
-  int tile_i, tile_j;
-  gemm_tile_coords(blockIdx.x, g.nti, g.ntj, tile_i, tile_j);
-  const int64_t i0 = (int64_t)tile_i * BI, j0 = (int64_t)tile_j * BJ;
+  double *Ls = lds;                // [2][BK][SL]
+  double *Rs = lds + 2 * BK * SL;  // [2][BK][SR]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wi = (wave / (BJ / WJ)) * WI, wj = (wave % (BJ / WJ)) * WJ;
   const int q = lane >> 4, c16 = lane & 15;
 
-  // global-load coordinates of this thread
   const int lcol = (tid % (BI / 2)) * 2, lrow = tid / (BI / 2);
   const int rcol = (tid % (BJ / 2)) * 2, rrow = tid / (BJ / 2);
-  const bool lvec = ((g.ldl & 1) == 0) && ((reinterpret_cast<uintptr_t>(g.L) & 15) == 0);
-  const bool rvec = ((g.ldr & 1) == 0) && ((reinterpret_cast<uintptr_t>(g.R) & 15) == 0);
-  const double *Lp = g.L + i0 + lcol;
-  const double *Rp = g.R + j0 + rcol;
-  const int64_t lrem = g.I - i0 - lcol;  // valid columns from this thread's first column
-  const int64_t rrem = g.J - j0 - rcol;
+  const int64_t lrem = EDGE ? g.I - i0 - lcol : 2;  // valid columns from this thread's first column
+  const int64_t rrem = EDGE ? g.J - j0 - rcol : 2;
+  const bool l0 = lrem >= 1, l1 = lrem >= 2, r0 = rrem >= 1, r1 = rrem >= 2;
+  const double *Lq = g.L + (l0 ? i0 + lcol : 0);
+  const double *Rq = g.R + (r0 ? j0 + rcol : 0);
 
   double2_t lreg[LPASS], rreg[RPASS];
+  bool lkin[LPASS], rkin[RPASS];  // only meaningful for the K-tail step
 
-  auto load_global = [&](int64_t k0) {
+  auto load_global = [&](int64_t k0, auto tail_tag) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
 #pragma unroll
     for (int p = 0; p < LPASS; ++p) {
-      const int64_t k = k0 + lrow + p * LROWS;
-      double2_t v = {0.0, 0.0};
-      if (k < g.K) {
-        const double *src = Lp + k * g.ldl;
-        if (lvec && lrem >= 2) {
-          v = *reinterpret_cast<const double2_t *>(src);
-        } else {
-          if (lrem >= 1) v.x = src[0];
-          if (lrem >= 2) v.y = src[1];
-        }
+      int64_t k = k0 + lrow + p * LROWS;
+      lkin[p] = true;
+      if (TAIL) {
+        lkin[p] = k < g.K;
+        k = lkin[p] ? k : g.K - 1;
       }
-      lreg[p] = v;
+      const double *src = Lq + k * g.ldl;
+      if (VEC) {
+        lreg[p] = *reinterpret_cast<const double2_t *>(src);
+      } else {
+        lreg[p].x = src[0];
+        lreg[p].y = l1 ? src[1] : 0.0;
+      }
     }
 #pragma unroll
     for (int p = 0; p < RPASS; ++p) {
-      const int64_t k = k0 + rrow + p * RROWS;
-      double2_t v = {0.0, 0.0};
-      if (k < g.K) {
-        const double *src = Rp + k * g.ldr;
-        if (rvec && rrem >= 2) {
-          v = *reinterpret_cast<const double2_t *>(src);
-        } else {
-          if (rrem >= 1) v.x = src[0];
-          if (rrem >= 2) v.y = src[1];
-        }
+      int64_t k = k0 + rrow + p * RROWS;
+      rkin[p] = true;
+      if (TAIL) {
+        rkin[p] = k < g.K;
+        k = rkin[p] ? k : g.K - 1;
       }
-      rreg[p] = v;
+      const double *src = Rq + k * g.ldr;
+      if (VEC) {
+        rreg[p] = *reinterpret_cast<const double2_t *>(src);
+      } else {
+        rreg[p].x = src[0];
+        rreg[p].y = r1 ? src[1] : 0.0;
+      }
     }
   };
-  auto store_lds = [&](int buf) {
+  auto store_lds = [&](int buf, auto tail_tag) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
     double *l = Ls + buf * BK * SL;
     double *r = Rs + buf * BK * SR;
 #pragma unroll
-    for (int p = 0; p < LPASS; ++p)
-      *reinterpret_cast<double2_t *>(l + (lrow + p * LROWS) * SL + lcol) = lreg[p];
+    for (int p = 0; p < LPASS; ++p) {
+      double2_t v = lreg[p];
+      if (EDGE || TAIL) {
+        v.x = (l0 && lkin[p]) ? v.x : 0.0;
+        v.y = (l1 && lkin[p]) ? v.y : 0.0;
+      }
+      *reinterpret_cast<double2_t *>(l + (lrow + p * LROWS) * SL + lcol) = v;
+    }
 #pragma unroll
-    for (int p = 0; p < RPASS; ++p)
-      *reinterpret_cast<double2_t *>(r + (rrow + p * RROWS) * SR + rcol) = rreg[p];
+    for (int p = 0; p < RPASS; ++p) {
+      double2_t v = rreg[p];
+      if (EDGE || TAIL) {
+        v.x = (r0 && rkin[p]) ? v.x : 0.0;
+        v.y = (r1 && rkin[p]) ? v.y : 0.0;
+      }
+      *reinterpret_cast<double2_t *>(r + (rrow + p * RROWS) * SR + rcol) = v;
+    }
   };
-
-  AccFrag<TI, TJ> acc;
-#pragma unroll
-  for (int a = 0; a < TI; ++a)
-#pragma unroll
-    for (int b = 0; b < TJ; ++b) acc.v[a][b] = double4_t{0.0, 0.0, 0.0, 0.0};
-
-  const int64_t nk = (g.K + BK - 1) / BK;
-  load_global(0);
-  store_lds(0);
-  __syncthreads();
-
-  for (int64_t kt = 0; kt < nk; ++kt) {
-    const int buf = (int)(kt & 1);
-    if (kt + 1 < nk) load_global((kt + 1) * BK);
+  auto compute = [&](int buf) {
     const double *l = Ls + buf * BK * SL + q * SL + wi + c16;
     const double *r = Rs + buf * BK * SR + q * SR + wj + c16;
 #pragma unroll
@@ -166,37 +168,142 @@ __global__ __launch_bounds__((BI / WI) * (BJ / WJ) * 64) void gemm_tn_f64_kernel
         for (int tb = 0; tb < TJ; ++tb)
           acc.v[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ta], b[tb], acc.v[ta][tb], 0, 0, 0);
     }
-    if (kt + 1 < nk) store_lds(buf ^ 1);
+  };
+
+  using full_t = std::integral_constant<bool, false>;
+  using tail_t = std::integral_constant<bool, true>;
+  const int64_t nk = (g.K + BK - 1) / BK;
+  const int64_t nk_full = g.K / BK;
+  if (g.K > 0) {  // (K == 0: acc stays zero; the clamp k = K-1 would be out of bounds)
+    if (nk_full > 0) {
+      load_global(0, full_t{});
+      store_lds(0, full_t{});
+    } else {
+      load_global(0, tail_t{});
+      store_lds(0, tail_t{});
+    }
+  }
+  __syncthreads();
+
+  int64_t kt = 0;
+  for (; kt + 1 < nk_full; ++kt) {  // steady state: the next step is a full one
+    const int buf = (int)(kt & 1);
+    load_global((kt + 1) * BK, full_t{});
+    compute(buf);
+    store_lds(buf ^ 1, full_t{});
     __syncthreads();
   }
+  for (; kt < nk; ++kt) {  // last full step and the K tail
+    const int buf = (int)(kt & 1);
+    const bool more = kt + 1 < nk;
+    if (more) load_global((kt + 1) * BK, tail_t{});
+    compute(buf);
+    if (more) store_lds(buf ^ 1, tail_t{});
+    __syncthreads();
+  }
+}
 
+template <int BI, int BJ, int WI, int WJ, int BK, int MINW, class Epilogue>
+__global__ __launch_bounds__((BI / WI) * (BJ / WJ) * 64, MINW) void gemm_tn_f64_kernel(GemmShape g, Epilogue epi) {
+  constexpr int TI = WI / 16, TJ = WJ / 16;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+
+  int tile_i, tile_j;
+  gemm_tile_coords(blockIdx.x, g.nti, g.ntj, tile_i, tile_j);
+  const int64_t i0 = (int64_t)tile_i * BI, j0 = (int64_t)tile_j * BJ;
+
+  AccFrag<TI, TJ> acc;
+#pragma unroll
+  for (int a = 0; a < TI; ++a)
+#pragma unroll
+    for (int b = 0; b < TJ; ++b) acc.v[a][b] = double4_t{0.0, 0.0, 0.0, 0.0};
+
+  // vector path: every row start is 16-B aligned; a pair that straddles the I/J edge stays inside its row's
+  // padding because the leading dimension is even
+  const bool vec = ((g.ldl & 1) == 0) && ((reinterpret_cast<uintptr_t>(g.L) & 15) == 0) && ((g.ldr & 1) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(g.R) & 15) == 0);
+  const bool edge = (i0 + BI > g.I) || (j0 + BJ > g.J);
+  if (vec) {
+    if (!edge)
+      gemm_tn_mainloop<BI, BJ, WI, WJ, BK, true, false>(g, i0, j0, lds, acc);
+    else
+      gemm_tn_mainloop<BI, BJ, WI, WJ, BK, true, true>(g, i0, j0, lds, acc);
+  } else {
+    gemm_tn_mainloop<BI, BJ, WI, WJ, BK, false, true>(g, i0, j0, lds, acc);
+  }
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wi = (wave / (BJ / WJ)) * WI, wj = (wave % (BJ / WJ)) * WJ;
   epi.template apply<TI, TJ>(acc, i0 + wi, j0 + wj, lane, wave, g.I, g.J, tile_i, lds);
 }
 
 // ---- epilogues ------------------------------------------------------------------------------------------------
-// apply(acc, iw, jw, lane, wave, I, J, tile_i, lds): iw/jw = global coordinates of the wave's block of C.
+// The accumulator block of a wave leaves the registers through LDS, 16 rows at a time: the MFMA layout (4 rows x
+// 16 columns per register) is written with compile-time register indices, then read back row-wise so that
+//   * a lane owns ONE column and walks down the rows in a run-time loop (the per-element code -- cost derivative,
+//     Box-Muller -- exists once, not once per accumulator register),
+//   * every global store / load of the epilogue is a contiguous row segment of WJ doubles,
+//   * rows i and i+4 (one Philox pair, philox.h) are handed to the functor together.
+// fn(i_lo, j, v_lo, hi_valid, v_hi) is called for every column j < J and row pair (i_lo, i_lo + 4) with i_lo < I.
+constexpr int EPI_PAD = 2;  // doubles; keeps the 4 rows a ds_write_b64 touches on different banks
 
-#define PLS_FOR_EACH_ACC(BODY)                                         \
-  _Pragma("unroll") for (int ta = 0; ta < TI; ++ta)                    \
-      _Pragma("unroll") for (int tb = 0; tb < TJ; ++tb)                \
-          _Pragma("unroll") for (int r = 0; r < 4; ++r) {              \
-    const int64_t i = iw + ta * 16 + r * 4 + (lane >> 4);             \
-    const int64_t j = jw + tb * 16 + (lane & 15);                     \
-    const double v = acc.v[ta][tb][r];                                 \
-    if (i < I && j < J) { BODY }                                       \
-  }
+template <int WJ>
+constexpr int epi_lds_doubles_per_wave() { return 16 * (WJ + EPI_PAD); }
+
+template <int TI, int TJ, class Fn>
+__device__ __forceinline__ void epilogue_row_pairs(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int wave,
+                                                   int64_t I, int64_t J, double *lds, Fn &&fn) {
+  constexpr int WJ = TJ * 16;
+  constexpr int STRIDE = WJ + EPI_PAD;
+  constexpr int RPI = 64 / WJ;  // row pairs handled per iteration by the 64 lanes (1 for WJ = 64, 2 for WJ = 32)
+  static_assert(WJ == 64 || WJ == 32, "wave tile width");
+  double *w = lds + wave * epi_lds_doubles_per_wave<WJ>();
+  const int q = lane >> 4, c16 = lane & 15;
+  const int col = lane % WJ, sub = lane / WJ;
+  const int64_t j = jw + col;
+  auto pass = [&](auto ta_tag) {
+    constexpr int ta = decltype(ta_tag)::value;
+#pragma unroll
+    for (int tb = 0; tb < TJ; ++tb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w[(4 * r + q) * STRIDE + tb * 16 + c16] = acc.v[ta][tb][r];
+    __syncthreads();
+    for (int it = 0; it < 8 / RPI; ++it) {
+      const int p = it * RPI + sub;                // pair index 0..7 inside the 16-row slab
+      const int rr = (p >> 2) * 8 + (p & 3);       // rows rr and rr + 4
+      const int64_t i_lo = iw + ta * 16 + rr;
+      const double v_lo = w[rr * STRIDE + col], v_hi = w[(rr + 4) * STRIDE + col];
+      if (i_lo < I && j < J) fn(i_lo, j, v_lo, i_lo + 4 < I, v_hi);
+    }
+    __syncthreads();
+  };
+  if constexpr (TI >= 1) pass(std::integral_constant<int, 0>{});
+  if constexpr (TI >= 2) pass(std::integral_constant<int, 1>{});
+  if constexpr (TI >= 3) pass(std::integral_constant<int, 2>{});
+  if constexpr (TI >= 4) pass(std::integral_constant<int, 3>{});
+  static_assert(TI <= 4, "extend the pass list");
+}
 
 struct EpiStore {  // C = alpha * acc + beta * C
+  static constexpr int kTag = 1;  // PLS_TAG_GEMM_STORE
   double *C;
   int64_t ldc;
   double alpha, beta;
   template <int TI, int TJ>
-  __device__ void apply(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int, int64_t I, int64_t J, int,
-                        double *) const {
+  __device__ void apply(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int wave, int64_t I, int64_t J,
+                        int, double *lds) const {
     if (beta == 0.0) {
-      PLS_FOR_EACH_ACC(C[i * ldc + j] = alpha * v;)
+      epilogue_row_pairs<TI, TJ>(acc, iw, jw, lane, wave, I, J, lds,
+                                 [&](int64_t i, int64_t j, double v0, bool hi, double v1) {
+                                   C[i * ldc + j] = alpha * v0;
+                                   if (hi) C[(i + 4) * ldc + j] = alpha * v1;
+                                 });
     } else {
-      PLS_FOR_EACH_ACC(C[i * ldc + j] = alpha * v + beta * C[i * ldc + j];)
+      epilogue_row_pairs<TI, TJ>(acc, iw, jw, lane, wave, I, J, lds,
+                                 [&](int64_t i, int64_t j, double v0, bool hi, double v1) {
+                                   C[i * ldc + j] = alpha * v0 + beta * C[i * ldc + j];
+                                   if (hi) C[(i + 4) * ldc + j] = alpha * v1 + beta * C[(i + 4) * ldc + j];
+                                 });
     }
   }
 };

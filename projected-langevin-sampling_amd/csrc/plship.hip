@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <string>
+#include <vector>
 
 #include "../../include/plship.h"
 #include "cost_device.h"
@@ -40,6 +41,35 @@ static int check_launch(const char *what) {
   return PLS_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// per-launch timeline (pls_timeline_begin / _end): events live outside the step path's no-allocation rule because
+// they are created in begin(), never inside a launch function
+// ---------------------------------------------------------------------------------------------------------------
+struct Timeline {
+  bool on = false;
+  int capacity = 0, count = 0;
+  std::vector<hipEvent_t> ev;  // 2 per launch
+  std::vector<int> tag;
+};
+static thread_local Timeline g_tl;
+
+struct LaunchScope {  // records the bracketing events of one launch when the timeline is on
+  hipStream_t st;
+  int slot;
+  LaunchScope(int tag, hipStream_t s) : st(s), slot(-1) {
+    if (!g_tl.on) return;
+    if (g_tl.count < g_tl.capacity) {
+      slot = g_tl.count;
+      g_tl.tag[slot] = tag;
+      (void)hipEventRecord(g_tl.ev[2 * slot], st);
+    }
+    ++g_tl.count;
+  }
+  ~LaunchScope() {
+    if (slot >= 0) (void)hipEventRecord(g_tl.ev[2 * slot + 1], st);
+  }
+};
+
 static inline hipStream_t S(void *stream) { return reinterpret_cast<hipStream_t>(stream); }
 __host__ __device__ static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -50,20 +80,26 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 
 // G = d cost / d f (acc = F tile); rows of this launch are rows [row0, row0 + I) of y.
 struct EpiCostDeriv {
+  static constexpr int kTag = PLS_TAG_GEMM_COST_DERIV;
   double *G;
   int64_t ldg;
   const double *y;
   CostP cp;
   template <int TI, int TJ>
-  __device__ void apply(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int, int64_t I, int64_t J, int,
-                        double *) const {
-    PLS_FOR_EACH_ACC(G[i * ldg + j] = cost_deriv(cp, y[i], v);)
+  __device__ void apply(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int wave, int64_t I, int64_t J,
+                        int, double *lds) const {
+    epilogue_row_pairs<TI, TJ>(acc, iw, jw, lane, wave, I, J, lds,
+                               [&](int64_t i, int64_t j, double v0, bool hi, double v1) {
+                                 G[i * ldg + j] = cost_deriv(cp, y[i], v0);
+                                 if (hi) G[(i + 4) * ldg + j] = cost_deriv(cp, y[i + 4], v1);
+                               });
   }
 };
 
 // partial[tile_i][j] = sum over the tile's rows of cost(y_i, acc_ij); deterministic order.
 template <int BI, int BJ, int WI, int WJ>
 struct EpiCostValue {
+  static constexpr int kTag = PLS_TAG_GEMM_COST_VALUE;
   double *partial;
   int64_t ldp;
   const double *y;
@@ -71,37 +107,23 @@ struct EpiCostValue {
   template <int TI, int TJ>
   __device__ void apply(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int wave, int64_t I, int64_t J,
                         int tile_i, double *lds) const {
-    double s[TJ];
-#pragma unroll
-    for (int tb = 0; tb < TJ; ++tb) s[tb] = 0.0;
-#pragma unroll
-    for (int ta = 0; ta < TI; ++ta)
-#pragma unroll
-      for (int tb = 0; tb < TJ; ++tb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int64_t i = iw + ta * 16 + r * 4 + (lane >> 4);
-          const int64_t j = jw + tb * 16 + (lane & 15);
-          if (i < I && j < J) s[tb] += cost_value(cp, y[i], acc.v[ta][tb][r]);
-        }
-#pragma unroll
-    for (int tb = 0; tb < TJ; ++tb) {
-      s[tb] += __shfl_xor(s[tb], 16);
-      s[tb] += __shfl_xor(s[tb], 32);
-    }
+    double s = 0.0;  // this lane's column, summed over the rows it is handed (fixed order)
+    epilogue_row_pairs<TI, TJ>(acc, iw, jw, lane, wave, I, J, lds,
+                               [&](int64_t i, int64_t, double v0, bool hi, double v1) {
+                                 s += cost_value(cp, y[i], v0);
+                                 if (hi) s += cost_value(cp, y[i + 4], v1);
+                               });
+    if (WJ == 32) s += __shfl_xor(s, 32);  // two lane halves share the 32 columns
     constexpr int NWJ = BJ / WJ, NWI = BI / WI;
     const int wrow = wave / NWJ, wcol = wave % NWJ;
-    // lds[wrow][BJ]
-    if (lane < 16) {
-#pragma unroll
-      for (int tb = 0; tb < TJ; ++tb) lds[wrow * BJ + wcol * WJ + tb * 16 + lane] = s[tb];
-    }
+    double *red = lds;  // [NWI][BJ]; epilogue_row_pairs ended with a barrier, its slabs are dead
+    if (lane < WJ) red[wrow * BJ + wcol * WJ + lane] = s;
     __syncthreads();
     const int t = threadIdx.x;
     if (t < BJ) {
       double tot = 0.0;
 #pragma unroll
-      for (int w = 0; w < NWI; ++w) tot += lds[w * BJ + t];
+      for (int w = 0; w < NWI; ++w) tot += red[w * BJ + t];
       const int64_t j = (jw - wcol * WJ) + t;
       if (j < J) partial[(int64_t)tile_i * ldp + j] = tot;
     }
@@ -137,6 +159,7 @@ static NoiseP make_noisep(const pls_noise_desc *n) {
 
 // Gaussian/identity fast path: acc = (B U)_ij;  out = [U +] -eta*(acc - c_i)/sigma2 - eta*U_ij/lam_i + sqrt(2 eta)*xi_ij
 struct EpiLangevinGaussian {
+  static constexpr int kTag = PLS_TAG_GEMM_LANGEVIN_GAUSSIAN;
   double *out;
   int64_t ldo;
   const double *U;
@@ -146,35 +169,28 @@ struct EpiLangevinGaussian {
   int add_u;
   NoiseP nz;
   template <int TI, int TJ>
-  __device__ void apply(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int, int64_t I, int64_t J, int,
-                        double *) const {
-#pragma unroll
-    for (int ta = 0; ta < TI; ++ta)
-#pragma unroll
-      for (int tb = 0; tb < TJ; ++tb) {
-        const int64_t j = jw + tb * 16 + (lane & 15);
-#pragma unroll
-        for (int rp = 0; rp < 2; ++rp) {  // rows (r = 2rp, 2rp+1) differ by 4: one Philox pair
-          const int64_t ib = iw + ta * 16 + rp * 8 + (lane >> 4);
+  __device__ void apply(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int wave, int64_t I, int64_t J,
+                        int, double *lds) const {
+    epilogue_row_pairs<TI, TJ>(
+        acc, iw, jw, lane, wave, I, J, lds, [&](int64_t i, int64_t j, double v0, bool hi, double v1) {
           double z0 = 0.0, z1 = 0.0;
           if (nz.kind == PLS_NOISE_PHILOX) {
-            if (ib < I && j < J) normal_pair(nz.seed, nz.step, ib, nz.j_offset + j, z0, z1);
+            normal_pair(nz.seed, nz.step, i, nz.j_offset + j, z0, z1);  // rows i and i + 4 share one Philox call
           } else if (nz.kind == PLS_NOISE_INJECTED) {
-            if (ib < I && j < J) z0 = nz.xi[ib * nz.ldxi + j];
-            if (ib + 4 < I && j < J) z1 = nz.xi[(ib + 4) * nz.ldxi + j];
+            z0 = nz.xi[i * nz.ldxi + j];
+            if (hi) z1 = nz.xi[(i + 4) * nz.ldxi + j];
           }
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const int64_t i = ib + 4 * h;
-            if (i < I && j < J) {
-              const double u = U[i * ldu + j];
-              const double v = acc.v[ta][tb][2 * rp + h];
-              double d = -eta * inv_noise * (v - c[i]) - eta * u / lam[i] + sq2eta * (h ? z1 : z0);
-              out[i * ldo + j] = add_u ? u + d : d;
-            }
+          {
+            const double u = U[i * ldu + j];
+            const double d = -eta * inv_noise * (v0 - c[i]) - eta * u / lam[i] + sq2eta * z0;
+            out[i * ldo + j] = add_u ? u + d : d;
           }
-        }
-      }
+          if (hi) {
+            const double u = U[(i + 4) * ldu + j];
+            const double d = -eta * inv_noise * (v1 - c[i + 4]) - eta * u / lam[i + 4] + sq2eta * z1;
+            out[(i + 4) * ldo + j] = add_u ? u + d : d;
+          }
+        });
   }
 };
 
@@ -184,9 +200,10 @@ struct EpiLangevinGaussian {
 template <int BI, int BJ, int WI, int WJ, class Epi>
 static int launch_gemm_cfg(GemmShape g, const Epi &epi, hipStream_t st) {
   constexpr int BK = 16;
+  constexpr int MINW = (BI >= 128) ? 2 : 4;  // waves per SIMD the register allocation must leave room for
   constexpr int NT = (BI / WI) * (BJ / WJ) * 64;
   constexpr size_t lds_bytes = (size_t)2 * BK * ((BI + 16) + (BJ + 16)) * sizeof(double);
-  auto kern = gemm_tn_f64_kernel<BI, BJ, WI, WJ, BK, Epi>;
+  auto kern = gemm_tn_f64_kernel<BI, BJ, WI, WJ, BK, MINW, Epi>;
   static bool attr_set = false;  // benign race: idempotent
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -199,7 +216,10 @@ static int launch_gemm_cfg(GemmShape g, const Epi &epi, hipStream_t st) {
   const int64_t nwg = (int64_t)g.nti * g.ntj;
   if (nwg <= 0) return PLS_OK;
   if (nwg > 0x7fffffff) return fail(PLS_ERR_INVALID_ARGUMENT, "gemm: too many tiles");
-  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(NT), lds_bytes, st, g, epi);
+  {
+    LaunchScope scope(Epi::kTag, st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(NT), lds_bytes, st, g, epi);
+  }
   return check_launch("gemm_tn_f64");
 }
 
@@ -390,6 +410,17 @@ __global__ __launch_bounds__(256) void langevin_update_kernel(double *out, int64
   }
 }
 
+__global__ __launch_bounds__(256) void link_transform_kernel(int link, double jitter, const double *__restrict__ in,
+                                                              int64_t ldin, int64_t rows, int64_t cols,
+                                                              double *__restrict__ out, int64_t ldout) {
+  const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (col >= cols) return;
+  for (int64_t row = blockIdx.y; row < rows; row += gridDim.y) {
+    double slope;
+    out[row * ldout + col] = link_eval(link, in[row * ldin + col], jitter, &slope);
+  }
+}
+
 __global__ __launch_bounds__(256) void normal_fill_kernel(double *__restrict__ out, int64_t ldo, int64_t rows,
                                                            int64_t j, uint64_t seed, uint64_t step, int64_t j_offset) {
   const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -508,6 +539,46 @@ extern "C" {
 const char *pls_last_error(void) { return g_last_error.c_str(); }
 int pls_abi_version(void) { return PLSHIP_ABI_VERSION; }
 
+int pls_timeline_begin(int32_t capacity) {
+  PLS_REQUIRE(capacity > 0 && capacity <= (1 << 20), "timeline_begin: capacity must be in (0, 2^20]");
+  PLS_REQUIRE(!g_tl.on, "timeline_begin: a timeline is already running on this thread");
+  g_tl.ev.resize(2 * (size_t)capacity);
+  g_tl.tag.assign(capacity, 0);
+  for (size_t i = 0; i < g_tl.ev.size(); ++i) {
+    hipError_t e = hipEventCreate(&g_tl.ev[i]);
+    if (e != hipSuccess) {
+      for (size_t k = 0; k < i; ++k) (void)hipEventDestroy(g_tl.ev[k]);
+      g_tl.ev.clear();
+      return fail(PLS_ERR_HIP, "timeline_begin: hipEventCreate: %s", hipGetErrorString(e));
+    }
+  }
+  g_tl.capacity = capacity;
+  g_tl.count = 0;
+  g_tl.on = true;
+  return PLS_OK;
+}
+
+int pls_timeline_end(float *ms, int32_t *tags, int32_t capacity, int32_t *count) {
+  PLS_REQUIRE(g_tl.on, "timeline_end: no timeline is running on this thread");
+  g_tl.on = false;
+  const int recorded = g_tl.count < g_tl.capacity ? g_tl.count : g_tl.capacity;
+  int rc = PLS_OK;
+  for (int i = 0; i < recorded; ++i) {
+    float t = 0.f;
+    hipError_t e = hipEventSynchronize(g_tl.ev[2 * i + 1]);
+    if (e == hipSuccess) e = hipEventElapsedTime(&t, g_tl.ev[2 * i], g_tl.ev[2 * i + 1]);
+    if (e != hipSuccess && rc == PLS_OK) rc = fail(PLS_ERR_HIP, "timeline_end: %s", hipGetErrorString(e));
+    if (ms && tags && i < capacity) {
+      ms[i] = t;
+      tags[i] = g_tl.tag[i];
+    }
+  }
+  for (hipEvent_t e : g_tl.ev) (void)hipEventDestroy(e);
+  g_tl.ev.clear();
+  if (count) *count = g_tl.count;
+  return rc;
+}
+
 int pls_kernel_gram(int32_t kernel_kind, const double *x1, int64_t n1, const double *x2, int64_t n2, int64_t d,
                     const double *lengthscale, double outputscale, double *out, int64_t ldout, void *stream) {
   PLS_REQUIRE(kernel_kind == PLS_KERNEL_RBF_ARD || kernel_kind == PLS_KERNEL_LINEAR, "unknown kernel kind %d", kernel_kind);
@@ -524,6 +595,7 @@ int pls_kernel_gram(int32_t kernel_kind, const double *x1, int64_t n1, const dou
   for (int64_t r0 = 0; r0 < n1; r0 += max_rows) {
     const int64_t rows = (n1 - r0 < max_rows) ? n1 - r0 : max_rows;
     dim3 g2((unsigned)cdiv(n2, 512), (unsigned)cdiv(rows, 8));
+    LaunchScope scope(PLS_TAG_KERNEL_GRAM, S(stream));
     if (d <= 8)
       hipLaunchKernelGGL(kernel_gram_kernel<8>, g2, dim3(256), 0, S(stream), kernel_kind, x1 + r0 * d, rows, x2, n2, (int)d,
                          lengthscale, outputscale, out + r0 * ldout, ldout);
@@ -590,6 +662,16 @@ int pls_cost_value(const pls_cost_desc *cost, const double *F, int64_t ldf, cons
   hipLaunchKernelGGL(column_reduce_kernel, dim3((unsigned)cdiv(j, 256)), dim3(256), 0, S(stream), partial, j, nparts, j, c,
                      0, 0, (const double *)nullptr, (int64_t)0, (int64_t)0, (const double *)nullptr, 0.0);
   return check_launch("column_reduce");
+}
+
+int pls_link_transform(int32_t link, double jitter, const double *in, int64_t ldin, int64_t rows, int64_t cols,
+                       double *out, int64_t ldout, void *stream) {
+  PLS_REQUIRE(link >= PLS_LINK_IDENTITY && link <= PLS_LINK_PROBIT, "link_transform: unknown link %d", link);
+  PLS_REQUIRE(in && out && rows >= 0 && cols >= 0 && ldin >= cols && ldout >= cols, "link_transform: bad arguments");
+  if (rows == 0 || cols == 0) return PLS_OK;
+  hipLaunchKernelGGL(link_transform_kernel, dim3((unsigned)cdiv(cols, 256), rows_grid(rows)), dim3(256), 0, S(stream),
+                     link, jitter, in, ldin, rows, cols, out, ldout);
+  return check_launch("link_transform");
 }
 
 int pls_normal_fill(double *out, int64_t ldout, int64_t rows, int64_t j, uint64_t seed, uint64_t step, int64_t j_offset,
@@ -697,7 +779,8 @@ int pls_onb_step(const pls_onb_desc *basis, const pls_cost_desc *cost, const dou
     return launch_gemm(basis->B, basis->ldb, U, ldu, basis->mk, j, basis->mk, e, st);
   }
   const size_t d_bytes = align_up((size_t)basis->mk * j * sizeof(double), 256);
-  if (!workspace || workspace_bytes < d_bytes + (size_t)128 * j * sizeof(double))
+  const int64_t min_rows = basis->n < 128 ? basis->n : 128;
+  if (!workspace || workspace_bytes < d_bytes + (size_t)min_rows * j * sizeof(double))
     return fail(PLS_ERR_WORKSPACE_TOO_SMALL, "onb_step: workspace %zu bytes, need at least %zu", workspace_bytes,
                 pls_onb_step_workspace_bytes(basis, j, 128));
   double *D = static_cast<double *>(workspace);
@@ -706,8 +789,11 @@ int pls_onb_step(const pls_onb_desc *basis, const pls_cost_desc *cost, const dou
   rc = stream_drift(basis->A, basis->lda, basis->At, basis->ldat, basis->mk, basis->n, U, ldu, j, cp, y, D, j, Gbuf,
                     n_chunk, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(langevin_update_kernel, dim3((unsigned)cdiv(j, 256), rows_grid(cdiv(basis->mk, 8) * 4)), dim3(256), 0,
-                     st, out, ldo, U, ldu, D, j, U, ldu, basis->lam, 0.0, basis->mk, j, eta, sqrt(2.0 * eta), out_mode, nz);
+  {
+    LaunchScope scope(PLS_TAG_LANGEVIN_UPDATE, st);
+    hipLaunchKernelGGL(langevin_update_kernel, dim3((unsigned)cdiv(j, 256), rows_grid(cdiv(basis->mk, 8) * 4)), dim3(256), 0,
+                       st, out, ldo, U, ldu, D, j, U, ldu, basis->lam, 0.0, basis->mk, j, eta, sqrt(2.0 * eta), out_mode, nz);
+  }
   return check_launch("langevin_update");
 }
 
@@ -734,6 +820,17 @@ int pls_onb_energy(const pls_onb_desc *basis, const pls_cost_desc *cost, const d
   else n_chunk = n_chunk / 128 * 128;
   return stream_cost(basis->A, basis->lda, basis->mk, basis->n, U, ldu, j, make_costp(cost), y,
                      static_cast<double *>(workspace), n_chunk, e, 1, U, ldu, basis->mk, basis->lam, 0.0, S(stream));
+}
+
+int pls_onb_prior_energy(const pls_onb_desc *basis, const double *U, int64_t ldu, int64_t j, const double *cost,
+                         double *e, void *stream) {
+  int rc = validate_onb(basis);
+  if (rc) return rc;
+  PLS_REQUIRE(U && e && j >= 0 && ldu >= j, "onb_prior_energy: bad arguments");
+  if (j == 0) return PLS_OK;
+  hipLaunchKernelGGL(column_reduce_kernel, dim3((unsigned)cdiv(j, 256)), dim3(256), 0, S(stream), cost, j,
+                     (int64_t)(cost ? 1 : 0), j, e, 0, 1, U, ldu, basis->mk, basis->lam, 0.0);
+  return check_launch("column_reduce");
 }
 
 // ---- inducing-point basis ---------------------------------------------------------------------------------------
@@ -830,7 +927,8 @@ int pls_ipb_step(const pls_ipb_desc *basis, const pls_cost_desc *cost, const dou
   PLS_REQUIRE(out_mode == 0 || out_mode == 1, "ipb_step: out_mode must be 0 or 1");
   if (j == 0) return PLS_OK;
   const size_t mj = align_up((size_t)basis->m * j * sizeof(double), 256);
-  if (!workspace || workspace_bytes < 4 * mj + (size_t)128 * j * sizeof(double))
+  const int64_t min_rows = basis->n < 128 ? basis->n : 128;
+  if (!workspace || workspace_bytes < 4 * mj + (size_t)min_rows * j * sizeof(double))
     return fail(PLS_ERR_WORKSPACE_TOO_SMALL, "ipb_step: workspace %zu bytes, need at least %zu", workspace_bytes,
                 pls_ipb_step_workspace_bytes(basis, j, 128));
   char *w = static_cast<char *>(workspace);
@@ -874,6 +972,24 @@ int pls_ipb_energy(const pls_ipb_desc *basis, const pls_cost_desc *cost, const d
   if (rc) return rc;
   return stream_cost(basis->Kzx, basis->ldkzx, basis->m, basis->n, V, j, j, make_costp(cost), y, partial, n_chunk, e, 2, V,
                      j, basis->m, nullptr, 0.5 * (double)basis->m, S(stream));
+}
+
+int pls_ipb_prior_energy(const pls_ipb_desc *basis, const double *U, int64_t ldu, int64_t j, const double *cost,
+                         double *e, void *workspace, size_t workspace_bytes, void *stream) {
+  int rc = validate_ipb(basis);
+  if (rc) return rc;
+  PLS_REQUIRE(U && e && j >= 0 && ldu >= j, "ipb_prior_energy: bad arguments");
+  if (j == 0) return PLS_OK;
+  const size_t need = (size_t)basis->m * j * sizeof(double);
+  if (!workspace || workspace_bytes < need)
+    return fail(PLS_ERR_WORKSPACE_TOO_SMALL, "ipb_prior_energy: workspace %zu < %zu bytes", workspace_bytes, need);
+  double *V = static_cast<double *>(workspace);
+  rc = pls_gemm_tn(basis->W, basis->ldw, U, ldu, V, j, basis->m, j, basis->m, 1.0, 0.0, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(column_reduce_kernel, dim3((unsigned)cdiv(j, 256)), dim3(256), 0, S(stream), cost, j,
+                     (int64_t)(cost ? 1 : 0), j, e, 0, 2, (const double *)V, j, basis->m, (const double *)nullptr,
+                     0.5 * (double)basis->m);
+  return check_launch("column_reduce");
 }
 
 }  // extern "C"

@@ -1,0 +1,69 @@
+"""J-sharding across the GPUs of one node.
+
+Every particle column evolves independently given the replicated basis, so a rank owns a contiguous block of
+columns and the Langevin step needs NO collective.  RCCL (torch.distributed backend "nccl") is used only where
+the reference reduces over J: the mean energy (orthonormal.py:126) and predictive moments (gaussian.py:49-52).
+The noise counters use GLOBAL column indices (basis.j_offset), so 1/2/4/8-GPU runs give identical particles."""
+from __future__ import annotations
+
+from typing import Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(number_of_particles: int, rank: int, world_size: int) -> Tuple[int, int]:
+    """Columns [j0, j1) owned by ``rank``: contiguous, sizes differ by at most one, earlier ranks get the extras."""
+    if not (0 <= rank < world_size):
+        raise ValueError(f"rank {rank} outside world of size {world_size}")
+    base, extra = divmod(number_of_particles, world_size)
+    j0 = rank * base + min(rank, extra)
+    return j0, j0 + base + (1 if rank < extra else 0)
+
+
+def shard_particles(particles: torch.Tensor, rank: int, world_size: int) -> torch.Tensor:
+    """This rank's columns of a full (M, J) particle matrix (contiguous copy)."""
+    j0, j1 = shard_bounds(particles.shape[1], rank, world_size)
+    return particles[:, j0:j1].contiguous()
+
+
+def attach_shard(basis, number_of_particles: int, rank: int, world_size: int) -> Tuple[int, int]:
+    """Tell ``basis`` which global columns its particles are, so its noise stream is GPU-count invariant."""
+    j0, j1 = shard_bounds(number_of_particles, rank, world_size)
+    basis.j_offset = j0
+    return j0, j1
+
+
+def mean_over_particles(local_values: torch.Tensor, number_of_particles: int, group=None) -> float:
+    """Global mean over J of a per-particle vector: all-reduce(sum) of one fp64 (collective C1 of SURVEY.md 2.2)."""
+    s = local_values.sum().reshape(1)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
+    return (s / number_of_particles).item()
+
+
+def predictive_moments(local_samples: torch.Tensor, number_of_particles: int, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Mean and unbiased variance over all J particles of (N*, J_local) samples: all-reduce of (N*, 2) sums
+    (collective C2; replaces prediction_samples.mean(dim=1) / .var(axis=1) at gaussian.py:49-52 on a sharded run)."""
+    sums = torch.stack([local_samples.sum(dim=1), (local_samples * local_samples).sum(dim=1)], dim=1)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+    mean = sums[:, 0] / number_of_particles
+    var = (sums[:, 1] - number_of_particles * mean * mean) / (number_of_particles - 1)
+    return mean, var
+
+
+def gather_particles(local_particles: torch.Tensor, number_of_particles: int, group=None) -> torch.Tensor:
+    """All-gather the column shards into the full (M, J) matrix on every rank (collective C3: conformal quantiles
+    need all samples of a test point, conformalise/pls.py:36-45).  Shards may differ by one column."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local_particles
+    world = dist.get_world_size(group)
+    m = local_particles.shape[0]
+    widths = [shard_bounds(number_of_particles, r, world) for r in range(world)]
+    wmax = max(b - a for a, b in widths)
+    padded = torch.zeros((wmax, m), dtype=local_particles.dtype, device=local_particles.device)
+    padded[: local_particles.shape[1]] = local_particles.T
+    out = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(out, padded, group=group)
+    return torch.cat([o[: b - a].T for o, (a, b) in zip(out, widths)], dim=1)

@@ -1,0 +1,40 @@
+"""Samplers (drop-in for src/samplers.py:6-44).
+
+``sample_multivariate_normal`` keeps the reference's stream: torch.normal on the CPU generator, coloured by
+eigh(cov).  It is setup / prediction code (the per-step Langevin noise uses the in-kernel Philox stream
+instead, see basis/), so the eigh runs on the host LAPACK exactly as in the reference and the product is
+done by libplship on the device."""
+from __future__ import annotations
+
+from typing import Tuple
+
+import torch
+
+from . import _lib as L
+from .kernel import _dev
+
+
+def sample_multivariate_normal(
+    mean: torch.Tensor,
+    cov: torch.Tensor,
+    size: Tuple[int] | None = None,
+    seed: int | None = None,
+) -> torch.Tensor:
+    """samplers.py:6-44.  Returns a (size..., n) float64 device tensor."""
+    generator = torch.Generator().manual_seed(seed) if seed is not None else None
+    size = (1,) if not size else size
+    eigenvalues, eigenvectors = torch.linalg.eigh(cov.detach().cpu().to(torch.float64))  # samplers.py:27
+    eigenvalues = torch.clip(eigenvalues, 0, None)
+    n = eigenvalues.shape[0]
+    normal_sample = torch.normal(mean=0.0, std=1.0, size=(n, *size), generator=generator)  # samplers.py:30-35
+    j = int(normal_sample.numel() // n)
+    xi = _dev(normal_sample.reshape(n, j))
+    # (Q sqrt(Lambda))^T stored k-major: L[k][i] = Q[i][k] * sqrt(lam_k)
+    lt = _dev((eigenvectors * torch.sqrt(eigenvalues)[None, :]).T)
+    out = torch.empty((n, j), dtype=torch.float64, device=xi.device)
+    L.check(
+        L.load().pls_gemm_tn(lt.data_ptr(), n, xi.data_ptr(), j, out.data_ptr(), j, n, j, n, 1.0, 0.0, L.stream_ptr()),
+        "pls_gemm_tn",
+    )
+    out = out + _dev(mean)[:, None]
+    return out.reshape(n, *size).movedim(0, -1) if len(size) > 1 else out.T

@@ -1,0 +1,65 @@
+"""CPU: the C-ABI library loads and exports every symbol include/plship.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "plship.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b(pls_[a-z0-9_]+)\s*\(", text)
+    return sorted(set(names))
+
+
+def test_header_declares_the_path():
+    names = declared_functions()
+    for must in ("pls_onb_step", "pls_ipb_step", "pls_gemm_tn", "pls_kernel_gram", "pls_cost_derivative", "pls_last_error"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    import projected_langevin_sampling_amd as pkg
+
+    lib = pkg._lib.load()
+    raw = ctypes.CDLL(pkg._lib.LIB_PATH)
+    for name in declared_functions():
+        assert hasattr(raw, name), f"{name} declared in include/plship.h but not exported"
+    assert set(pkg._lib.SIGNATURES) == set(declared_functions()), "ctypes table and header disagree"
+    assert lib.pls_abi_version() == 1
+    assert lib.pls_last_error() is not None
+
+
+def test_struct_layouts_match_the_header():
+    """sizeof / field order of the descriptor structs (plain C layout on x86-64)."""
+    import projected_langevin_sampling_amd as pkg
+
+    L = pkg._lib
+    assert ctypes.sizeof(L.CostDesc) == 4 * 4 + 4 * 8 + 8
+    assert ctypes.sizeof(L.NoiseDesc) == 8 + 8 + 8 + 8 + 8 + 8
+    assert ctypes.sizeof(L.OnbDesc) == 10 * 8
+    assert ctypes.sizeof(L.IpbDesc) == 10 * 8
+    assert L.CostDesc.p.offset == 16 and L.CostDesc.jitter.offset == 48
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    import projected_langevin_sampling_amd as pkg
+
+    L = pkg._lib
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "LIB_PATH", str(tmp_path / "libplship.so"))
+    with pytest.raises(L.PlsHipError, match="no CPU fallback|not found"):
+        L.load()
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg_dir = os.path.join(ROOT, "projected-langevin-sampling_amd")
+    for dirpath, _, files in os.walk(pkg_dir):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+                assert "/root/reference" not in text, f

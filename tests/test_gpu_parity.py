@@ -1,0 +1,583 @@
+"""GPU parity: libplship (through the drop-in Python API, i.e. through the C ABI) against the CPU oracle on the
+same seeded inputs, against the reference's literal goldens, and -- at BASELINE.json's full sizes -- through
+size-independent properties.  Floating point: BASELINE.json's north_star asks for fp64 output within 1e-8 of the
+reference; the tests hold the kernels to rel_err <= 1e-9 (scaled by max|expected|), well inside that bound.
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import philox_ref
+from oracle import pls_oracle as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+TOL = 1e-9  # < the 1e-8 fp64 tolerance of BASELINE.json north_star
+
+
+@pytest.fixture(scope="module")
+def P():
+    import projected_langevin_sampling_amd as pkg
+    from projected_langevin_sampling_amd import basis, costs, distributed, link_functions, samplers
+
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    pkg._lib.load()
+
+    class NS:
+        pass
+
+    ns = NS()
+    ns.pkg, ns.basis, ns.costs, ns.links, ns.dist, ns.samplers = pkg, basis, costs, link_functions, distributed, samplers
+    return ns
+
+
+@pytest.fixture(scope="module")
+def G():
+    with open(os.path.join(HERE, "golden", "reference_unit_goldens.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def V():
+    return dict(np.load(os.path.join(HERE, "golden", "reference_vectors.npz")))
+
+
+@pytest.fixture(autouse=True)
+def _f64_default():
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    yield
+    torch.set_default_dtype(prev)
+
+
+def relerr(got, want):
+    got = got.detach().cpu().double() if isinstance(got, torch.Tensor) else torch.as_tensor(got).double()
+    want = want.detach().cpu().double() if isinstance(want, torch.Tensor) else torch.as_tensor(want).double()
+    assert got.shape == want.shape, (got.shape, want.shape)
+    if want.numel() == 0:
+        return 0.0
+    return ((got - want).abs().max() / want.abs().max().clamp_min(1e-300)).item()
+
+
+def cu(t):
+    return t.to(device="cuda", dtype=torch.float64)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# problem builders shared by oracle and GPU
+# ------------------------------------------------------------------------------------------------------------
+def make_problem(n, m, j, d, seed=0, kernel="rbf"):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(n, d, generator=g) * 2 - 1
+    z = x[torch.randperm(n, generator=g)[:m]].clone()
+    w = torch.randn(d, generator=g)
+    fstar = torch.sin(2.0 * (x @ w))
+    y = fstar + 0.1 * torch.randn(n, generator=g)
+    u = torch.randn(m, j, generator=g)
+    ls = (0.5 + torch.rand(d, generator=g)) * (0.6 if d > 1 else 0.3)
+    return dict(x=x, z=z, y=y, u=u, ls=ls, fstar=fstar, gen=g)
+
+
+def make_costs(P, y, fstar, gen):
+    """(name, oracle cost, gpu cost) for every cost/link pair the reference dispatches on, plus autograd-only ones."""
+    y_count = torch.poisson((2.0 * fstar) ** 2 + 0.5, generator=gen)
+    y_bin = (torch.rand(y.shape[0], generator=gen) < torch.sigmoid(2 * fstar)).double()
+    Lk = P.links
+    return [
+        ("gaussian/identity", O.GaussianCost(0.3, y, O.IdentityLink()), P.costs.GaussianCost(0.3, y, Lk.IdentityLinkFunction())),
+        ("poisson/square", O.PoissonCost(y_count, O.SquareLink()), P.costs.PoissonCost(y_count, Lk.SquareLinkFunction())),
+        ("bernoulli/sigmoid", O.BernoulliCost(y_bin, O.SigmoidLink()), P.costs.BernoulliCost(y_bin, Lk.SigmoidLinkFunction())),
+        ("bernoulli/probit", O.BernoulliCost(y_bin, O.ProbitLink()), P.costs.BernoulliCost(y_bin, Lk.ProbitLinkFunction())),
+        ("student_t/identity", O.StudentTCost(3.0, y, O.IdentityLink(), 0.7), P.costs.StudentTCost(3.0, y, Lk.IdentityLinkFunction(), 0.7)),
+        ("multimodal/identity", O.MultiModalCost(0.7, 1.5, 0.3, y, O.IdentityLink()),
+         P.costs.MultiModalCost(0.7, 1.5, 0.3, y, Lk.IdentityLinkFunction())),
+        ("poisson/identity", O.PoissonCost(y_count, O.IdentityLink()), P.costs.PoissonCost(y_count, Lk.IdentityLinkFunction())),
+        ("gaussian/square", O.GaussianCost(0.3, y.abs(), O.SquareLink()), P.costs.GaussianCost(0.3, y.abs(), Lk.SquareLinkFunction())),
+    ]
+
+
+def build_onb(P, pr, threshold=1e-6, kernel="rbf"):
+    """Oracle and GPU orthonormal bases sharing ONE spectrum (the eigenvector gauge is LAPACK's)."""
+    ok = O.RBFARDKernel(pr["ls"], 1.3) if kernel == "rbf" else O.LinearKernel()
+    gk = P.pkg.ARDKernel(pr["ls"], 1.3) if kernel == "rbf" else P.pkg.LinearKernel()
+    ob = O.OrthonormalBasis(ok, pr["z"], pr["x"], threshold)
+    lam_all, vec_all = torch.linalg.eigh((1 / pr["z"].shape[0]) * ob.base_gram_induce)
+    gb = P.basis.OrthonormalBasis(P.pkg.PLSKernel(gk, pr["z"]), pr["z"], pr["x"], threshold, spectrum=(lam_all, vec_all),
+                                  verbose=False)
+    assert gb.approximation_dimension == ob.approximation_dimension
+    return ob, gb
+
+
+def build_ipb(P, pr):
+    ok = O.RBFARDKernel(pr["ls"], 1.3)
+    gk = P.pkg.ARDKernel(pr["ls"], 1.3)
+    yz = pr["y"][: pr["z"].shape[0]]
+    ob = O.InducingPointBasis(ok, pr["z"], yz, pr["x"])
+    gb = P.basis.InducingPointBasis(P.pkg.PLSKernel(gk, pr["z"]), pr["z"], yz, pr["x"])
+    return ob, gb
+
+
+# ------------------------------------------------------------------------------------------------------------
+# 1. the reference's own goldens, through the GPU path
+# ------------------------------------------------------------------------------------------------------------
+def _fixture_bases(P, G, threshold=0.0):
+    fx = G["basis_fixture"]
+    z, x = torch.tensor(fx["x_induce"]), torch.tensor(fx["x_train"])
+    k = P.pkg.PLSKernel(P.pkg.LinearKernel(), z)
+    onb = P.basis.OrthonormalBasis(k, z, x, eigenvalue_threshold=threshold, verbose=False)
+    ipb = P.basis.InducingPointBasis(k, z, torch.tensor(fx["y_induce"]), x)
+    return onb, ipb, cu(torch.tensor(fx["particles"]))
+
+
+def test_reference_goldens_bases(P, G):
+    onb, ipb, u = _fixture_bases(P, G)
+    assert onb.approximation_dimension == G["onb_approximation_dimension"]["threshold_0"]
+    assert _fixture_bases(P, G, 1.0)[0].approximation_dimension == G["onb_approximation_dimension"]["threshold_1"]
+    assert ipb.approximation_dimension == G["ipb_approximation_dimension"]["value"]
+    # goldens are float32 results of the reference -> rtol 1e-4 (cond(K_ZZ) = 803)
+    f = onb.calculate_untransformed_train_prediction_samples(u).cpu()
+    want = torch.tensor(G["onb_train_prediction_samples"]["value"])
+    assert torch.allclose(f, want, rtol=1e-4)  # same host LAPACK gauge as the reference
+    f = ipb.calculate_untransformed_train_prediction_samples(u).cpu()
+    assert torch.allclose(f, torch.tensor(G["ipb_train_prediction_samples"]["value"]), rtol=1e-4, atol=1e-4)
+    ones = torch.ones(3, dtype=torch.float64, device="cuda")
+    assert np.allclose(onb.calculate_energy_potential(u, ones), G["onb_energy_potential"]["value"], rtol=1e-4)
+    assert np.allclose(ipb.calculate_energy_potential(u, ones), G["ipb_energy_potential"]["value"], rtol=1e-4)
+
+
+def test_reference_goldens_onb_forward_with_oracle_gauge(P, G):
+    fx = G["basis_fixture"]
+    z, x = torch.tensor(fx["x_induce"]), torch.tensor(fx["x_train"])
+    ob = O.OrthonormalBasis(O.LinearKernel(), z, x, 0.0)
+    lam, vec = torch.linalg.eigh(0.5 * ob.base_gram_induce)
+    gb = P.basis.OrthonormalBasis(P.pkg.PLSKernel(P.pkg.LinearKernel(), z), z, x, 0.0, spectrum=(lam, vec), verbose=False)
+    u = torch.tensor(fx["particles"])
+    f = gb.calculate_untransformed_train_prediction_samples(cu(u))
+    assert relerr(f, ob.calculate_untransformed_train_prediction_samples(u)) < TOL
+    # and the literal golden (float32 in the reference): the oracle gauge is the reference's gauge (same LAPACK)
+    assert torch.allclose(f.cpu(), torch.tensor(G["onb_train_prediction_samples"]["value"]), rtol=1e-4)
+
+
+def test_reference_goldens_initial_particles(P, G):
+    onb, ipb, _ = _fixture_bases(P, G)
+    torch.set_default_dtype(torch.float32)  # the reference's tests draw float32 normals
+    got = onb.initialise_particles(3, seed=0).cpu()
+    assert torch.allclose(got, torch.tensor(G["onb_initialised_particles"]["threshold_0"], dtype=torch.float64), rtol=1e-6)
+    got = ipb.initialise_particles(2, seed=0, noise_only=False).cpu()
+    assert torch.allclose(got, torch.tensor(G["ipb_initialised_particles"]["with_y_induce"], dtype=torch.float64), rtol=1e-6)
+    with pytest.raises(ValueError):
+        onb.initialise_particles(3, noise_only=False, seed=0)
+
+
+def test_reference_goldens_costs(P, G):
+    Lk = P.links
+    mk = {
+        "bernoulli_sigmoid": lambda s, y: P.costs.BernoulliCost(y, Lk.SigmoidLinkFunction()),
+        "bernoulli_probit": lambda s, y: P.costs.BernoulliCost(y, Lk.ProbitLinkFunction()),
+        "gaussian_identity": lambda s, y: P.costs.GaussianCost(s["observation_noise"], y, Lk.IdentityLinkFunction()),
+        "poisson_square": lambda s, y: P.costs.PoissonCost(y, Lk.SquareLinkFunction()),
+        "poisson_identity": lambda s, y: P.costs.PoissonCost(y, Lk.IdentityLinkFunction()),
+        "student_t_identity": lambda s, y: P.costs.StudentTCost(s["degrees_of_freedom"], y, Lk.IdentityLinkFunction()),
+        "multimodal_identity": lambda s, y: P.costs.MultiModalCost(s["observation_noise"], s["shift"], s["bernoulli_noise"], y,
+                                                                    Lk.IdentityLinkFunction()),
+    }
+    for name, spec in G["costs"].items():
+        if name == "source":
+            continue
+        c = mk[name](spec, torch.tensor(spec["y"]))
+        f = cu(torch.tensor(spec["f"]))
+        assert torch.allclose(c.calculate_cost(f).cpu(), torch.tensor(spec["cost"]), rtol=1e-3), name  # test_costs.py:143
+        assert torch.allclose(c.calculate_cost_derivative(f).cpu(), torch.tensor(spec["dcost"]), rtol=1e-3), name
+    for name, spec in G["autograd_cost_derivatives"].items():
+        if name == "source":
+            continue
+        c = mk[name](spec, torch.tensor(spec["y"]))
+        g = c.calculate_cost_derivative(cu(torch.tensor(spec["f"])), force_autograd=True)
+        assert torch.allclose(g.cpu(), torch.tensor(spec["dcost"]), rtol=1e-3), name  # test_costs.py:269
+
+
+def test_reference_goldens_pls_kernel(P, G):
+    for key in ("case0", "case1"):
+        c = G["pls_kernel"][key]
+        k = P.pkg.PLSKernel(P.pkg.LinearKernel(), torch.tensor(c["z"]))
+        r = k(torch.tensor(c["x1"]), torch.tensor(c["x2"]))
+        assert torch.allclose(r.cpu(), torch.tensor(c["gram"]), rtol=1e-6)  # test_pls_kernel.py:52 (float32 golden)
+
+
+def test_reference_vectors_costs_and_links(P, V):
+    """Outputs of the reference's own cost / link modules (tests/golden/make_reference_vectors.py), fp64."""
+    Lk = P.links
+    f, fw = cu(torch.tensor(V["f"])), cu(torch.tensor(V["f_wide"]))
+    links = {"identity": Lk.IdentityLinkFunction, "square": Lk.SquareLinkFunction, "sigmoid": Lk.SigmoidLinkFunction,
+             "probit": Lk.ProbitLinkFunction}
+    for name, cls in links.items():
+        assert np.allclose(cls()(f).cpu().numpy(), V[f"link_{name}"], rtol=1e-13, atol=1e-300)
+        assert np.allclose(cls()(fw).cpu().numpy(), V[f"link_{name}_wide"], rtol=1e-13, atol=1e-300)
+    for lname in ("square", "identity"):
+        c = P.costs.PoissonCost(torch.tensor(V["y_count"]), links[lname]())
+        assert np.allclose(c.calculate_cost(f).cpu().numpy(), V[f"poisson_{lname}_cost"], rtol=1e-12)
+        assert np.allclose(c.calculate_cost_derivative(f).cpu().numpy(), V[f"poisson_{lname}_dcost"], rtol=1e-12)
+        assert np.allclose(c.calculate_cost_derivative(f, force_autograd=True).cpu().numpy(),
+                           V[f"poisson_{lname}_dcost_autograd"], rtol=1e-12)
+    for lname in ("sigmoid", "probit"):
+        c = P.costs.BernoulliCost(torch.tensor(V["y_bin"]), links[lname]())
+        for tag, ff in (("", f), ("_wide", fw)):
+            assert np.allclose(c.calculate_cost(ff).cpu().numpy(), V[f"bernoulli_{lname}_cost{tag}"], rtol=1e-12)
+            assert np.allclose(c.calculate_cost_derivative(ff).cpu().numpy(), V[f"bernoulli_{lname}_dcost{tag}"],
+                               rtol=1e-10, atol=1e-300)
+            assert np.allclose(c.calculate_cost_derivative(ff, force_autograd=True).cpu().numpy(),
+                               V[f"bernoulli_{lname}_dcost_autograd{tag}"], rtol=1e-9, atol=1e-300)
+    sig, shift, p = V["multimodal_params"]
+    c = P.costs.MultiModalCost(float(sig), float(shift), float(p), torch.tensor(V["y_real"]), Lk.IdentityLinkFunction())
+    assert np.allclose(c.calculate_cost(f).cpu().numpy(), V["multimodal_identity_cost"], rtol=1e-12)
+    assert np.allclose(c.calculate_cost_derivative(f).cpu().numpy(), V["multimodal_identity_dcost"], rtol=1e-10)
+
+
+def test_reference_vectors_sampler(P, V):
+    s = P.samplers.sample_multivariate_normal(torch.zeros(6), torch.tensor(V["mvn_cov"]), (9,), seed=7)
+    assert np.allclose(s.cpu().numpy(), V["mvn_sample_seed7"], rtol=1e-10, atol=1e-12)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# 2. kernels vs oracle on seeded inputs
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n1,n2,d", [(1, 1, 1), (7, 5, 3), (64, 1000, 8), (129, 513, 13), (10, 33, 40)])
+def test_rbf_ard_gram(P, n1, n2, d):
+    g = torch.Generator().manual_seed(n1 * 1000 + n2)
+    x1, x2 = torch.randn(n1, d, generator=g), torch.randn(n2, d, generator=g)
+    ls = 0.5 + torch.rand(d, generator=g)
+    got = P.pkg.ARDKernel(ls, 2.5)(x1, x2)
+    assert relerr(got, O.RBFARDKernel(ls, 2.5)(x1, x2)) < 1e-13
+    assert relerr(P.pkg.LinearKernel()(x1, x2), x1 @ x2.T) < 1e-13
+
+
+@pytest.mark.parametrize("i,j,k", [(1, 1, 1), (5, 3, 2), (64, 64, 16), (100, 64, 10), (257, 129, 33), (1000, 3, 1030), (2048, 4096, 200)])
+def test_gemm_tn(P, i, j, k):
+    L = P.pkg._lib
+    g = torch.Generator().manual_seed(i + j + k)
+    a, b = torch.randn(k, i, generator=g), torch.randn(k, j, generator=g)
+    c0 = torch.randn(i, j, generator=g)
+    c = cu(c0)
+    da, db = cu(a), cu(b)
+    L.check(L.load().pls_gemm_tn(da.data_ptr(), i, db.data_ptr(), j, c.data_ptr(), j, i, j, k, 0.75, -0.5, L.stream_ptr()))
+    assert relerr(c, 0.75 * (a.T @ b) - 0.5 * c0) < 1e-13
+
+
+def test_philox_stream_matches_numpy_restatement(P):
+    L = P.pkg._lib
+    for rows, cols, seed, step, joff in [(8, 16, 1, 0, 0), (13, 37, 0xDEADBEEFCAFE, 5, 1000), (1030, 70, 2**63 + 11, 2**33 + 3, 123456)]:
+        out = torch.empty(rows, cols, dtype=torch.float64, device="cuda")
+        L.check(L.load().pls_normal_fill(out.data_ptr(), cols, rows, cols, seed, step, joff, L.stream_ptr()))
+        want = philox_ref.normal_matrix(rows, cols, seed, step, joff)
+        assert np.allclose(out.cpu().numpy(), want, rtol=1e-12, atol=1e-13)
+    # J-shard invariance: a shard's block is the same numbers as the full matrix's columns
+    full = torch.empty(64, 100, dtype=torch.float64, device="cuda")
+    part = torch.empty(64, 30, dtype=torch.float64, device="cuda")
+    L.check(L.load().pls_normal_fill(full.data_ptr(), 100, 64, 100, 9, 2, 0, L.stream_ptr()))
+    L.check(L.load().pls_normal_fill(part.data_ptr(), 30, 64, 30, 9, 2, 50, L.stream_ptr()))
+    assert torch.equal(full[:, 50:80], part)
+    z = torch.empty(2048, 2048, dtype=torch.float64, device="cuda")
+    L.check(L.load().pls_normal_fill(z.data_ptr(), 2048, 2048, 2048, 77, 1, 0, L.stream_ptr()))
+    assert abs(z.mean().item()) < 3e-3 and abs(z.var().item() - 1) < 4e-3 and abs((z**4).mean().item() - 3) < 3e-2
+    assert abs(torch.corrcoef(torch.stack([z[:-4].flatten(), z[4:].flatten()]))[0, 1].item()) < 3e-3  # pair rows uncorrelated
+
+
+def test_costs_vs_oracle_all_pairs(P):
+    pr = make_problem(300, 8, 17, 2, seed=3)
+    g = pr["gen"]
+    f = torch.randn(300, 17, generator=g) * 1.5
+    f[0, 0], f[1, 1] = 40.0, -40.0  # drive the sigmoid/probit clips
+    for name, oc, gc in make_costs(P, pr["y"], pr["fstar"], g):
+        assert relerr(gc.calculate_cost(cu(f)), oc.calculate_cost(f).reshape(-1)) < 1e-11, name
+        assert relerr(gc.calculate_cost_derivative(cu(f)), oc.calculate_cost_derivative(f)) < 1e-9, name
+        if name != "multimodal/identity":
+            assert relerr(gc.calculate_cost_derivative(cu(f), force_autograd=True), oc.calculate_cost_derivative(f, force_autograd=True)) < 1e-9, name
+
+
+def step_tolerance(ob, oc, u, eta, noise, want, solve_cond=1.0):
+    """End-to-end tolerance of one step: TOL, unless the problem itself is ill-conditioned.  Costs with a 1/f term
+    (Poisson) amplify the rounding of F wherever f = sum_k a_k u_k cancels to something small -- for the oracle as
+    much as for the GPU, whose summation orders differ.  The oracle re-evaluates the step with F perturbed by the
+    size of that rounding, 1e-15 * (|K_XZ| |V~| |U|) (times cond(K_ZZ) when a solve is involved); 30x the observed
+    change is the floor."""
+    f = ob.calculate_untransformed_train_prediction_samples(u)
+    if hasattr(ob, "scaled_eigenvectors"):
+        bound = (ob.base_gram_induce_train.T.abs() @ ob.scaled_eigenvectors.abs()) @ u.abs()
+    else:
+        bound = ob.base_gram_induce_train.T.abs() @ O._chol_solve(ob.base_gram_induce, u).abs() * solve_cond
+    g = torch.Generator().manual_seed(99)
+    f2 = f + 1e-15 * bound * torch.randn(f.shape, generator=g)
+    want2 = ob.calculate_particle_update(u, oc.calculate_cost_derivative(f2), eta, noise=noise)
+    return max(TOL, 30.0 * relerr(want2, want))
+
+
+# ------------------------------------------------------------------------------------------------------------
+# 3. the Langevin step (unpinned by the reference's own tests -> oracle on identical inputs, injected noise)
+# ------------------------------------------------------------------------------------------------------------
+SHAPES = [(512, 32, 64, 3), (100, 10, 64, 1), (1000, 40, 3, 5), (333, 17, 1, 2), (2100, 130, 260, 4)]
+
+
+@pytest.mark.parametrize("n,m,j,d", SHAPES)
+def test_onb_step_all_costs(P, n, m, j, d):
+    pr = make_problem(n, m, j, d, seed=n + m)
+    ob, gb = build_onb(P, pr)
+    mk = ob.approximation_dimension
+    u = pr["u"][:mk].contiguous()
+    xi = torch.randn(mk, j, generator=pr["gen"])
+    eta = 1e-3
+    for name, oc, gc in make_costs(P, pr["y"], pr["fstar"], pr["gen"]):
+        want = O.PLS(ob, oc).calculate_particle_update(u.clone(), eta, noise=xi)
+        tol = step_tolerance(ob, oc, u, eta, xi, want)
+        if tol >= 1e-8:
+            continue  # this (cost, data) pair cannot be held to 1e-8 by ANY fp64 implementation; stages are checked below
+
+        pls = P.pkg.PLS(gb, gc)
+        got = pls.calculate_particle_update(cu(u), eta, noise=cu(xi))
+        assert relerr(got, want) < tol, f"fused {name}"
+        # un-fused composition (what a user-defined cost goes through)
+        fdev = gb.calculate_untransformed_train_prediction_samples(cu(u))
+        assert relerr(fdev, ob.calculate_untransformed_train_prediction_samples(u)) < 1e-12, name
+        gdev = gc.calculate_cost_derivative(fdev)
+        got2 = gb.calculate_particle_update(cu(u), gdev, eta, noise=cu(xi))
+        assert relerr(got2, want) < tol, f"unfused {name}"
+        # each stage on the ORACLE's inputs is tight regardless of conditioning
+        f_or = ob.calculate_untransformed_train_prediction_samples(u)
+        g_or = oc.calculate_cost_derivative(f_or)
+        assert relerr(gc.calculate_cost_derivative(cu(f_or)), g_or) < 1e-11, name
+        assert relerr(gb.calculate_particle_update(cu(u), cu(g_or), eta, noise=cu(xi)),
+                      ob.calculate_particle_update(u, g_or, eta, noise=xi)) < 1e-12, name
+        # energy
+        e_want = O.PLS(ob, oc).calculate_energy_potential(u.clone())
+        assert abs(pls.calculate_energy_potential(cu(u)) - e_want) <= 1e-10 * abs(e_want), name
+        if name == "gaussian/identity":  # the B = A A^T path and the generic path are both exercised
+            got3 = gb.fused_step(gc, cu(u), eta, noise=P.basis.NoiseSpec(injected=cu(xi)), force_generic=True)
+            assert relerr(got3, want) < tol, "generic gaussian"
+            assert gb._B is not None
+
+
+@pytest.mark.parametrize("n,m,j,d", [(512, 24, 64, 3), (100, 10, 7, 1), (700, 33, 130, 2)])
+def test_ipb_step_all_costs(P, n, m, j, d):
+    pr = make_problem(n, m, j, d, seed=7 * n + m)
+    pr["ls"] = pr["ls"] * 0.35  # keeps cond(k(Z,Z)) small enough for 1e-9 parity of the solves
+    ob, gb = build_ipb(P, pr)
+    cond = torch.linalg.cond(ob.base_gram_induce).item()
+    u = pr["u"]
+    e_noise = torch.randn(m, j, generator=pr["gen"])
+    eta = 1e-3
+    for name, oc, gc in make_costs(P, pr["y"], pr["fstar"], pr["gen"]):
+        want = O.PLS(ob, oc).calculate_particle_update(u.clone(), eta, noise=e_noise)
+        # the two M x M solves lose cond(k(Z,Z)) * eps in BOTH implementations (explicit inverse here, Cholesky solve there)
+        tol = max(step_tolerance(ob, oc, u, eta, e_noise, want, solve_cond=cond), cond * 1e-14)
+        if tol >= 1e-8:
+            continue
+        pls = P.pkg.PLS(gb, gc)
+        assert relerr(pls.calculate_particle_update(cu(u), eta, noise=cu(e_noise)), want) < tol, name
+        gdev = gc.calculate_cost_derivative(gb.calculate_untransformed_train_prediction_samples(cu(u)))
+        assert relerr(gb.calculate_particle_update(cu(u), gdev, eta, noise=cu(e_noise)), want) < tol, name
+        e_want = O.PLS(ob, oc).calculate_energy_potential(u.clone())
+        assert abs(pls.calculate_energy_potential(cu(u)) - e_want) <= max(1e-10, tol) * abs(e_want), name
+
+
+def test_ipb_philox_noise_is_coloured_by_kzz(P):
+    pr = make_problem(200, 6, 20000, 1, seed=5)
+    pr["ls"] = pr["ls"] * 0.35
+    ob, gb = build_ipb(P, pr)
+    gc = P.costs.GaussianCost(0.5, pr["y"], P.links.IdentityLinkFunction())
+    u = torch.zeros(6, 20000, dtype=torch.float64, device="cuda")
+    eta = 0.5
+    base = gb.fused_step(gc, u, eta, noise=P.basis.NoiseSpec(none=True))
+    got = gb.fused_step(gc, u, eta, noise=P.basis.NoiseSpec(seed=3, step=0))
+    e = (got - base) / math.sqrt(2 * eta)  # = L_c xi
+    cov = (e @ e.T / e.shape[1]).cpu()
+    assert relerr(cov, ob.base_gram_induce) < 5e-2
+
+
+def test_config1_train_pls_trajectory(P):
+    """BASELINE.json configs[0]: 1D sin regression N=100, M=10, J=64, Gaussian cost (README.md:94-265):
+    200 steps of train_pls with the oracle's noise injected -> same particles, same energies, same stop index."""
+    n, m, j, steps, eta = 100, 10, 64, 200, 1e-3
+    x = torch.linspace(-1, 1, n).reshape(-1, 1)
+    y = torch.sin(2 * torch.pi * x.reshape(-1)) + 0.1 * torch.normal(
+        mean=torch.tensor(0.0), std=torch.tensor(1.0), generator=torch.Generator().manual_seed(0), size=(n,))
+    z = x[:: n // m][:m].clone()
+    pr = dict(x=x, z=z, y=y, ls=torch.tensor([0.15]))
+    ok = O.RBFARDKernel([0.15], 3.0)
+    ob = O.OrthonormalBasis(ok, z, x, 0.0)
+    lam, vec = torch.linalg.eigh((1 / m) * ob.base_gram_induce)
+    gb = P.basis.OrthonormalBasis(P.pkg.PLSKernel(P.pkg.ARDKernel([0.15], 3.0), z), z, x, 0.0, spectrum=(lam, vec), verbose=False)
+    u0 = ob.initialise_particles(j, seed=0).double()
+    g = torch.Generator().manual_seed(1)
+    noises = [torch.randn(ob.approximation_dimension, j, generator=g) for _ in range(steps)]
+    oc = O.GaussianCost(0.5, y, O.IdentityLink())
+    gc = P.costs.GaussianCost(0.5, y, P.links.IdentityLinkFunction())
+    u_want, e_want = O.train_pls(O.PLS(ob, oc), u0.clone(), steps, eta, 1e9, noises=noises)
+    u_got, e_got = P.pkg.train_pls(P.pkg.PLS(gb, gc), cu(u0), steps, eta, 1e9, noises=[cu(t) for t in noises])
+    assert len(e_got) == len(e_want) == steps
+    assert relerr(u_got, u_want) < 1e-8
+    assert np.allclose(e_got, e_want, rtol=1e-9)
+    # early stop rule: a tiny patience stops both at the same index
+    _, e1 = O.train_pls(O.PLS(ob, oc), u0.clone(), steps, eta, 2.5 * eta, noises=noises)
+    _, e2 = P.pkg.train_pls(P.pkg.PLS(gb, gc), cu(u0), steps, eta, 2.5 * eta, noises=[cu(t) for t in noises])
+    assert len(e1) == len(e2)
+
+
+def test_user_defined_python_cost_goes_through_unfused_entry_points(P):
+    pr = make_problem(256, 12, 20, 2, seed=11)
+    ob, gb = build_onb(P, pr)
+    mk = ob.approximation_dimension
+    y_dev = cu(pr["y"])
+
+    class HuberLikeCost(P.costs.PLSCost):  # user code: plain torch on device tensors
+        def __init__(self):
+            super().__init__(link_function=P.links.IdentityLinkFunction())
+            self.y_train = pr["y"]
+
+        def predict(self, prediction_samples):
+            return None
+
+        def calculate_cost(self, untransformed_train_prediction_samples):
+            return torch.log(torch.cosh(untransformed_train_prediction_samples - y_dev[:, None])).sum(dim=0)
+
+        def calculate_cost_derivative(self, untransformed_train_prediction_samples, force_autograd=False):
+            return torch.tanh(untransformed_train_prediction_samples - y_dev[:, None])
+
+    class OracleCost(O._Cost):
+        def calculate_cost(self, f):
+            return torch.log(torch.cosh(f - pr["y"][:, None])).sum(dim=0)
+
+        def calculate_cost_derivative(self, f):
+            return torch.tanh(f - pr["y"][:, None])
+
+    cost = HuberLikeCost()
+    assert not cost.is_native()
+    u = pr["u"][:mk].contiguous()
+    xi = torch.randn(mk, 20, generator=pr["gen"])
+    want = O.PLS(ob, OracleCost()).calculate_particle_update(u.clone(), 2e-3, noise=xi)
+    got = P.pkg.PLS(gb, cost).calculate_particle_update(cu(u), 2e-3, noise=cu(xi))
+    assert relerr(got, want) < TOL
+    e_want = O.PLS(ob, OracleCost()).calculate_energy_potential(u.clone())
+    assert abs(P.pkg.PLS(gb, cost).calculate_energy_potential(cu(u)) - e_want) < 1e-10 * abs(e_want)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# 4. edge cases and error behaviour of the boundary
+# ------------------------------------------------------------------------------------------------------------
+def test_error_behaviour(P):
+    pr = make_problem(64, 6, 4, 2, seed=1)
+    ob, gb = build_onb(P, pr)
+    gc = P.costs.GaussianCost(0.3, pr["y"], P.links.IdentityLinkFunction())
+    pls = P.pkg.PLS(gb, gc)
+    bad = torch.zeros(gb.approximation_dimension + 1, 4, dtype=torch.float64, device="cuda")
+    with pytest.raises(AssertionError):  # basis/base.py:156-158
+        pls.calculate_particle_update(bad, 1e-3)
+    with pytest.raises(AssertionError):  # projected_langevin_sampling.py:131-133
+        pls.calculate_energy_potential(bad)
+    with pytest.raises(P.pkg._lib.PlsHipError):  # no CPU fallback
+        pls.calculate_particle_update(torch.zeros(gb.approximation_dimension, 4, dtype=torch.float64), 1e-3)
+    with pytest.raises(P.pkg._lib.PlsHipError):
+        pls.calculate_particle_update(torch.zeros(gb.approximation_dimension, 4, dtype=torch.float32, device="cuda"), 1e-3)
+    L = P.pkg._lib
+    rc = L.load().pls_gemm_tn(None, 1, None, 1, None, 1, 1, 1, 1, 1.0, 0.0, None)
+    assert rc == 1 and b"NULL" in L.load().pls_last_error()
+    d = L.CostDesc()
+    d.cost = 99
+    rc = L.load().pls_cost_derivative(d, bad.data_ptr(), 4, bad.data_ptr(), 1, 4, bad.data_ptr(), 4, None)
+    assert rc == 1 and b"unknown cost" in L.load().pls_last_error()
+
+
+def test_empty_and_ragged_particle_sets(P):
+    pr = make_problem(150, 9, 5, 2, seed=2)
+    ob, gb = build_onb(P, pr)
+    mk = ob.approximation_dimension
+    gc = P.costs.PoissonCost(torch.poisson(torch.full((150,), 2.0), generator=pr["gen"]), P.links.SquareLinkFunction())
+    pls = P.pkg.PLS(gb, gc)
+    empty = torch.zeros(mk, 0, dtype=torch.float64, device="cuda")
+    assert pls.calculate_particle_update(empty, 1e-3).shape == (mk, 0)
+    # a column slice of a wider tensor (ragged leading dimension, odd width) gives the same numbers as a compact copy
+    wide = cu(torch.randn(mk, 11, generator=pr["gen"]) + 2.0)
+    view = wide[:, 2:9]
+    xi = cu(torch.randn(mk, 7, generator=pr["gen"]))
+    a = pls.calculate_particle_update(view, 1e-3, noise=xi)
+    b = pls.calculate_particle_update(view.contiguous(), 1e-3, noise=xi)
+    assert torch.equal(a, b)
+
+
+def test_noise_is_reproducible_under_set_seed_and_fresh_per_step(P):
+    pr = make_problem(128, 8, 16, 2, seed=4)
+    ob, gb = build_onb(P, pr)
+    gc = P.costs.GaussianCost(0.3, pr["y"], P.links.IdentityLinkFunction())
+    pls = P.pkg.PLS(gb, gc)
+    u = cu(pr["u"][: gb.approximation_dimension].contiguous())
+    torch.manual_seed(123)
+    a1, a2 = pls.calculate_particle_update(u, 1e-2), pls.calculate_particle_update(u, 1e-2)
+    torch.manual_seed(123)
+    b1 = pls.calculate_particle_update(u, 1e-2)
+    assert torch.equal(a1, b1) and not torch.equal(a1, a2)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# 5. J-sharding: a rank's shard evolves exactly like the same columns of the full run
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cost_name", ["gaussian/identity", "poisson/square"])
+def test_j_shard_invariance(P, cost_name):
+    pr = make_problem(400, 20, 96, 3, seed=21)
+    ob, gb = build_onb(P, pr)
+    mk = ob.approximation_dimension
+    costs = {n: g for n, _, g in make_costs(P, pr["y"], pr["fstar"], pr["gen"])}
+    pls = P.pkg.PLS(gb, costs[cost_name])
+    u = cu(pr["u"][:mk].contiguous())
+    full = gb.fused_step(costs[cost_name], u, 1e-3, noise=P.basis.NoiseSpec(seed=5, step=7, j_offset=0))
+    for world in (2, 3):
+        parts = []
+        for r in range(world):
+            j0, j1 = P.dist.shard_bounds(96, r, world)
+            parts.append(gb.fused_step(costs[cost_name], u[:, j0:j1].contiguous(), 1e-3,
+                                       noise=P.basis.NoiseSpec(seed=5, step=7, j_offset=j0)))
+        assert relerr(torch.cat(parts, dim=1), full) < 1e-13
+    del pls
+
+
+# ------------------------------------------------------------------------------------------------------------
+# 6. BASELINE.json full size (configs[1]: N=1e5, M=1024, J=8192): size-independent properties
+# ------------------------------------------------------------------------------------------------------------
+def test_full_size_properties(P):
+    n, m, j, d = 100_000, 1024, 8192, 8
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(n, d, generator=g) * 2 - 1
+    z = x[torch.randperm(n, generator=g)[:m]].clone()
+    w = torch.randn(d, generator=g)
+    y = torch.sin(2.0 * (x @ w)) + 0.1 * torch.randn(n, generator=g)
+    ls = 0.5 + torch.rand(d, generator=g)
+    gb = P.basis.OrthonormalBasis(P.pkg.PLSKernel(P.pkg.ARDKernel(ls, 1.0), z), z, x, eigenvalue_threshold=1e-8, verbose=False,
+                                  keep_gram=False)
+    mk = gb.approximation_dimension
+    gc = P.costs.GaussianCost(0.01, y, P.links.IdentityLinkFunction())
+    u = torch.randn(mk, j, generator=g).cuda()
+    eta = 0.5 * gb.eigenvalues.min().item()  # eta / lambda_min < 2
+    ns = P.basis.NoiseSpec(seed=11, step=3)
+    fast = gb.fused_step(gc, u, eta, noise=ns)
+    generic = gb.fused_step(gc, u, eta, noise=ns, force_generic=True)
+    # (a) algebraic identity B U - c 1^T == A (A^T U - y 1^T): two different kernels, same step
+    assert relerr(fast, generic) < 1e-8
+    # (b) J-shard invariance at full size (columns 4096.. as its own shard)
+    shard = gb.fused_step(gc, u[:, 4096:].contiguous(), eta, noise=P.basis.NoiseSpec(seed=11, step=3, j_offset=4096),
+                          force_generic=True)
+    assert relerr(shard, generic[:, 4096:]) < 1e-12
+    # (c) zero step size -> zero update; (d) the drift is linear in eta (no noise)
+    assert gb.fused_step(gc, u, 0.0, noise=P.basis.NoiseSpec(none=True)).abs().max().item() == 0.0
+    d1 = gb.fused_step(gc, u, eta, noise=P.basis.NoiseSpec(none=True), force_generic=True)
+    d2 = gb.fused_step(gc, u, 2 * eta, noise=P.basis.NoiseSpec(none=True), force_generic=True)
+    assert relerr(d2, 2 * d1) < 1e-13
+    # (e) A and At are transposes of each other; A A^T = I-ish scaling: V~^T K_ZX K_XZ V~ is symmetric PSD
+    assert torch.equal(gb._A[:, :4096].T.contiguous(), gb._At[:4096, :].contiguous()) or relerr(gb._A[:, :4096].T, gb._At[:4096, :]) < 1e-13
+    assert relerr(gb._B, gb._B.T) < 1e-12
+    # (f) energy: fused (cost inside the GEMM epilogue) == un-fused composition
+    e_fused = P.pkg.PLS(gb, gc).particle_energy_potential(u[:, :512].contiguous())
+    f = gb.calculate_untransformed_train_prediction_samples(u[:, :512].contiguous())
+    e_unfused = gb.particle_energy_potential(u[:, :512].contiguous(), gc.calculate_cost(f))
+    assert relerr(e_fused, e_unfused) < 1e-11

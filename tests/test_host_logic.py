@@ -1,0 +1,104 @@
+"""CPU: host-side logic of the drop-in layer that needs no GPU (sharding math, stop rule, descriptors,
+argument validation in the C ABI, loud failure without a device)."""
+import numpy as np
+import pytest
+import torch
+
+import projected_langevin_sampling_amd as pkg
+from projected_langevin_sampling_amd import costs, distributed, link_functions
+from projected_langevin_sampling_amd.basis.base import NoiseSpec, padded_ld
+
+L = pkg._lib
+
+
+def test_shard_bounds_partition_every_column_once():
+    for j in (0, 1, 7, 64, 8192, 8193):
+        for world in (1, 2, 3, 4, 8):
+            bounds = [distributed.shard_bounds(j, r, world) for r in range(world)]
+            assert bounds[0][0] == 0 and bounds[-1][1] == j
+            assert all(a[1] == b[0] for a, b in zip(bounds, bounds[1:]))
+            widths = [b - a for a, b in bounds]
+            assert max(widths) - min(widths) <= 1
+    with pytest.raises(ValueError):
+        distributed.shard_bounds(8, 3, 2)
+
+
+def test_early_stopper_matches_reference_rule():
+    es = pkg.EarlyStopper(patience=0.25)
+    seq = [(1.0, False), (1.0, False), (2.0, False), (0.5, False), (0.5, False), (0.5, False), (0.5, True)]
+    for loss, want in seq:
+        assert es.should_stop(loss, 0.1) is want
+    assert pkg.EarlyStopper().should_stop(float("inf"), 1e-3) is True
+    assert pkg.EarlyStopper().should_stop(float("nan"), 1e-3) is True
+
+
+def test_cost_descriptors():
+    y = torch.zeros(4)
+    d = costs.GaussianCost(0.3, y, link_functions.IdentityLinkFunction()).desc()
+    assert (d.cost, d.link, d.deriv_mode, d.p[0]) == (L.COST_GAUSSIAN, L.LINK_IDENTITY, L.DERIV_REFERENCE, 0.3)
+    d = costs.StudentTCost(3, y, link_functions.IdentityLinkFunction(), scale=0.5).desc(force_autograd=True)
+    assert (d.cost, d.deriv_mode, d.p[0], d.p[1]) == (L.COST_STUDENT_T, L.DERIV_AUTOGRAD, 3.0, 0.5)
+    d = costs.MultiModalCost(0.7, 1.5, 0.3, y, link_functions.SigmoidLinkFunction(jitter=1e-6)).desc()
+    assert (d.cost, d.link, d.p[0], d.p[1], d.p[2], d.jitter) == (L.COST_MULTIMODAL, L.LINK_SIGMOID, 0.7, 1.5, 0.3, 1e-6)
+    assert costs.BernoulliCost(torch.tensor([0, 1]), link_functions.ProbitLinkFunction()).y_train.dtype == torch.float64
+
+    class UserLink(link_functions.PLSLinkFunction):
+        def transform(self, y):
+            return y
+
+    c = costs.PoissonCost(y, UserLink())
+    assert not c.is_native()
+    with pytest.raises(L.PlsHipError):
+        c.desc()
+
+
+def test_noise_spec_descriptor():
+    d = NoiseSpec(seed=2**64 + 5, step=9, j_offset=4096).desc()
+    assert (d.kind, d.seed, d.step, d.j_offset) == (L.NOISE_PHILOX, 5, 9, 4096)
+    assert NoiseSpec(none=True).desc().kind == L.NOISE_NONE
+    with pytest.raises(L.PlsHipError):
+        NoiseSpec(injected=torch.zeros(2, 2, dtype=torch.float64)).desc()  # CPU tensor: no fallback
+
+
+def test_padded_leading_dimension():
+    assert [padded_ld(c) for c in (1, 16, 17, 1021, 1024)] == [16, 16, 32, 1024, 1024]
+
+
+def test_cabi_argument_validation_without_a_gpu():
+    """Validation happens before any HIP call, so these run on the CPU-only box."""
+    lib = L.load()
+    assert lib.pls_gemm_tn(None, 1, None, 1, None, 1, 1, 1, 1, 1.0, 0.0, None) == 1
+    assert b"NULL" in lib.pls_last_error()
+    assert lib.pls_gemm_tn(8, 1, 8, 1, 8, 1, 4, 4, 4, 1.0, 0.0, None) == 1  # ld < size
+    assert b"leading dimension" in lib.pls_last_error()
+    bad = L.CostDesc()
+    bad.cost, bad.link = 0, 7
+    assert lib.pls_cost_derivative(bad, 8, 1, 8, 1, 1, 8, 1, None) == 1
+    assert b"unknown link" in lib.pls_last_error()
+    g = L.CostDesc()
+    g.cost, g.link, g.p[0] = L.COST_GAUSSIAN, L.LINK_IDENTITY, 0.0
+    assert lib.pls_cost_derivative(g, 8, 1, 8, 1, 1, 8, 1, None) == 1
+    assert b"observation_noise" in lib.pls_last_error()
+    o = L.OnbDesc()
+    assert lib.pls_onb_forward(o, 8, 1, 1, 8, 1, None) == 1
+    assert lib.pls_kernel_gram(0, 8, 1, 8, 1, 100, 8, 1.0, 8, 1, None) == 1  # d > 64
+    assert lib.pls_cost_value_workspace_bytes(1000, 8) == 4 * 8 * 8
+    assert lib.pls_onb_step_workspace_bytes(None, 8, 0) == 0
+
+
+def test_product_fails_loudly_without_a_device():
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    k = pkg.ARDKernel([1.0], 1.0)
+    with pytest.raises(L.PlsHipError, match="no CPU fallback"):
+        k(torch.zeros(2, 1), torch.zeros(3, 1))
+    c = costs.GaussianCost(0.3, torch.zeros(4), link_functions.IdentityLinkFunction())
+    with pytest.raises(L.PlsHipError, match="no CPU fallback"):
+        c.calculate_cost(torch.zeros(4, 2, dtype=torch.float64))
+
+
+def test_predictive_moments_single_process():
+    s = torch.randn(5, 64, dtype=torch.float64)
+    mean, var = distributed.predictive_moments(s, 64)
+    assert np.allclose(mean, s.mean(dim=1)) and np.allclose(var, s.var(dim=1))
+    assert np.isclose(distributed.mean_over_particles(s[0], 64), s[0].mean().item())
