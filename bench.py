@@ -68,12 +68,32 @@ def make_data(cfg, seed=0):
     return x, z, y, ls
 
 
+def host_cores() -> int:
+    """CPU threads this process may really use: scheduler affinity capped by the cgroup CPU quota
+    (os.cpu_count() reports the whole host and oversubscribes a containerised box)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, quota // period))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(cfg, x, z, y, ls, lam_all, vec_all):
     """The oracle ("port": faithful torch-CPU restatement of the reference's step, oracle/pls_oracle.py) timed on this
     box's host cores on a bounded sample: two particle-subset sizes, linear in J, extrapolated to the full J."""
     from oracle import pls_oracle as O
 
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     prev = torch.get_default_dtype()
     torch.set_default_dtype(torch.float64)
@@ -85,6 +105,8 @@ def cpu_baseline(cfg, x, z, y, ls, lam_all, vec_all):
         ob.base_gram_induce_train = torch.empty(z.shape[0], x.shape[0])
         for r0 in range(0, x.shape[0], 8192):  # chunked k(Z,X): the broadcasted build would need N*M*D doubles
             ob.base_gram_induce_train[:, r0:r0 + 8192] = kern(z, x[r0:r0 + 8192])
+            if (r0 // 8192) % 4 == 0:
+                log(f"cpu baseline: host k(Z,X) rows {r0}/{x.shape[0]}")
         ob.eigenvalues, ob.eigenvectors = lam_all, vec_all
         ob.scaled_eigenvectors = vec_all / torch.sqrt(lam_all.shape[0] * lam_all)[None, :]
         if cfg["cost"] == "poisson":
@@ -105,6 +127,7 @@ def cpu_baseline(cfg, x, z, y, ls, lam_all, vec_all):
             reps = 2
             for _ in range(reps):
                 u += pls.calculate_particle_update(u, cfg["eta"])  # faithful: eigh(I) noise, dense diag @ U, full F and G
+                log(f"cpu baseline: step done ({time.perf_counter() - t0:.1f} s since start of timing)")
             times[js] = (time.perf_counter() - t0) / reps
         (j1, t1), (j2, t2) = sorted(times.items())
         slope = (t2 - t1) / (j2 - j1)

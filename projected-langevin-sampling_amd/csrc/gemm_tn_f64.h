@@ -64,7 +64,12 @@ struct AccFrag {
 //   EDGE: the tile overhangs I or J -> overhanging lanes read column 0 of their row (always inside the matrix)
 //         and are zeroed when the pair is written to LDS (after the MFMAs, so the loads stay in flight)
 // so that the steady-state loop contains no branch and no use of a loaded value before the MFMAs of the step.
-template <int BI, int BJ, int WI, int WJ, int BK, bool VEC, bool EDGE, int TI, int TJ>
+//   DMA : full k-steps are copied global -> LDS by the LDS-DMA path (global_load_lds_dwordx4: no staging VGPRs, no
+//         ds_write instructions); one wave-instruction fills one 1-KiB k-row of a 128-wide tile, so the row pad stays.
+//         Overhanging lanes then deposit real (finite or not) matrix data of other columns: harmless, because output
+//         (i, j) only ever combines column i of L with column j of R and the epilogue drops i >= I, j >= J.  The K tail
+//         (rows that must read as zero) always goes through registers.
+template <int BI, int BJ, int WI, int WJ, int BK, bool VEC, bool EDGE, bool DMA, int TI, int TJ>
 __device__ __forceinline__ void gemm_tn_mainloop(const GemmShape &g, int64_t i0, int64_t j0, double *lds,
                                                  AccFrag<TI, TJ> &acc) {
   constexpr int NW = (BI / WI) * (BJ / WJ);
@@ -93,6 +98,40 @@ __device__ __forceinline__ void gemm_tn_mainloop(const GemmShape &g, int64_t i0,
 
   double2_t lreg[LPASS], rreg[RPASS];
   bool lkin[LPASS], rkin[RPASS];  // only meaningful for the K-tail step
+
+  typedef __attribute__((address_space(3))) void *lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void *glb_ptr_t;
+  // DMA addressing (buffer_load_dwordx4 ... offen lds): a 128-bit buffer descriptor whose base is the wave-uniform
+  // address of the step's first k-row (rebuilt with two scalar adds per step, so any matrix size works), the row
+  // inside the step as an SGPR offset, and ONE loop-invariant 32-bit lane offset in a VGPR: no VALU in the k-loop.
+  static_assert(!DMA || (BI == 128 && BJ == 128), "one wave-instruction must cover exactly one k-row");
+  const int wrow = __builtin_amdgcn_readfirstlane(lrow);  // = wave index: uniform
+  const int loff = (int)((l0 ? i0 + lcol : 0) * 8), roff = (int)((r0 ? j0 + rcol : 0) * 8);
+  int lsoff[LPASS], rsoff[RPASS];
+#pragma unroll
+  for (int p = 0; p < LPASS; ++p) lsoff[p] = (int)((int64_t)(wrow + p * LROWS) * g.ldl * 8);
+#pragma unroll
+  for (int p = 0; p < RPASS; ++p) rsoff[p] = (int)((int64_t)(wrow + p * RROWS) * g.ldr * 8);
+  const char *lnext = reinterpret_cast<const char *>(g.L), *rnext = reinterpret_cast<const char *>(g.R);
+  const int64_t lstep = (int64_t)BK * g.ldl * 8, rstep = (int64_t)BK * g.ldr * 8;
+  auto dma_load = [&](int buf) {  // copies the NEXT full k-step (lnext/rnext run one step ahead) into `buf`
+#if defined(__HIP_DEVICE_COMPILE__)  // (the buffer-resource type and builtins exist in the device pass only)
+    const __amdgpu_buffer_rsrc_t lr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(lnext), 0, 0x7FFFFFF0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(rnext), 0, 0x7FFFFFF0, 0x00020000);
+#pragma unroll
+    for (int p = 0; p < LPASS; ++p)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(lr, (lds_ptr_t)(Ls + buf * BK * SL + (wrow + p * LROWS) * SL), 16, loff, lsoff[p], 0,
+                                               0);
+#pragma unroll
+    for (int p = 0; p < RPASS; ++p)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rr, (lds_ptr_t)(Rs + buf * BK * SR + (wrow + p * RROWS) * SR), 16, roff, rsoff[p], 0,
+                                               0);
+    lnext += lstep;
+    rnext += rstep;
+#else
+    (void)buf;
+#endif
+  };
 
   auto load_global = [&](int64_t k0, auto tail_tag) {
     constexpr bool TAIL = decltype(tail_tag)::value;
@@ -152,21 +191,30 @@ __device__ __forceinline__ void gemm_tn_mainloop(const GemmShape &g, int64_t i0,
       *reinterpret_cast<double2_t *>(r + (rrow + p * RROWS) * SR + rcol) = v;
     }
   };
+  // Fragments are double-buffered in registers: the ds_reads of k-quad q+1 are issued before the MFMAs of
+  // k-quad q, so their LDS latency hides under 16 (TI*TJ) 64-cycle MFMAs instead of stalling the wave.
   auto compute = [&](int buf) {
     const double *l = Ls + buf * BK * SL + q * SL + wi + c16;
     const double *r = Rs + buf * BK * SR + q * SR + wj + c16;
+    double a[2][TI], b[2][TJ];
+#pragma unroll
+    for (int t = 0; t < TI; ++t) a[0][t] = l[t * 16];
+#pragma unroll
+    for (int t = 0; t < TJ; ++t) b[0][t] = r[t * 16];
 #pragma unroll
     for (int kq = 0; kq < BK / 4; ++kq) {
-      double a[TI], b[TJ];
+      const int cur = kq & 1, nxt = cur ^ 1;
+      if (kq + 1 < BK / 4) {
 #pragma unroll
-      for (int t = 0; t < TI; ++t) a[t] = l[kq * 4 * SL + t * 16];
+        for (int t = 0; t < TI; ++t) a[nxt][t] = l[(kq + 1) * 4 * SL + t * 16];
 #pragma unroll
-      for (int t = 0; t < TJ; ++t) b[t] = r[kq * 4 * SR + t * 16];
+        for (int t = 0; t < TJ; ++t) b[nxt][t] = r[(kq + 1) * 4 * SR + t * 16];
+      }
 #pragma unroll
       for (int ta = 0; ta < TI; ++ta)
 #pragma unroll
         for (int tb = 0; tb < TJ; ++tb)
-          acc.v[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ta], b[tb], acc.v[ta][tb], 0, 0, 0);
+          acc.v[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][ta], b[cur][tb], acc.v[ta][tb], 0, 0, 0);
     }
   };
 
@@ -176,8 +224,12 @@ __device__ __forceinline__ void gemm_tn_mainloop(const GemmShape &g, int64_t i0,
   const int64_t nk_full = g.K / BK;
   if (g.K > 0) {  // (K == 0: acc stays zero; the clamp k = K-1 would be out of bounds)
     if (nk_full > 0) {
-      load_global(0, full_t{});
-      store_lds(0, full_t{});
+      if (DMA) {
+        dma_load(0);
+      } else {
+        load_global(0, full_t{});
+        store_lds(0, full_t{});
+      }
     } else {
       load_global(0, tail_t{});
       store_lds(0, tail_t{});
@@ -186,12 +238,78 @@ __device__ __forceinline__ void gemm_tn_mainloop(const GemmShape &g, int64_t i0,
   __syncthreads();
 
   int64_t kt = 0;
-  for (; kt + 1 < nk_full; ++kt) {  // steady state: the next step is a full one
-    const int buf = (int)(kt & 1);
-    load_global((kt + 1) * BK, full_t{});
-    compute(buf);
-    store_lds(buf ^ 1, full_t{});
-    __syncthreads();
+  if (DMA) {
+    // Rotated pipeline.  Per step: issue the DMA of the next tile; run k-quads 0..2 (their fragments prefetched one
+    // quad ahead); drain the DMA and cross the barrier; fetch the NEXT step's first fragments from the other buffer;
+    // only then issue the last quad's 16 MFMAs, which cover the barrier skew and that fetch's LDS latency.
+    auto read_frag = [&](int buf, int kq, double (&a)[TI], double (&b)[TJ]) {
+      const double *l = Ls + buf * BK * SL + (kq * 4 + q) * SL + wi + c16;
+      const double *r = Rs + buf * BK * SR + (kq * 4 + q) * SR + wj + c16;
+#pragma unroll
+      for (int t = 0; t < TI; ++t) a[t] = l[t * 16];
+#pragma unroll
+      for (int t = 0; t < TJ; ++t) b[t] = r[t * 16];
+    };
+    auto mfma_block = [&](const double (&a)[TI], const double (&b)[TJ]) {
+#pragma unroll
+      for (int ta = 0; ta < TI; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < TJ; ++tb)
+          acc.v[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ta], b[tb], acc.v[ta][tb], 0, 0, 0);
+    };
+    static_assert(BK == 16, "the rotated loop is written for 4 k-quads per step");
+    if (nk_full > 1) {
+      double fa[TI], fb[TJ], ga[TI], gb[TJ];
+      read_frag(0, 0, fa, fb);
+      auto body = [&](auto buf_tag) {  // buf is a compile-time constant: LDS addresses fold into instruction offsets
+        constexpr int buf = decltype(buf_tag)::value;
+        dma_load(buf ^ 1);
+        read_frag(buf, 1, ga, gb);
+        mfma_block(fa, fb);  // quad 0
+        read_frag(buf, 2, fa, fb);
+        mfma_block(ga, gb);  // quad 1
+        read_frag(buf, 3, ga, gb);
+        mfma_block(fa, fb);  // quad 2
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();  // vmcnt(0): the DMA has landed; barrier: every wave is done reading `buf`
+        __builtin_amdgcn_sched_barrier(0);
+        read_frag(buf ^ 1, 0, fa, fb);      // next step's quad 0
+        __builtin_amdgcn_sched_barrier(0);  // keep that fetch AHEAD of the 16 MFMAs that hide its latency
+        mfma_block(ga, gb);                 // quad 3 of this step
+      };
+      for (; kt + 2 < nk_full; kt += 2) {
+        body(std::integral_constant<int, 0>{});
+        body(std::integral_constant<int, 1>{});
+      }
+      if (kt + 1 < nk_full) {
+        body(std::integral_constant<int, 0>{});
+        ++kt;
+      }
+      // fa/fb hold quad 0 of step kt (the last full step, or the one before the tail): finish it here
+      {
+        const int buf = (int)(kt & 1);
+        const bool more = kt + 1 < nk;
+        if (more) load_global((kt + 1) * BK, tail_t{});
+        read_frag(buf, 1, ga, gb);
+        mfma_block(fa, fb);
+        read_frag(buf, 2, fa, fb);
+        mfma_block(ga, gb);
+        read_frag(buf, 3, ga, gb);
+        mfma_block(fa, fb);
+        mfma_block(ga, gb);
+        if (more) store_lds(buf ^ 1, tail_t{});
+        __syncthreads();
+        ++kt;
+      }
+    }
+  } else {
+    for (; kt + 1 < nk_full; ++kt) {  // steady state: the next step is a full one
+      const int buf = (int)(kt & 1);
+      load_global((kt + 1) * BK, full_t{});
+      compute(buf);
+      store_lds(buf ^ 1, full_t{});
+      __syncthreads();
+    }
   }
   for (; kt < nk; ++kt) {  // last full step and the K tail
     const int buf = (int)(kt & 1);
@@ -223,13 +341,14 @@ __global__ __launch_bounds__((BI / WI) * (BJ / WJ) * 64, MINW) void gemm_tn_f64_
   const bool vec = ((g.ldl & 1) == 0) && ((reinterpret_cast<uintptr_t>(g.L) & 15) == 0) && ((g.ldr & 1) == 0) &&
                    ((reinterpret_cast<uintptr_t>(g.R) & 15) == 0);
   const bool edge = (i0 + BI > g.I) || (j0 + BJ > g.J);
+  constexpr bool kDma = (BI == 128 && BJ == 128);
   if (vec) {
     if (!edge)
-      gemm_tn_mainloop<BI, BJ, WI, WJ, BK, true, false>(g, i0, j0, lds, acc);
+      gemm_tn_mainloop<BI, BJ, WI, WJ, BK, true, false, kDma>(g, i0, j0, lds, acc);
     else
-      gemm_tn_mainloop<BI, BJ, WI, WJ, BK, true, true>(g, i0, j0, lds, acc);
+      gemm_tn_mainloop<BI, BJ, WI, WJ, BK, true, true, kDma>(g, i0, j0, lds, acc);
   } else {
-    gemm_tn_mainloop<BI, BJ, WI, WJ, BK, false, true>(g, i0, j0, lds, acc);
+    gemm_tn_mainloop<BI, BJ, WI, WJ, BK, false, true, false>(g, i0, j0, lds, acc);
   }
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -281,7 +400,11 @@ __device__ __forceinline__ void epilogue_row_pairs(const AccFrag<TI, TJ> &acc, i
   if constexpr (TI >= 2) pass(std::integral_constant<int, 1>{});
   if constexpr (TI >= 3) pass(std::integral_constant<int, 2>{});
   if constexpr (TI >= 4) pass(std::integral_constant<int, 3>{});
-  static_assert(TI <= 4, "extend the pass list");
+  if constexpr (TI >= 5) pass(std::integral_constant<int, 4>{});
+  if constexpr (TI >= 6) pass(std::integral_constant<int, 5>{});
+  if constexpr (TI >= 7) pass(std::integral_constant<int, 6>{});
+  if constexpr (TI >= 8) pass(std::integral_constant<int, 7>{});
+  static_assert(TI <= 8, "extend the pass list");
 }
 
 struct EpiStore {  // C = alpha * acc + beta * C

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -197,10 +198,9 @@ struct EpiLangevinGaussian {
 // ---------------------------------------------------------------------------------------------------------------
 // GEMM launcher
 // ---------------------------------------------------------------------------------------------------------------
-template <int BI, int BJ, int WI, int WJ, class Epi>
+template <int BI, int BJ, int WI, int WJ, class Epi, int MINW = ((BI >= 128) ? 2 : 4)>
 static int launch_gemm_cfg(GemmShape g, const Epi &epi, hipStream_t st) {
-  constexpr int BK = 16;
-  constexpr int MINW = (BI >= 128) ? 2 : 4;  // waves per SIMD the register allocation must leave room for
+  constexpr int BK = 16;  // MINW: waves per SIMD the register allocation must leave room for
   constexpr int NT = (BI / WI) * (BJ / WJ) * 64;
   constexpr size_t lds_bytes = (size_t)2 * BK * ((BI + 16) + (BJ + 16)) * sizeof(double);
   auto kern = gemm_tn_f64_kernel<BI, BJ, WI, WJ, BK, MINW, Epi>;
