@@ -35,6 +35,7 @@ struct GemmShape {
   int64_t ldr;
   int64_t I, J, K;
   int nti, ntj;
+  int64_t kchunk;  // split-K: block (x, y) contracts k in [y * kchunk, min(K, (y + 1) * kchunk)); gridDim.y slabs
 };
 
 // blockIdx.x -> (tile_i, tile_j)
@@ -100,7 +101,6 @@ __device__ __forceinline__ void gemm_tn_mainloop(const GemmShape &g, int64_t i0,
   bool lkin[LPASS], rkin[RPASS];  // only meaningful for the K-tail step
 
   typedef __attribute__((address_space(3))) void *lds_ptr_t;
-  typedef const __attribute__((address_space(1))) void *glb_ptr_t;
   // DMA addressing (buffer_load_dwordx4 ... offen lds): a 128-bit buffer descriptor whose base is the wave-uniform
   // address of the step's first k-row (rebuilt with two scalar adds per step, so any matrix size works), the row
   // inside the step as an SGPR offset, and ONE loop-invariant 32-bit lane offset in a VGPR: no VALU in the k-loop.
@@ -115,6 +115,7 @@ __device__ __forceinline__ void gemm_tn_mainloop(const GemmShape &g, int64_t i0,
   const char *lnext = reinterpret_cast<const char *>(g.L), *rnext = reinterpret_cast<const char *>(g.R);
   const int64_t lstep = (int64_t)BK * g.ldl * 8, rstep = (int64_t)BK * g.ldr * 8;
   auto dma_load = [&](int buf) {  // copies the NEXT full k-step (lnext/rnext run one step ahead) into `buf`
+    (void)sizeof(lds_ptr_t);
 #if defined(__HIP_DEVICE_COMPILE__)  // (the buffer-resource type and builtins exist in the device pass only)
     const __amdgpu_buffer_rsrc_t lr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(lnext), 0, 0x7FFFFFF0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(rnext), 0, 0x7FFFFFF0, 0x00020000);
@@ -129,7 +130,7 @@ __device__ __forceinline__ void gemm_tn_mainloop(const GemmShape &g, int64_t i0,
     lnext += lstep;
     rnext += rstep;
 #else
-    (void)buf;
+    (void)buf, (void)loff, (void)roff, (void)lnext, (void)rnext, (void)lstep, (void)rstep, (void)lsoff, (void)rsoff;
 #endif
   };
 
@@ -329,6 +330,13 @@ __global__ __launch_bounds__((BI / WI) * (BJ / WJ) * 64, MINW) void gemm_tn_f64_
   int tile_i, tile_j;
   gemm_tile_coords(blockIdx.x, g.nti, g.ntj, tile_i, tile_j);
   const int64_t i0 = (int64_t)tile_i * BI, j0 = (int64_t)tile_j * BJ;
+  const int split = blockIdx.y;
+  if (gridDim.y > 1) {  // split-K slab: shift the operands to this block's k-range
+    const int64_t k0 = (int64_t)split * g.kchunk;
+    g.L += k0 * g.ldl;
+    g.R += k0 * g.ldr;
+    g.K = (g.K - k0 < g.kchunk) ? g.K - k0 : g.kchunk;
+  }
 
   AccFrag<TI, TJ> acc;
 #pragma unroll
@@ -353,7 +361,7 @@ __global__ __launch_bounds__((BI / WI) * (BJ / WJ) * 64, MINW) void gemm_tn_f64_
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wi = (wave / (BJ / WJ)) * WI, wj = (wave % (BJ / WJ)) * WJ;
-  epi.template apply<TI, TJ>(acc, i0 + wi, j0 + wj, lane, wave, g.I, g.J, tile_i, lds);
+  epi.template apply<TI, TJ>(acc, i0 + wi, j0 + wj, lane, wave, g.I, g.J, tile_i, split, lds);
 }
 
 // ---- epilogues ------------------------------------------------------------------------------------------------
@@ -407,14 +415,16 @@ __device__ __forceinline__ void epilogue_row_pairs(const AccFrag<TI, TJ> &acc, i
   static_assert(TI <= 8, "extend the pass list");
 }
 
-struct EpiStore {  // C = alpha * acc + beta * C
+struct EpiStore {  // C = alpha * acc + beta * C   (split-K: slab `split` of C, slabs `slab` doubles apart)
   static constexpr int kTag = 1;  // PLS_TAG_GEMM_STORE
-  double *C;
+  double *C0;
   int64_t ldc;
   double alpha, beta;
+  int64_t slab;
   template <int TI, int TJ>
   __device__ void apply(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int wave, int64_t I, int64_t J,
-                        int, double *lds) const {
+                        int, int split, double *lds) const {
+    double *C = C0 + (int64_t)split * slab;
     if (beta == 0.0) {
       epilogue_row_pairs<TI, TJ>(acc, iw, jw, lane, wave, I, J, lds,
                                  [&](int64_t i, int64_t j, double v0, bool hi, double v1) {

@@ -88,7 +88,7 @@ struct EpiCostDeriv {
   CostP cp;
   template <int TI, int TJ>
   __device__ void apply(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int wave, int64_t I, int64_t J,
-                        int, double *lds) const {
+                        int, int, double *lds) const {
     epilogue_row_pairs<TI, TJ>(acc, iw, jw, lane, wave, I, J, lds,
                                [&](int64_t i, int64_t j, double v0, bool hi, double v1) {
                                  G[i * ldg + j] = cost_deriv(cp, y[i], v0);
@@ -107,7 +107,7 @@ struct EpiCostValue {
   CostP cp;
   template <int TI, int TJ>
   __device__ void apply(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int wave, int64_t I, int64_t J,
-                        int tile_i, double *lds) const {
+                        int tile_i, int, double *lds) const {
     double s = 0.0;  // this lane's column, summed over the rows it is handed (fixed order)
     epilogue_row_pairs<TI, TJ>(acc, iw, jw, lane, wave, I, J, lds,
                                [&](int64_t i, int64_t, double v0, bool hi, double v1) {
@@ -171,7 +171,7 @@ struct EpiLangevinGaussian {
   NoiseP nz;
   template <int TI, int TJ>
   __device__ void apply(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int wave, int64_t I, int64_t J,
-                        int, double *lds) const {
+                        int, int, double *lds) const {
     epilogue_row_pairs<TI, TJ>(
         acc, iw, jw, lane, wave, I, J, lds, [&](int64_t i, int64_t j, double v0, bool hi, double v1) {
           double z0 = 0.0, z1 = 0.0;
@@ -216,21 +216,40 @@ static int launch_gemm_cfg(GemmShape g, const Epi &epi, hipStream_t st) {
   const int64_t nwg = (int64_t)g.nti * g.ntj;
   if (nwg <= 0) return PLS_OK;
   if (nwg > 0x7fffffff) return fail(PLS_ERR_INVALID_ARGUMENT, "gemm: too many tiles");
+  unsigned nsplit = 1;
+  if (g.kchunk > 0 && g.kchunk < g.K) nsplit = (unsigned)cdiv(g.K, g.kchunk);
   {
     LaunchScope scope(Epi::kTag, st);
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(NT), lds_bytes, st, g, epi);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg, nsplit), dim3(NT), lds_bytes, st, g, epi);
   }
   return check_launch("gemm_tn_f64");
 }
 
-static bool use_big_tiles(int64_t I, int64_t J) { return cdiv(I, 128) * cdiv(J, 128) >= 256; }
+static bool use_big_tiles(int64_t I, int64_t J, int64_t nsplit = 1) { return cdiv(I, 128) * cdiv(J, 128) * nsplit >= 256; }
 
+// kchunk > 0 (EpiStore only): split-K into cdiv(K, kchunk) slabs, one grid.y plane each
 template <class Epi>
 static int launch_gemm(const double *L, int64_t ldl, const double *R, int64_t ldr, int64_t I, int64_t J, int64_t K,
-                       const Epi &epi, hipStream_t st) {
-  GemmShape g{L, ldl, R, ldr, I, J, K, 0, 0};
-  if (use_big_tiles(I, J)) return launch_gemm_cfg<128, 128, 64, 64>(g, epi, st);
+                       const Epi &epi, hipStream_t st, int64_t kchunk = 0) {
+  GemmShape g{L, ldl, R, ldr, I, J, K, 0, 0, kchunk};
+  const int64_t nsplit = (kchunk > 0 && kchunk < K) ? cdiv(K, kchunk) : 1;
+  if (use_big_tiles(I, J, nsplit)) return launch_gemm_cfg<128, 128, 64, 64>(g, epi, st);
   return launch_gemm_cfg<64, 64, 32, 32>(g, epi, st);
+}
+
+// Split-K plan for the back-projection D (I x J) = L^T R with a long contraction (K = rows of the N chunk):
+// when the output has too few 128x128 tiles to fill 256 CUs twice over, the contraction is cut into slabs that are
+// summed in a fixed order by the update kernel (deterministic, no atomics).  Returns the number of slabs.
+static int64_t plan_split_k(int64_t I, int64_t J, int64_t K, int64_t *kchunk) {
+  const int64_t tiles = cdiv(I, 128) * cdiv(J, 128);
+  int64_t s = 1;
+  if (tiles < 512) s = cdiv(512, tiles);
+  if (s > 16) s = 16;
+  while (s > 1 && K / s < 1024) --s;  // keep every slab's k-loop long enough to amortise its prologue / epilogue
+  int64_t kc = cdiv(cdiv(K, s), 16) * 16;
+  s = cdiv(K, kc);
+  *kchunk = (s > 1) ? kc : 0;
+  return s;
 }
 
 // cost-value GEMM (tile geometry is part of the epilogue type); returns the number of partial rows written
@@ -239,7 +258,7 @@ static int64_t cost_value_partial_rows(int64_t I, int64_t J) { return use_big_ti
 static int launch_gemm_cost_value(const double *L, int64_t ldl, const double *R, int64_t ldr, int64_t I, int64_t J,
                                   int64_t K, double *partial, int64_t ldp, const double *y, const CostP &cp,
                                   hipStream_t st) {
-  GemmShape g{L, ldl, R, ldr, I, J, K, 0, 0};
+  GemmShape g{L, ldl, R, ldr, I, J, K, 0, 0, 0};
   if (use_big_tiles(I, J)) {
     EpiCostValue<128, 128, 64, 64> e{partial, ldp, y, cp};
     return launch_gemm_cfg<128, 128, 64, 64>(g, e, st);
@@ -377,10 +396,12 @@ __global__ __launch_bounds__(256) void column_reduce_kernel(const double *__rest
 // out = [U +] -eta * D - eta * pscale_i * P + sq2eta * noise     (rows x J)
 //   ONB: P = U, pscale_i = 1/lam_i (pass lam, lam_is_vec = 1);  IPB: P = W U, pscale = M (lam = NULL, pconst = M)
 // One thread per (row pair {ib, ib+4}, column): the pair shares one Philox call (philox.h).
-// (out may alias D element for element: each thread reads D[i][col] before it writes out[i][col].)
+// (out may alias slab 0 of D element for element: each thread reads D[..][i][col] before it writes out[i][col].)
+// D may be split into nslab slabs (split-K partial sums of the back-projection), slab_stride doubles apart.
 __global__ __launch_bounds__(256) void langevin_update_kernel(double *out, int64_t ldo,
                                                                const double *__restrict__ U, int64_t ldu,
-                                                               const double *D, int64_t ldd,
+                                                               const double *D, int64_t ldd, int nslab,
+                                                               int64_t slab_stride,
                                                                const double *__restrict__ P, int64_t ldp,
                                                                const double *__restrict__ lam, double pconst,
                                                                int64_t rows, int64_t j, double eta, double sq2eta,
@@ -403,7 +424,9 @@ __global__ __launch_bounds__(256) void langevin_update_kernel(double *out, int64
       const int64_t i = ib + 4 * h;
       if (i < rows) {
         const double ps = lam ? 1.0 / lam[i] : pconst;
-        const double d = -eta * D[i * ldd + col] - eta * ps * P[i * ldp + col] + sq2eta * (h ? z1 : z0);
+        double drift = D[i * ldd + col];
+        for (int sl = 1; sl < nslab; ++sl) drift += D[sl * slab_stride + i * ldd + col];  // split-K slabs, fixed order
+        const double d = -eta * drift - eta * ps * P[i * ldp + col] + sq2eta * (h ? z1 : z0);
         out[i * ldo + col] = add_u ? U[i * ldu + col] + d : d;
       }
     }
@@ -485,14 +508,25 @@ static int validate_noise(const pls_noise_desc *n, int64_t rows) {
 //   D  (K x J): receives the drift  Lb^T cost'(...)
 static int stream_drift(const double *Lf, int64_t ldlf, const double *Lb, int64_t ldlb, int64_t kdim, int64_t n,
                         const double *V, int64_t ldv, int64_t j, const CostP &cp, const double *y, double *D,
-                        int64_t ldd, double *Gbuf, int64_t n_chunk, hipStream_t st) {
+                        int64_t ldd, int64_t max_slabs, int64_t slab_stride, int64_t *slabs_used, double *Gbuf,
+                        int64_t n_chunk, hipStream_t st) {
+  // one split-K plan for every chunk (slab s accumulates over the chunks; the update kernel sums the slabs)
+  int64_t kchunk = 0;
+  int64_t nslab = plan_split_k(kdim, j, n < n_chunk ? n : n_chunk, &kchunk);
+  if (nslab > max_slabs) {
+    nslab = 1;
+    kchunk = 0;
+  }
+  *slabs_used = nslab;
   for (int64_t r0 = 0, c = 0; r0 < n; r0 += n_chunk, ++c) {
     const int64_t rows = (n - r0 < n_chunk) ? (n - r0) : n_chunk;
     EpiCostDeriv e1{Gbuf, j, y + r0, cp};
     int rc = launch_gemm(Lf + r0, ldlf, V, ldv, rows, j, kdim, e1, st);
     if (rc) return rc;
-    EpiStore e2{D, ldd, 1.0, c == 0 ? 0.0 : 1.0};
-    rc = launch_gemm(Lb + r0 * ldlb, ldlb, Gbuf, j, kdim, j, rows, e2, st);
+    // slab s accumulates rows [s * kchunk, (s + 1) * kchunk) of every chunk; the first chunk has the planned row count,
+    // so it writes (beta = 0) every slab; a shorter last chunk simply leaves its missing slabs untouched
+    EpiStore e2{D, ldd, 1.0, c == 0 ? 0.0 : 1.0, slab_stride};
+    rc = launch_gemm(Lb + r0 * ldlb, ldlb, Gbuf, j, kdim, j, rows, e2, st, nslab > 1 ? kchunk : 0);
     if (rc) return rc;
   }
   return PLS_OK;
@@ -619,7 +653,7 @@ int pls_gemm_tn(const double *L, int64_t ldl, const double *R, int64_t ldr, doub
   PLS_REQUIRE(ldl >= I && ldr >= J && ldc >= J, "gemm_tn: leading dimension too small (ldl=%lld I=%lld ldr=%lld J=%lld ldc=%lld)",
               (long long)ldl, (long long)I, (long long)ldr, (long long)J, (long long)ldc);
   if (I == 0 || J == 0) return PLS_OK;
-  EpiStore e{C, ldc, alpha, beta};
+  EpiStore e{C, ldc, alpha, beta, 0};
   return launch_gemm(L, ldl, R, ldr, I, J, K, e, S(stream));
 }
 
@@ -740,8 +774,8 @@ int pls_onb_particle_update(const pls_onb_desc *basis, const double *U, int64_t 
   rc = pls_gemm_tn(basis->At, basis->ldat, G, ldg, dU, lddu, basis->mk, j, basis->n, 1.0, 0.0, stream);
   if (rc) return rc;
   hipLaunchKernelGGL(langevin_update_kernel, dim3((unsigned)cdiv(j, 256), rows_grid(cdiv(basis->mk, 8) * 4)), dim3(256), 0,
-                     S(stream), dU, lddu, U, ldu, dU, lddu, U, ldu, basis->lam, 0.0, basis->mk, j, eta, sqrt(2.0 * eta), 0,
-                     make_noisep(noise));
+                     S(stream), dU, lddu, U, ldu, dU, lddu, 1, (int64_t)0, U, ldu, basis->lam, 0.0, basis->mk, j, eta, sqrt(2.0 * eta),
+                     0, make_noisep(noise));
   return check_launch("langevin_update");
 }
 
@@ -749,11 +783,17 @@ static bool onb_fast_path(const pls_onb_desc *b, const pls_cost_desc *c, int for
   return !force_generic && b->B && b->c && c->cost == PLS_COST_GAUSSIAN && c->link == PLS_LINK_IDENTITY;
 }
 
+static int64_t onb_max_slabs(int64_t mk, int64_t j, int64_t n) {
+  int64_t kc;
+  return plan_split_k(mk, j, n, &kc);
+}
+
 size_t pls_onb_step_workspace_bytes(const pls_onb_desc *basis, int64_t j, int64_t n_chunk) {
   if (!basis || j <= 0) return 0;
   if (n_chunk <= 0 || n_chunk > basis->n) n_chunk = basis->n;
-  // D (mk x j) + G chunk (n_chunk x j)
-  return align_up((size_t)basis->mk * j * sizeof(double), 256) + (size_t)n_chunk * j * sizeof(double);
+  // D slabs (split-K of the back-projection, each mk x j) + G chunk (n_chunk x j)
+  return (size_t)onb_max_slabs(basis->mk, j, basis->n) * align_up((size_t)basis->mk * j * sizeof(double), 256) +
+         (size_t)n_chunk * j * sizeof(double);
 }
 
 int pls_onb_step(const pls_onb_desc *basis, const pls_cost_desc *cost, const double *y, double *U, int64_t ldu,
@@ -779,20 +819,23 @@ int pls_onb_step(const pls_onb_desc *basis, const pls_cost_desc *cost, const dou
     return launch_gemm(basis->B, basis->ldb, U, ldu, basis->mk, j, basis->mk, e, st);
   }
   const size_t d_bytes = align_up((size_t)basis->mk * j * sizeof(double), 256);
+  const int64_t max_slabs = onb_max_slabs(basis->mk, j, basis->n);
   const int64_t min_rows = basis->n < 128 ? basis->n : 128;
-  if (!workspace || workspace_bytes < d_bytes + (size_t)min_rows * j * sizeof(double))
+  if (!workspace || workspace_bytes < max_slabs * d_bytes + (size_t)min_rows * j * sizeof(double))
     return fail(PLS_ERR_WORKSPACE_TOO_SMALL, "onb_step: workspace %zu bytes, need at least %zu", workspace_bytes,
                 pls_onb_step_workspace_bytes(basis, j, 128));
   double *D = static_cast<double *>(workspace);
-  double *Gbuf = reinterpret_cast<double *>(static_cast<char *>(workspace) + d_bytes);
-  const int64_t n_chunk = pick_chunk(basis->n, workspace_bytes - d_bytes, j, 0);
-  rc = stream_drift(basis->A, basis->lda, basis->At, basis->ldat, basis->mk, basis->n, U, ldu, j, cp, y, D, j, Gbuf,
-                    n_chunk, st);
+  double *Gbuf = reinterpret_cast<double *>(static_cast<char *>(workspace) + max_slabs * d_bytes);
+  const int64_t n_chunk = pick_chunk(basis->n, workspace_bytes - max_slabs * d_bytes, j, 0);
+  int64_t nslab = 1;
+  rc = stream_drift(basis->A, basis->lda, basis->At, basis->ldat, basis->mk, basis->n, U, ldu, j, cp, y, D, j, max_slabs,
+                    (int64_t)(d_bytes / sizeof(double)), &nslab, Gbuf, n_chunk, st);
   if (rc) return rc;
   {
     LaunchScope scope(PLS_TAG_LANGEVIN_UPDATE, st);
     hipLaunchKernelGGL(langevin_update_kernel, dim3((unsigned)cdiv(j, 256), rows_grid(cdiv(basis->mk, 8) * 4)), dim3(256), 0,
-                       st, out, ldo, U, ldu, D, j, U, ldu, basis->lam, 0.0, basis->mk, j, eta, sqrt(2.0 * eta), out_mode, nz);
+                       st, out, ldo, U, ldu, D, j, (int)nslab, (int64_t)(d_bytes / sizeof(double)), U, ldu, basis->lam, 0.0,
+                       basis->mk, j, eta, sqrt(2.0 * eta), out_mode, nz);
   }
   return check_launch("langevin_update");
 }
@@ -860,8 +903,8 @@ int pls_ipb_forward(const pls_ipb_desc *basis, const double *U, int64_t ldu, int
 }
 
 // shared tail of the IPB update: out = [U +] -eta*D - eta*M*V + sqrt(2 eta) e
-static int ipb_finish(const pls_ipb_desc *basis, const double *U, int64_t ldu, const double *D, const double *V,
-                      int64_t j, double eta, const pls_noise_desc *noise, double *out, int64_t ldo, int add_u,
+static int ipb_finish(const pls_ipb_desc *basis, const double *U, int64_t ldu, const double *D, int nslab,
+                      int64_t slab_stride, const double *V, int64_t j, double eta, const pls_noise_desc *noise, double *out, int64_t ldo, int add_u,
                       double *xi_buf, double *e_buf, hipStream_t st) {
   NoiseP nz = make_noisep(noise);
   if (nz.kind == PLS_NOISE_PHILOX) {
@@ -878,8 +921,8 @@ static int ipb_finish(const pls_ipb_desc *basis, const double *U, int64_t ldu, c
     nz.ldxi = j;
   }
   hipLaunchKernelGGL(langevin_update_kernel, dim3((unsigned)cdiv(j, 256), rows_grid(cdiv(basis->m, 8) * 4)), dim3(256), 0, st,
-                     out, ldo, U, ldu, D, j, V, j, (const double *)nullptr, (double)basis->m, basis->m, j, eta,
-                     sqrt(2.0 * eta), add_u, nz);
+                     out, ldo, U, ldu, D, j, nslab, slab_stride, V, j, (const double *)nullptr, (double)basis->m, basis->m, j,
+                     eta, sqrt(2.0 * eta), add_u, nz);
   return check_launch("langevin_update");
 }
 
@@ -903,13 +946,15 @@ int pls_ipb_particle_update(const pls_ipb_desc *basis, const double *U, int64_t 
   if (rc) return rc;
   rc = pls_gemm_tn(basis->Kxz, basis->ldkxz, G, ldg, D, j, basis->m, j, basis->n, 1.0, 0.0, stream);
   if (rc) return rc;
-  return ipb_finish(basis, U, ldu, D, V, j, eta, noise, dU, lddu, 0, xi, e, S(stream));
+  return ipb_finish(basis, U, ldu, D, 1, (int64_t)0, V, j, eta, noise, dU, lddu, 0, xi, e, S(stream));
 }
 
 size_t pls_ipb_step_workspace_bytes(const pls_ipb_desc *basis, int64_t j, int64_t n_chunk) {
   if (!basis || j <= 0) return 0;
   if (n_chunk <= 0 || n_chunk > basis->n) n_chunk = basis->n;
-  return 4 * align_up((size_t)basis->m * j * sizeof(double), 256) + (size_t)n_chunk * j * sizeof(double);
+  // V, xi, e (m x j each) + D slabs + G chunk
+  return (size_t)(3 + onb_max_slabs(basis->m, j, basis->n)) * align_up((size_t)basis->m * j * sizeof(double), 256) +
+         (size_t)n_chunk * j * sizeof(double);
 }
 
 int pls_ipb_step(const pls_ipb_desc *basis, const pls_cost_desc *cost, const double *y, double *U, int64_t ldu, int64_t j,
@@ -927,22 +972,26 @@ int pls_ipb_step(const pls_ipb_desc *basis, const pls_cost_desc *cost, const dou
   PLS_REQUIRE(out_mode == 0 || out_mode == 1, "ipb_step: out_mode must be 0 or 1");
   if (j == 0) return PLS_OK;
   const size_t mj = align_up((size_t)basis->m * j * sizeof(double), 256);
+  const int64_t max_slabs = onb_max_slabs(basis->m, j, basis->n);
+  const size_t fixed = (size_t)(3 + max_slabs) * mj;
   const int64_t min_rows = basis->n < 128 ? basis->n : 128;
-  if (!workspace || workspace_bytes < 4 * mj + (size_t)min_rows * j * sizeof(double))
+  if (!workspace || workspace_bytes < fixed + (size_t)min_rows * j * sizeof(double))
     return fail(PLS_ERR_WORKSPACE_TOO_SMALL, "ipb_step: workspace %zu bytes, need at least %zu", workspace_bytes,
                 pls_ipb_step_workspace_bytes(basis, j, 128));
   char *w = static_cast<char *>(workspace);
-  double *V = reinterpret_cast<double *>(w), *D = reinterpret_cast<double *>(w + mj);
-  double *xi = reinterpret_cast<double *>(w + 2 * mj), *e = reinterpret_cast<double *>(w + 3 * mj);
-  double *Gbuf = reinterpret_cast<double *>(w + 4 * mj);
-  const int64_t n_chunk = pick_chunk(basis->n, workspace_bytes - 4 * mj, j, 0);
+  double *V = reinterpret_cast<double *>(w), *xi = reinterpret_cast<double *>(w + mj);
+  double *e = reinterpret_cast<double *>(w + 2 * mj), *D = reinterpret_cast<double *>(w + 3 * mj);
+  double *Gbuf = reinterpret_cast<double *>(w + fixed);
+  const int64_t n_chunk = pick_chunk(basis->n, workspace_bytes - fixed, j, 0);
   hipStream_t st = S(stream);
   rc = pls_gemm_tn(basis->W, basis->ldw, U, ldu, V, j, basis->m, j, basis->m, 1.0, 0.0, stream);
   if (rc) return rc;
+  int64_t nslab = 1;
   rc = stream_drift(basis->Kzx, basis->ldkzx, basis->Kxz, basis->ldkxz, basis->m, basis->n, V, j, j, make_costp(cost), y,
-                    D, j, Gbuf, n_chunk, st);
+                    D, j, max_slabs, (int64_t)(mj / sizeof(double)), &nslab, Gbuf, n_chunk, st);
   if (rc) return rc;
-  return ipb_finish(basis, U, ldu, D, V, j, eta, noise, out, ldo, out_mode, xi, e, st);
+  return ipb_finish(basis, U, ldu, D, (int)nslab, (int64_t)(mj / sizeof(double)), V, j, eta, noise, out, ldo, out_mode, xi, e,
+                    st);
 }
 
 size_t pls_ipb_energy_workspace_bytes(const pls_ipb_desc *basis, int64_t j, int64_t n_chunk) {

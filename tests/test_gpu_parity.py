@@ -360,6 +360,33 @@ def test_onb_step_all_costs(P, n, m, j, d):
             assert gb._B is not None
 
 
+def test_onb_step_chunked_and_split_k(P):
+    """N streamed in several chunks (small workspace) with the back-projection split over K into slabs; the last
+    chunk is shorter than a slab.  Same numbers as the one-chunk run and as the oracle."""
+    pr = make_problem(5000, 40, 64, 3, seed=77)
+    ob, gb = build_onb(P, pr)
+    mk = ob.approximation_dimension
+    u = pr["u"][:mk].contiguous()
+    xi = torch.randn(mk, 64, generator=pr["gen"])
+    eta = 1e-3
+    for name, oc, gc in make_costs(P, pr["y"], pr["fstar"], pr["gen"])[:3]:
+        want = O.PLS(ob, oc).calculate_particle_update(u.clone(), eta, noise=xi)
+        tol = step_tolerance(ob, oc, u, eta, xi, want)
+        gb.workspace_bytes = 2 << 30
+        one = gb.fused_step(gc, cu(u), eta, noise=P.basis.NoiseSpec(injected=cu(xi)), force_generic=True)
+        lib = P.pkg._lib.load()
+        gb.workspace_bytes = lib.pls_onb_step_workspace_bytes(gb._desc(), 64, 2048)  # -> chunks of 2048, 2048, 904 rows
+        gb._ws.clear()
+        many = gb.fused_step(gc, cu(u), eta, noise=P.basis.NoiseSpec(injected=cu(xi)), force_generic=True)
+        assert relerr(one, want) < tol and relerr(many, want) < tol, name
+        assert relerr(many, one) < 1e-12, name
+        e_one = gb.fused_particle_energy(gc, cu(u))
+        gb.workspace_bytes = 8 * 64 * 8 * 3
+        gb._ws.clear()
+        e_many = gb.fused_particle_energy(gc, cu(u))
+        assert relerr(e_many, e_one) < 1e-12, name
+
+
 @pytest.mark.parametrize("n,m,j,d", [(512, 24, 64, 3), (100, 10, 7, 1), (700, 33, 130, 2)])
 def test_ipb_step_all_costs(P, n, m, j, d):
     pr = make_problem(n, m, j, d, seed=7 * n + m)
