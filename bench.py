@@ -34,7 +34,7 @@ CONFIGS = {
     # name: (N, M, J, D, cost)
     "c2": dict(n=100_000, m=1024, j=8192, d=8, cost="gaussian", eta=1e-5, obs=0.01,
                workload="configs[1]: synthetic regression N=1e5 M=1024 J=8192 D=8, RBF/ARD, ONB + Gaussian/identity, fp64"),
-    "c3": dict(n=50_000, m=512, j=16384, d=1, cost="poisson", eta=1e-6, obs=None,
+    "c3": dict(n=50_000, m=512, j=16384, d=1, cost="poisson", eta=1e-6, obs=None, threshold=1e-7,
                workload="configs[2]: Poisson (f^2 link) regression N=5e4 M=512 J=16384 D=1, ONB, fp64"),
     "small": dict(n=4096, m=128, j=512, d=4, cost="gaussian", eta=1e-4, obs=0.01,
                   workload="smoke-sized regression N=4096 M=128 J=512"),
@@ -122,11 +122,11 @@ def cpu_baseline(cfg, x, z, y, ls, lam_all, vec_all):
         for js in j_samples:
             log(f"cpu baseline: timing oracle steps at J={js}")
             u = torch.randn(mk, js, generator=torch.Generator().manual_seed(3))
-            u += pls.calculate_particle_update(u, cfg["eta"])  # warm-up
+            u += pls.calculate_particle_update(u, 1e-12)  # warm-up
             t0 = time.perf_counter()
             reps = 2
             for _ in range(reps):
-                u += pls.calculate_particle_update(u, cfg["eta"])  # faithful: eigh(I) noise, dense diag @ U, full F and G
+                u += pls.calculate_particle_update(u, 1e-12)  # faithful: eigh(I) noise, dense diag @ U, full F and G
                 log(f"cpu baseline: step done ({time.perf_counter() - t0:.1f} s since start of timing)")
             times[js] = (time.perf_counter() - t0) / reps
         (j1, t1), (j2, t2) = sorted(times.items())
@@ -153,6 +153,9 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workspace-gb", type=float, default=8.0, help="cap of the per-step G-chunk workspace")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="development aid: run rank 0's particle shard of an N-GPU job on ONE GPU (no collectives); "
+                         "the JSON line is marked emulated and is not a scaling result")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
 
@@ -167,7 +170,7 @@ def main():
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
 
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:
         dist.init_process_group("nccl", rank=rank, world_size=world)  # RCCL; used for the barrier / max-time only
 
     import projected_langevin_sampling_amd as pkg
@@ -181,16 +184,16 @@ def main():
     log("synthetic data ready")
     t_setup = time.perf_counter()
     kernel = pkg.PLSKernel(pkg.ARDKernel(ls, 1.0), z)
-    basis = OrthonormalBasis(kernel, z, x, eigenvalue_threshold=0.0, verbose=False, keep_gram=False)
+    basis = OrthonormalBasis(kernel, z, x, eigenvalue_threshold=cfg.get("threshold", 0.0), verbose=False, keep_gram=False)
     basis.workspace_bytes = int(args.workspace_gb * (1 << 30))
     mk = basis.approximation_dimension
     cost = (PoissonCost(y, SquareLinkFunction()) if cfg["cost"] == "poisson"
             else GaussianCost(cfg["obs"], y, IdentityLinkFunction()))
     j_total = cfg["j"]
-    j0, j1 = D.attach_shard(basis, j_total, rank, world)
+    shard_world = args.emulate_world if (args.emulate_world > 1 and world == 1) else world
+    j0, j1 = D.attach_shard(basis, j_total, rank, shard_world)
     j_loc = j1 - j0
-    eta = cfg["eta"]
-    assert eta / basis.eigenvalues.min().item() < 2.0, "step size too large for the kept spectrum (SURVEY H5)"
+    eta = min(cfg["eta"], 0.5 * basis.eigenvalues.min().item())  # eta / lambda_min < 2 keeps the prior drift stable
     # identical initial particles for any GPU count: one seeded (Mk, J) draw, every rank keeps its columns
     u_full = torch.normal(0.0, 1.0, size=(mk, j_total), generator=torch.Generator().manual_seed(0), dtype=torch.float64)
     ping = u_full[:, j0:j1].contiguous().cuda()
@@ -204,7 +207,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -249,6 +252,16 @@ def main():
     gemm_launches = sum(tl[k]["launches"] for k in ("gemm_cost_deriv", "gemm_store") if k in tl)
     flop_per_step_rank = 4.0 * n * m * j_loc
     achieved = flop_per_step_rank * args.steps / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    traffic, traffic_src = None, None
+    prof = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    if args.config == "c2" and world == 1 and shard_world == 1 and os.path.exists(prof):
+        # HBM bytes per launch of the same two kernels on the same workload, from separate rocprofv3 --pmc passes
+        # (FETCH_SIZE doubled, WRITE_SIZE as is: MI355X_MICROARCH.md "HBM"); see tools/profile_bench.sh
+        pm = json.load(open(prof))
+        ks = [pm.get("gemm_tn_f64<128x128>::EpiCostDeriv", {}), pm.get("gemm_tn_f64<128x128>::EpiStore", {})]
+        if all("hbm_bytes_per_launch" in k for k in ks):
+            traffic = sum(k["hbm_bytes_per_launch"] for k in ks) / len(ks)
+            traffic_src = "profiles/r01_pmc_summary.json"
     roofline = {
         "kernel": "gemm_tn_f64_kernel<128,128,64,64,16,*> (cost-derivative + back-projection launches of the step)",
         "bound": "mfma",
@@ -256,7 +269,10 @@ def main():
         "peak": FP64_MFMA_PEAK_TFLOPS,
         "unit": "TFLOP/s",
         "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-        "traffic": None,
+        "traffic": traffic,
+        "traffic_unit": "bytes per launch (fabric-side L2 misses incl. Infinity-Cache hits)",
+        "traffic_source": traffic_src,
+        "algorithmic_bytes_per_launch": 8.0 * (n * m + m * j_loc + 2 * n * j_loc) / 2.0,
         "flop_per_launch": flop_per_step_rank / max(gemm_launches / args.steps, 1),
         "avg_launch_ms": gemm_ms / max(gemm_launches, 1),
         "launches_per_step": gemm_launches / args.steps,
@@ -275,6 +291,7 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
+        **({"emulated_world": shard_world} if shard_world != world else {}),
         "config": {"workload": cfg["workload"], "N": n, "M": cfg["m"], "M_k": mk, "J": j_total, "J_per_gpu": j_loc,
                    "path": "like-for-like: F=A^T U -> d cost/d f -> A G, 4*N*M*J flop/step", "step_size": eta,
                    "parallelism": f"J-sharded x{world}, no per-step collective", "setup_s": round(t_setup, 2)},
@@ -303,7 +320,7 @@ def main():
         out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
