@@ -179,9 +179,17 @@ size_t pls_cost_value_workspace_bytes(int64_t n, int64_t j);
 int pls_cost_value(const pls_cost_desc *cost, const double *F, int64_t ldf, const double *y, int64_t n, int64_t j,
                    double *c, void *workspace, size_t workspace_bytes, void *stream);
 
-/* out = link(in) element-wise (rows x cols).  Replaces PLSLinkFunction.transform (link_functions.py:30-80). */
+/* out = link(in + col_offset[col]) element-wise (rows x cols); col_offset may be NULL.
+ * Replaces PLSLinkFunction.transform (link_functions.py:30-80) and, with the per-particle observation noise as
+ * col_offset, PLSCost.predict_samples (costs/base.py:117-133). */
 int pls_link_transform(int32_t link, double jitter, const double *in, int64_t ldin, int64_t rows, int64_t cols,
-                       double *out, int64_t ldout, void *stream);
+                       const double *col_offset, double *out, int64_t ldout, void *stream);
+
+/* out[r] = sum_j (S[r][j] - shift[r])^power, power in {1, 2}, shift may be NULL; fixed summation order.
+ * The two passes (power 1 -> mean, power 2 about the mean) replace prediction_samples.mean(dim=1) / .var(axis=1) at
+ * costs/gaussian.py:49-52; on a J-sharded run each pass is followed by one all-reduce of `rows` doubles. */
+int pls_row_power_sums(const double *S, int64_t lds, int64_t rows, int64_t cols, const double *shift, int32_t power,
+                       double *out, void *stream);
 
 /* out(rows x J) standard normals from the library's counter-based generator (same stream the fused
  * step uses).  Replaces torch.normal at basis/base.py:55-63 and samplers.py:30-35 for on-device runs. */

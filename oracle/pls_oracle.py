@@ -325,9 +325,11 @@ def _chol_solve(k: torch.Tensor, rhs: torch.Tensor) -> torch.Tensor:
 class OrthonormalBasis:
     """basis/orthonormal.py:22-159."""
 
-    def __init__(self, base_kernel, x_induce, x_train, eigenvalue_threshold: float = 0.0):
+    def __init__(self, base_kernel, x_induce, x_train, eigenvalue_threshold: float = 0.0, r_kernel=None):
         self.base_kernel = base_kernel
         self.x_induce = x_induce
+        # r(x1, x2, extra approximation samples): kernel.py:31-76 unless a test double is handed in
+        self.r_kernel = r_kernel or (lambda x1, x2, extra: pls_kernel_r(base_kernel, x_induce, x1, x2, extra))
         self.base_gram_induce = base_kernel(x_induce, x_induce)  # :36-38
         self.base_gram_induce_train = base_kernel(x_induce, x_train)  # :39-41
         self.eigenvalues, self.eigenvectors = torch.linalg.eigh(
@@ -379,13 +381,40 @@ class OrthonormalBasis:
         )  # :151-158
 
 
-class InducingPointBasis:
-    """basis/inducing_point.py:23-150."""
+    def sample_predictive_noise(self, particles, x):
+        """orthonormal.py:161-214 (without the optional additional noise distribution)."""
+        gram_x = self.r_kernel(x, x, x)  # :174-178
+        base_gram_x_induce = self.base_kernel(x, self.x_induce)  # :179-182
+        off = base_gram_x_induce @ self.scaled_eigenvectors @ torch.diag(self.eigenvalues)  # :183-185
+        cov = torch.concatenate(
+            [
+                torch.concatenate([torch.diag(self.eigenvalues), off.T], dim=1),
+                torch.concatenate([off, gram_x], dim=1),
+            ],
+            dim=0,
+        )  # :186-204
+        return sample_multivariate_normal(
+            mean=torch.zeros(cov.shape[0]), cov=cov, size=(particles.shape[1],)
+        ).T  # :205-209
 
-    def __init__(self, base_kernel, x_induce, y_induce, x_train):
+    def predict_untransformed_samples(self, particles, x, noise=None):
+        """orthonormal.py:216-244."""
+        base_gram_x_induce = self.base_kernel(x, self.x_induce)
+        if noise is None:
+            noise = self.sample_predictive_noise(particles, x)
+        mk = self.approximation_dimension
+        return noise[mk:, :] + (base_gram_x_induce @ self.scaled_eigenvectors @ (particles - noise[:mk, :]))
+
+
+class InducingPointBasis:
+    """basis/inducing_point.py:23-240."""
+
+    def __init__(self, base_kernel, x_induce, y_induce, x_train, r_kernel=None):
         self.base_kernel = base_kernel
         self.x_induce = x_induce
         self.y_induce = y_induce
+        self.r_kernel = r_kernel or (lambda x1, x2, extra: pls_kernel_r(base_kernel, x_induce, x1, x2, extra))
+        self.gram_induce = self.r_kernel(x_induce, x_induce, None)  # :38-40
         self.base_gram_induce = base_kernel(x_induce, x_induce)  # :41-43
         self.base_gram_induce_train = base_kernel(x_induce, x_train)  # :44-46
 
@@ -424,6 +453,54 @@ class InducingPointBasis:
             - step_size * self.approximation_dimension * v
             + math.sqrt(2.0 * step_size) * noise
         )  # :143-149
+
+
+    def sample_predictive_noise(self, particles, x):
+        """inducing_point.py:152-202 (without the optional additional noise distribution)."""
+        gram_x = self.r_kernel(x, x, x)
+        gram_induce_x = self.r_kernel(self.x_induce, x, x)
+        cov = torch.concatenate(
+            [
+                torch.concatenate([self.gram_induce, gram_induce_x], dim=1),
+                torch.concatenate([gram_induce_x.T, gram_x], dim=1),
+            ],
+            dim=0,
+        )
+        return sample_multivariate_normal(
+            mean=torch.zeros(cov.shape[0]), cov=cov, size=(particles.shape[1],)
+        ).T
+
+    def predict_untransformed_samples(self, particles, x, noise=None):
+        """inducing_point.py:204-240: G(x) + r(x,Z) r(Z,Z)^-1 (U - G(Z))."""
+        gram_x_induce = self.r_kernel(x, self.x_induce, x)
+        gram_induce = self.r_kernel(self.x_induce, self.x_induce, x)
+        if noise is None:
+            noise = self.sample_predictive_noise(particles, x)
+        m = self.approximation_dimension
+        return noise[m:, :] + gram_x_induce @ _chol_solve(gram_induce, particles - noise[:m, :])
+
+
+def cost_sample_observation_noise(observation_noise, number_of_particles, seed=None):
+    """costs/base.py:86-115."""
+    if observation_noise is None:
+        return torch.zeros(number_of_particles)
+    generator = torch.Generator().manual_seed(seed) if seed is not None else None
+    return torch.normal(mean=0.0, std=observation_noise, size=(number_of_particles,), generator=generator).flatten()
+
+
+def cost_predict_samples(link_function, untransformed_samples, observation_noise):
+    """costs/base.py:117-133: link(f + eps_j)."""
+    return link_function(untransformed_samples + observation_noise[None, :])
+
+
+def gaussian_predict_moments(prediction_samples):
+    """costs/gaussian.py:40-52: mean and (unbiased) variance over the particle axis."""
+    return prediction_samples.mean(dim=1), prediction_samples.var(axis=1)
+
+
+def temper_scale(y_calibration, mean, variance) -> float:
+    """temper/base.py:30-46: 2 * mean((y - m)^2 / sigma^2)."""
+    return 2 * torch.mean(torch.div(torch.square(y_calibration - mean), variance)).item()
 
 
 # --------------------------------------------------------------------------------------

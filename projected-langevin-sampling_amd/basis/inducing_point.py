@@ -4,6 +4,7 @@ from __future__ import annotations
 import torch
 
 from .. import _lib as L
+from .. import _ops
 from ..kernel import PLSKernel, _dev
 from ..samplers import sample_multivariate_normal
 from .base import NoiseSpec, PLSBasis, alloc_matrix
@@ -167,24 +168,21 @@ class InducingPointBasis(PLSBasis):
         if self.additional_predictive_noise_distribution is not None:
             extra = self.additional_predictive_noise_distribution.sample(predictive_noise.shape).reshape(predictive_noise.shape)
             predictive_noise = predictive_noise + _dev(extra)
-        return predictive_noise
+        return predictive_noise.contiguous()
 
     def predict_untransformed_samples(self, particles: torch.Tensor, x: torch.Tensor,
                                       noise: torch.Tensor | None = None) -> torch.Tensor:
-        """G(x) + r(x,Z) r(Z,Z)^-1 (U - G(Z))  (:204-240); the M x M solve is a host Cholesky (one-time per call)."""
+        """G(x) + r(x,Z) r(Z,Z)^-1 (U - G(Z))  (:204-240); the M x M solve is a host Cholesky (once per call)."""
+        u = _rows_contiguous(L.require_gpu_tensor(particles, "particles"))
         gram_induce_x = self.kernel.forward(x1=self.x_induce, x2=x, additional_approximation_samples=x)  # r(Z,x) (M,N*)
         gram_induce = self.kernel.forward(x1=self.x_induce, x2=self.x_induce, additional_approximation_samples=x)
         if noise is None:
             noise = self.sample_predictive_noise(particles=particles, x=x)
+        noise = L.require_gpu_tensor(noise, "noise")
         m = self.approximation_dimension
-        delta = (L.require_gpu_tensor(particles, "particles") - noise[:m, :]).contiguous()
-        w = _dev(torch.cholesky_inverse(torch.linalg.cholesky(gram_induce.cpu())))
-        j, nstar = delta.shape[1], gram_induce_x.shape[1]
-        lib = L.load()
-        v = torch.empty((m, j), dtype=torch.float64, device=delta.device)
-        L.check(lib.pls_gemm_tn(w.data_ptr(), m, delta.data_ptr(), L.ld(delta), v.data_ptr(), max(j, 1), m, j, m, 1.0, 0.0,
-                                L.stream_ptr()), "pls_gemm_tn")
+        w = _dev(torch.cholesky_inverse(torch.linalg.cholesky(gram_induce.cpu())))  # symmetric: W^T = W
+        q = _ops.gemm_tn(w, gram_induce_x)  # (M, N*) = r(Z,Z)^-1 r(Z,x)
         out = noise[m:, :].contiguous().clone()
-        L.check(lib.pls_gemm_tn(gram_induce_x.data_ptr(), L.ld(gram_induce_x), v.data_ptr(), max(j, 1), out.data_ptr(), L.ld(out),
-                                nstar, j, m, 1.0, 1.0, L.stream_ptr()), "pls_gemm_tn")
+        _ops.gemm_tn(q, u, 1.0, 1.0, out=out)
+        _ops.gemm_tn(q, noise[:m, :].contiguous(), -1.0, 1.0, out=out)
         return out

@@ -6,6 +6,7 @@ import math
 import torch
 
 from .. import _lib as L
+from .. import _ops
 from ..kernel import PLSKernel, _dev
 from ..samplers import sample_multivariate_normal
 from .base import NoiseSpec, PLSBasis, alloc_matrix
@@ -51,6 +52,7 @@ class OrthonormalBasis(PLSBasis):
         self.eigenvalues = _dev(eigenvalues)
         self.eigenvectors = _dev(eigenvectors)
         self.scaled_eigenvectors = _dev(scaled)  # (M, Mk)
+        self._scaled_eigenvectors_lam = _dev(scaled * eigenvalues[None, :])  # V~ diag(lambda), prediction only
         n = base_gram_induce_train.shape[1]
         self._n = n
         self._A = alloc_matrix(mk, n, dev)
@@ -202,44 +204,37 @@ class OrthonormalBasis(PLSBasis):
 
     # ---- prediction (one-time, not on the step path) -----------------------------------------------
     def sample_predictive_noise(self, particles: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
-        """(M_k + N*, J) joint Gaussian noise (:161-214); the (M_k+N*) eigh runs on the host like the reference."""
-        gram_x = self.kernel.forward(x1=x, x2=x, additional_approximation_samples=x)
-        base_gram_x_induce = self.kernel.base_kernel(x1=x, x2=self.x_induce)
-        off_diagonal_block = base_gram_x_induce @ self.scaled_eigenvectors @ torch.diag(self.eigenvalues)
+        """(M_k + N*, J) joint Gaussian noise G([Z, x]) (:161-214).  Gram blocks and the products are libplship
+        kernels; the (M_k + N*) eigh of the sampler runs on the host LAPACK exactly like the reference (samplers.py:27)."""
+        gram_x = self.kernel.forward(x1=x, x2=x, additional_approximation_samples=x)  # r(x,x)  :174-178
+        base_gram_induce_x = self.kernel.base_kernel(x1=self.x_induce, x2=x)  # k(Z,x) (M, N*): k-major operand
+        # off_diagonal_block = k(x,Z) V~ diag(lambda)  (N*, M_k)  :183-185 -- the column scale is folded into the operand
+        off = _ops.gemm_tn(base_gram_induce_x, self._scaled_eigenvectors_lam)
+        lam_diag = torch.diag(self.eigenvalues)
         noise_covariance = torch.cat(
-            [
-                torch.cat([torch.diag(self.eigenvalues), off_diagonal_block.T], dim=1),
-                torch.cat([off_diagonal_block, gram_x], dim=1),
-            ],
-            dim=0,
-        )
+            [torch.cat([lam_diag, off.T], dim=1), torch.cat([off, gram_x], dim=1)], dim=0
+        )  # (M_k+N*, M_k+N*)  :186-204
         predictive_noise = sample_multivariate_normal(
             mean=torch.zeros(noise_covariance.shape[0]), cov=noise_covariance, size=(particles.shape[1],)
-        ).T
+        ).T  # :205-209
         if self.additional_predictive_noise_distribution is not None:
             extra = self.additional_predictive_noise_distribution.sample(predictive_noise.shape).reshape(predictive_noise.shape)
-            predictive_noise = predictive_noise + _dev(extra)
-        return predictive_noise
+            predictive_noise = predictive_noise + _dev(extra)  # :210-213
+        return predictive_noise.contiguous()
 
     def predict_untransformed_samples(self, particles: torch.Tensor, x: torch.Tensor,
                                       noise: torch.Tensor | None = None) -> torch.Tensor:
-        """G(x) + k(x,Z) V~ (U - G(Z))  (:216-244)."""
-        base_gram_induce_x = self.kernel.base_kernel(x1=self.x_induce, x2=x)  # k(Z, x) (M, N*): k-major operand
+        """G(x) + k(x,Z) V~ (U - G(Z))  (:216-244), as  G(x) + P U - P G(Z)  with P^T = V~^T k(Z,x) built once."""
+        u = _rows_contiguous(L.require_gpu_tensor(particles, "particles"))
+        base_gram_induce_x = self.kernel.base_kernel(x1=self.x_induce, x2=x)  # k(Z, x) (M, N*)
         if noise is None:
             noise = self.sample_predictive_noise(particles=particles, x=x)
+        noise = L.require_gpu_tensor(noise, "noise")
         mk = self.approximation_dimension
-        delta = (L.require_gpu_tensor(particles, "particles") - noise[:mk, :]).contiguous()
-        j = delta.shape[1]
-        nstar = base_gram_induce_x.shape[1]
-        lib = L.load()
-        # P (N* x Mk) = k(x,Z) V~ ; then P delta via the k-major form with L = P^T = V~^T k(Z,x)
-        pt = torch.empty((mk, nstar), dtype=torch.float64, device=delta.device)
-        L.check(lib.pls_gemm_tn(self.scaled_eigenvectors.data_ptr(), L.ld(self.scaled_eigenvectors), base_gram_induce_x.data_ptr(),
-                                L.ld(base_gram_induce_x), pt.data_ptr(), max(nstar, 1), mk, nstar, self.x_induce.shape[0], 1.0, 0.0,
-                                L.stream_ptr()), "pls_gemm_tn")
+        pt = _ops.gemm_tn(self.scaled_eigenvectors, base_gram_induce_x)  # (M_k, N*) = V~^T k(Z,x)
         out = noise[mk:, :].contiguous().clone()
-        L.check(lib.pls_gemm_tn(pt.data_ptr(), max(nstar, 1), delta.data_ptr(), L.ld(delta), out.data_ptr(), L.ld(out), nstar, j, mk,
-                                1.0, 1.0, L.stream_ptr()), "pls_gemm_tn")
+        _ops.gemm_tn(pt, u, 1.0, 1.0, out=out)
+        _ops.gemm_tn(pt, noise[:mk, :].contiguous(), -1.0, 1.0, out=out)
         return out
 
 

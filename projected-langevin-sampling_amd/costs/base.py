@@ -117,6 +117,8 @@ class PLSCost(ABC):
         """costs/base.py:117-133."""
         if observation_noise is None:
             observation_noise = self.sample_observation_noise(number_of_particles=untransformed_samples.shape[1])
+        if getattr(self.link_function, "kind", None) is not None:  # one kernel: link(f + eps_j)
+            return self.link_function._native_transform(untransformed_samples, col_offset=_dev(observation_noise))
         return self.link_function(untransformed_samples + observation_noise[None, :])
 
 

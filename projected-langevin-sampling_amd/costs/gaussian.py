@@ -19,9 +19,11 @@ class GaussianCost(PLSCost):
     def _params(self):
         return (float(self.observation_noise), 0.0, 0.0, 0.0)
 
-    def predict(self, prediction_samples: torch.Tensor) -> torch.distributions.MultivariateNormal:
-        """gaussian.py:40-52: moments over the particle axis."""
-        return torch.distributions.MultivariateNormal(
-            loc=prediction_samples.mean(dim=1),
-            covariance_matrix=torch.diag(prediction_samples.var(axis=1)),
-        )
+    def predict(self, prediction_samples: torch.Tensor, number_of_particles: int | None = None,
+                group=None) -> torch.distributions.MultivariateNormal:
+        """gaussian.py:40-52: mean and unbiased variance over the particle axis.  On a J-sharded run pass the global
+        particle count: the two passes are then all-reduced over the ranks (distributed.predictive_moments)."""
+        from ..distributed import predictive_moments
+
+        mean, var = predictive_moments(prediction_samples, number_of_particles or prediction_samples.shape[1], group=group)
+        return torch.distributions.MultivariateNormal(loc=mean, covariance_matrix=torch.diag(var))

@@ -435,13 +435,36 @@ __global__ __launch_bounds__(256) void langevin_update_kernel(double *out, int64
 
 __global__ __launch_bounds__(256) void link_transform_kernel(int link, double jitter, const double *__restrict__ in,
                                                               int64_t ldin, int64_t rows, int64_t cols,
+                                                              const double *__restrict__ col_offset,
                                                               double *__restrict__ out, int64_t ldout) {
   const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (col >= cols) return;
+  const double off = col_offset ? col_offset[col] : 0.0;
   for (int64_t row = blockIdx.y; row < rows; row += gridDim.y) {
     double slope;
-    out[row * ldout + col] = link_eval(link, in[row * ldin + col], jitter, &slope);
+    out[row * ldout + col] = link_eval(link, in[row * ldin + col] + off, jitter, &slope);
   }
+}
+
+// out[row] = sum_j (S[row][j] - shift[row])^power: one block per row, fixed-order tree reduction
+__global__ __launch_bounds__(256) void row_power_sums_kernel(const double *__restrict__ S, int64_t lds, int64_t cols,
+                                                              const double *__restrict__ shift, int power,
+                                                              double *__restrict__ out) {
+  __shared__ double red[256];
+  const double *row = S + (int64_t)blockIdx.x * lds;
+  const double sh = shift ? shift[blockIdx.x] : 0.0;
+  double s = 0.0;
+  for (int64_t k = threadIdx.x; k < cols; k += 256) {
+    const double v = row[k] - sh;
+    s += (power == 2) ? v * v : v;
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = red[0];
 }
 
 __global__ __launch_bounds__(256) void normal_fill_kernel(double *__restrict__ out, int64_t ldo, int64_t rows,
@@ -699,13 +722,23 @@ int pls_cost_value(const pls_cost_desc *cost, const double *F, int64_t ldf, cons
 }
 
 int pls_link_transform(int32_t link, double jitter, const double *in, int64_t ldin, int64_t rows, int64_t cols,
-                       double *out, int64_t ldout, void *stream) {
+                       const double *col_offset, double *out, int64_t ldout, void *stream) {
   PLS_REQUIRE(link >= PLS_LINK_IDENTITY && link <= PLS_LINK_PROBIT, "link_transform: unknown link %d", link);
   PLS_REQUIRE(in && out && rows >= 0 && cols >= 0 && ldin >= cols && ldout >= cols, "link_transform: bad arguments");
   if (rows == 0 || cols == 0) return PLS_OK;
   hipLaunchKernelGGL(link_transform_kernel, dim3((unsigned)cdiv(cols, 256), rows_grid(rows)), dim3(256), 0, S(stream),
-                     link, jitter, in, ldin, rows, cols, out, ldout);
+                     link, jitter, in, ldin, rows, cols, col_offset, out, ldout);
   return check_launch("link_transform");
+}
+
+int pls_row_power_sums(const double *samples, int64_t lds, int64_t rows, int64_t cols, const double *shift, int32_t power,
+                       double *out, void *stream) {
+  PLS_REQUIRE(samples && out && rows >= 0 && cols >= 0 && lds >= cols, "row_power_sums: bad arguments");
+  PLS_REQUIRE(power == 1 || power == 2, "row_power_sums: power must be 1 or 2");
+  PLS_REQUIRE(rows <= 0x7fffffff, "row_power_sums: too many rows");
+  if (rows == 0) return PLS_OK;
+  hipLaunchKernelGGL(row_power_sums_kernel, dim3((unsigned)rows), dim3(256), 0, S(stream), samples, lds, cols, shift, power, out);
+  return check_launch("row_power_sums");
 }
 
 int pls_normal_fill(double *out, int64_t ldout, int64_t rows, int64_t j, uint64_t seed, uint64_t step, int64_t j_offset,

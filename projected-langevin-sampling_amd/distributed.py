@@ -43,14 +43,27 @@ def mean_over_particles(local_values: torch.Tensor, number_of_particles: int, gr
 
 
 def predictive_moments(local_samples: torch.Tensor, number_of_particles: int, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Mean and unbiased variance over all J particles of (N*, J_local) samples: all-reduce of (N*, 2) sums
-    (collective C2; replaces prediction_samples.mean(dim=1) / .var(axis=1) at gaussian.py:49-52 on a sharded run)."""
-    sums = torch.stack([local_samples.sum(dim=1), (local_samples * local_samples).sum(dim=1)], dim=1)
+    """Mean and unbiased variance over all J particles of (N*, J_local) samples, two passes (sum, then squared deviations
+    about the global mean), each followed by one all-reduce of N* doubles (collective C2; replaces
+    prediction_samples.mean(dim=1) / .var(axis=1) at gaussian.py:49-52).  Device tensors go through libplship's
+    fixed-order row reduction; CPU tensors (tests of the bookkeeping) through torch."""
+    on_gpu = local_samples.device.type == "cuda"
+    if on_gpu:
+        from . import _ops
+
+        s1 = _ops.row_power_sums(local_samples, 1)
+    else:
+        s1 = local_samples.sum(dim=1)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
-    mean = sums[:, 0] / number_of_particles
-    var = (sums[:, 1] - number_of_particles * mean * mean) / (number_of_particles - 1)
-    return mean, var
+        dist.all_reduce(s1, op=dist.ReduceOp.SUM, group=group)
+    mean = s1 / number_of_particles
+    if on_gpu:
+        s2 = _ops.row_power_sums(local_samples, 2, shift=mean)
+    else:
+        s2 = ((local_samples - mean[:, None]) ** 2).sum(dim=1)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(s2, op=dist.ReduceOp.SUM, group=group)
+    return mean, s2 / (number_of_particles - 1)
 
 
 def gather_particles(local_particles: torch.Tensor, number_of_particles: int, group=None) -> torch.Tensor:

@@ -23,15 +23,17 @@ class PLSLinkFunction(ABC):
     def __call__(self, *args, **kwargs):
         return self.transform(*args, **kwargs)
 
-    def _native_transform(self, y: torch.Tensor) -> torch.Tensor:
+    def _native_transform(self, y: torch.Tensor, col_offset: torch.Tensor | None = None) -> torch.Tensor:
+        """link(y + col_offset[None, :]) in one libplship kernel."""
         L.require_gpu_tensor(y, "y")
         y2 = y.reshape(1, -1) if y.dim() != 2 else y
         y2 = y2 if y2.stride(-1) == 1 else y2.contiguous()
         out = torch.empty(y2.shape, dtype=torch.float64, device=y.device)
         L.check(
             L.load().pls_link_transform(
-                self.kind, float(self.jitter), y2.data_ptr(), L.ld(y2), y2.shape[0], y2.shape[1], out.data_ptr(),
-                L.ld(out), L.stream_ptr(),
+                self.kind, float(self.jitter), y2.data_ptr(), L.ld(y2), y2.shape[0], y2.shape[1],
+                None if col_offset is None else L.require_gpu_tensor(col_offset, "col_offset").contiguous().data_ptr(),
+                out.data_ptr(), L.ld(out), L.stream_ptr(),
             ),
             "pls_link_transform",
         )
@@ -44,7 +46,7 @@ class IdentityLinkFunction(PLSLinkFunction):
     kind = L.LINK_IDENTITY
 
     def transform(self, y: torch.Tensor) -> torch.Tensor:
-        return y
+        return y  # link_functions.py:54-55 returns its argument
 
 
 class SquareLinkFunction(PLSLinkFunction):

@@ -608,3 +608,99 @@ def test_full_size_properties(P):
     f = gb.calculate_untransformed_train_prediction_samples(u[:, :512].contiguous())
     e_unfused = gb.particle_energy_potential(u[:, :512].contiguous(), gc.calculate_cost(f))
     assert relerr(e_fused, e_unfused) < 1e-11
+
+
+# ------------------------------------------------------------------------------------------------------------
+# 7. prediction + tempering -- pinned by the reference's tests/test_basis.py:522-977
+# ------------------------------------------------------------------------------------------------------------
+def _mock_pls_kernel(P, z):
+    """The reference's MockProjectedLangevinSamplingKernel (mockers/kernel.py:26-43): r = plain inner product."""
+
+    class MockPLSKernel(P.pkg.PLSKernel):
+        def forward(self, x1, x2, additional_approximation_samples=None, **kw):
+            return self.base_kernel(x1, x2)
+
+        __call__ = forward
+
+    return MockPLSKernel(P.pkg.LinearKernel(), z)
+
+
+def test_reference_goldens_prediction(P, G):
+    fx, pg = G["basis_fixture"], G["prediction"]
+    z, xt, x = torch.tensor(fx["x_induce"]), torch.tensor(fx["x_train"]), torch.tensor(pg["x"])
+    u = cu(torch.tensor(fx["particles"]))
+    onb = P.basis.OrthonormalBasis(_mock_pls_kernel(P, z), z, xt, 0.0, verbose=False)
+    ipb = P.basis.InducingPointBasis(_mock_pls_kernel(P, z), z, torch.tensor(fx["y_induce"]), xt)
+    torch.set_default_dtype(torch.float32)  # the reference's tests draw float32 normals
+    torch.manual_seed(0)
+    got = onb.sample_predictive_noise(u, x).cpu()
+    assert torch.allclose(got, torch.tensor(pg["onb_predictive_noise_seed0"], dtype=torch.float64), rtol=1e-3, atol=5e-3)
+    torch.manual_seed(0)
+    got = ipb.sample_predictive_noise(u, x).cpu()
+    assert torch.allclose(got, torch.tensor(pg["ipb_predictive_noise_seed0"], dtype=torch.float64), rtol=1e-3, atol=5e-3)
+    noise = cu(torch.tensor(pg["onb_predict_with_noise"]["noise"]))
+    got = onb.predict_untransformed_samples(u, x, noise=noise).cpu()
+    assert torch.allclose(got, torch.tensor(pg["onb_predict_with_noise"]["value"], dtype=torch.float64), rtol=1e-3)
+    torch.manual_seed(1)
+    got = onb.predict_untransformed_samples(u, x, noise=None).cpu()
+    assert torch.allclose(got, torch.tensor(pg["onb_predict_sampled_seed1"], dtype=torch.float64), rtol=1e-3, atol=5e-3)
+
+
+def test_prediction_vs_oracle(P):
+    pr = make_problem(300, 12, 40, 2, seed=31)
+    ob, gb = build_onb(P, pr)
+    pr2 = dict(pr)
+    pr2["ls"] = pr["ls"] * 0.35
+    oi, gi = build_ipb(P, pr2)
+    g = pr["gen"]
+    xs = torch.rand(9, 2, generator=g) * 2 - 1
+    mk = ob.approximation_dimension
+    u = pr["u"][:mk].contiguous()
+    noise = torch.randn(mk + 9, 40, generator=g)
+    assert relerr(gb.predict_untransformed_samples(cu(u), xs, noise=cu(noise)), ob.predict_untransformed_samples(u, xs, noise=noise)) < TOL
+    noise_i = torch.randn(12 + 9, 40, generator=g)
+    tol_i = max(TOL, torch.linalg.cond(oi.r_kernel(pr["z"], pr["z"], xs)).item() * 1e-14)
+    assert relerr(gi.predict_untransformed_samples(cu(pr["u"]), xs, noise=cu(noise_i)),
+                  oi.predict_untransformed_samples(pr["u"], xs, noise=noise_i)) < tol_i
+    # sampled noise: same torch CPU stream, same host LAPACK eigh -> same joint sample up to the Gram rounding
+    torch.manual_seed(5)
+    want = ob.sample_predictive_noise(u, xs)
+    torch.manual_seed(5)
+    got = gb.sample_predictive_noise(cu(u), xs)
+    assert relerr(got, want) < 1e-6
+    # full predict: link(f + eps_j), Gaussian moments over J, tempering scale
+    oc = O.GaussianCost(0.3, pr["y"], O.IdentityLink())
+    gc = P.costs.GaussianCost(0.3, pr["y"], P.links.IdentityLinkFunction())
+    pls = P.pkg.PLS(gb, gc)
+    eps = O.cost_sample_observation_noise(0.3, 40, seed=9)
+    f_want = ob.predict_untransformed_samples(u, xs, noise=noise)
+    s_want = O.cost_predict_samples(O.IdentityLink(), f_want, eps)
+    s_got = pls.predict_samples(cu(u), xs, predictive_noise=cu(noise), observation_noise=gc.sample_observation_noise(40, seed=9))
+    assert relerr(s_got, s_want) < TOL
+    m_want, v_want = O.gaussian_predict_moments(s_want)
+    dist = gc.predict(s_got)
+    assert relerr(dist.mean, m_want) < 1e-12 and relerr(torch.diag(dist.covariance_matrix), v_want) < 1e-11
+    sig = P.costs.BernoulliCost((pr["y"] > 0).double(), P.links.SigmoidLinkFunction())
+    assert relerr(sig.predict_samples(cu(f_want), cu(eps)), O.cost_predict_samples(O.SigmoidLink(), f_want, eps)) < 1e-13
+
+
+def test_temper_scale_vs_oracle(P):
+    from projected_langevin_sampling_amd.temper import TemperPLS
+
+    pr = make_problem(200, 10, 64, 1, seed=41)
+    ob, gb = build_onb(P, pr)
+    mk = ob.approximation_dimension
+    u = pr["u"][:mk].contiguous()
+    gc = P.costs.GaussianCost(0.3, pr["y"], P.links.IdentityLinkFunction())
+    xc, yc = pr["x"][:25], pr["y"][:25]
+    torch.manual_seed(3)
+    t = TemperPLS(xc, yc, P.pkg.PLS(gb, gc), cu(u))
+    torch.manual_seed(3)
+    noise = ob.sample_predictive_noise(u, xc)
+    f = ob.predict_untransformed_samples(u, xc, noise=noise)
+    s = O.cost_predict_samples(O.IdentityLink(), f, O.cost_sample_observation_noise(0.3, 64))
+    m, v = O.gaussian_predict_moments(s)
+    assert abs(t.scale - O.temper_scale(yc, m, v)) <= 1e-5 * abs(t.scale)
+    torch.manual_seed(3)
+    d = t(xc)
+    assert relerr(torch.diag(d.covariance_matrix), t.scale * v) < 1e-5

@@ -259,3 +259,28 @@ def test_train_pls_early_stop_rule():
     assert es.should_stop(0.5, 0.1) is False
     assert es.should_stop(0.5, 0.1) is True  # 0.3 >= 0.25
     assert O.EarlyStopper().should_stop(float("nan"), 0.1) is True
+
+
+# ---- prediction, pinned by the reference's test_basis.py:522-977 -----------------------------
+
+
+def _linear_r(x1, x2, extra=None):
+    return x1 @ x2.T  # mockers/kernel.py:26-43: the test double's r is the plain inner product
+
+
+def test_prediction_goldens(G):
+    fx, pg = G["basis_fixture"], G["prediction"]
+    z, xt, u, x = t32(fx["x_induce"]), t32(fx["x_train"]), t32(fx["particles"]), t32(pg["x"])
+    onb = O.OrthonormalBasis(O.LinearKernel(), z, xt, 0.0, r_kernel=_linear_r)
+    ipb = O.InducingPointBasis(O.LinearKernel(), z, t32(fx["y_induce"]), xt, r_kernel=_linear_r)
+    torch.manual_seed(0)
+    assert torch.allclose(onb.sample_predictive_noise(u, x), t32(pg["onb_predictive_noise_seed0"]), rtol=1e-3, atol=2e-4)
+    torch.manual_seed(0)
+    # the 4x4 covariance of this fixture has rank 3: its fourth eigenvalue is float32 rounding noise (~1e-5 * ||cov||), so
+    # sqrt(clip(lambda)) injects an arbitrary +-3e-3 component that depends on the LAPACK build -> atol 5e-3
+    assert torch.allclose(ipb.sample_predictive_noise(u, x), t32(pg["ipb_predictive_noise_seed0"]), rtol=1e-3, atol=5e-3)
+    got = onb.predict_untransformed_samples(u, x, noise=t32(pg["onb_predict_with_noise"]["noise"]))
+    assert torch.allclose(got, t32(pg["onb_predict_with_noise"]["value"]), rtol=1e-3)
+    torch.manual_seed(1)
+    got = onb.predict_untransformed_samples(u, x, noise=None)
+    assert torch.allclose(got, t32(pg["onb_predict_sampled_seed1"]), rtol=1e-3)
