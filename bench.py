@@ -153,6 +153,8 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workspace-gb", type=float, default=8.0, help="cap of the per-step G-chunk workspace")
+    ap.add_argument("--converge-steps", type=int, default=4000,
+                    help="step cap of the wall-clock-to-converged-energy run (0 = skip it)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="development aid: run rank 0's particle shard of an N-GPU job on ONE GPU (no collectives); "
                          "the JSON line is marked emulated and is not a scaling result")
@@ -199,8 +201,14 @@ def main():
     ping = u_full[:, j0:j1].contiguous().cuda()
     pong = torch.empty_like(ping)
     del u_full
+    rho = None
     if cfg["cost"] == "gaussian":
         basis.prepare_gaussian(cost.y_device())
+        # Euler-Maruyama is stable for eta * rho < 2, rho = largest eigenvalue of the drift Jacobian B/sigma2 + Lambda^-1;
+        # the reference finds a usable step by search (experiments/runners.py:356-433), here it is read off the spectrum
+        jac = (basis._B.cpu() / cfg["obs"]) + torch.diag(1.0 / basis.eigenvalues.cpu())
+        rho = torch.linalg.eigvalsh(jac)
+        eta = min(eta, 1.0 / rho.max().item())
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup
     log(f"basis ready (M_k = {mk}), setup {t_setup:.2f} s")
@@ -313,6 +321,31 @@ def main():
                          "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
                          "traffic": None, "avg_launch_ms": k["avg_ms"]},
         }
+    # ---- wall-clock to converged energy: the reference's train_pls loop (step, energy, early stop) ----
+    if cfg["cost"] == "gaussian" and args.converge_steps > 0:
+        from projected_langevin_sampling_amd.trainers import train_pls
+
+        eta_c = 1.0 / rho.max().item()
+        patience = 100 * eta_c
+        u0 = torch.normal(0.0, 1.0, size=(mk, j_total), generator=torch.Generator().manual_seed(0), dtype=torch.float64)
+        particles = u0[:, j0:j1].contiguous().cuda()
+        del u0
+        pls = pkg.PLS(basis, cost)
+        torch.manual_seed(0)
+        reduce_fn = (lambda e: D.mean_over_particles(e, j_total)) if world > 1 else None
+        barrier()
+        t0 = time.perf_counter()
+        particles, energies = train_pls(pls, particles, args.converge_steps, eta_c, patience, energy_reduce=reduce_fn)
+        barrier()
+        wall = time.perf_counter() - t0
+        out["converged_energy"] = {
+            "wall_s": wall, "steps": len(energies), "step_cap": args.converge_steps, "stopped_early": len(energies) < args.converge_steps,
+            "step_size": eta_c, "patience_simulated_time": patience, "first_energy": energies[0] if energies else None,
+            "final_energy": energies[-1] if energies else None, "ms_per_step_with_energy": wall / max(len(energies), 1) * 1e3,
+            "loop": "train_pls (experiments/trainers.py:139-162): fused step + energy (.item() sync) + EarlyStopper every step",
+            "relaxation_rate_min": rho.min().item(), "stiffness_max": rho.max().item(),
+        }
+        log(f"train_pls: {len(energies)} steps in {wall:.2f} s, energy {energies[0]:.4g} -> {energies[-1]:.4g}")
     # ---- CPU baseline (rank 0, N=1 only) ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         lam_all, vec_all = basis.eigenvalues.cpu(), basis.eigenvectors.cpu()

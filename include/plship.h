@@ -104,7 +104,8 @@ typedef struct {
  *   At = k(X,Z) V~        (N x Mk), ldat  -- the same matrix transposed, so both contractions stream
  *                                            k-major operands (DESIGN.md "data layout")
  *   lam = kept eigenvalues of k(Z,Z)/M (Mk)
- * Optional Gaussian/identity fast path (paper's O(M^3 + J M^2) step): B = A A^T (Mk x Mk), c = A y (Mk). */
+ * Optional Gaussian/identity fast path (paper's O(M^3 + J M^2) step): B = A A^T (Mk x Mk), c = A y (Mk entries,
+ * followed by ONE more entry c[Mk] = y^T y used by the fast energy). */
 typedef struct {
   int64_t mk, n;
   const double *A;
@@ -206,7 +207,7 @@ int pls_normal_fill(double *out, int64_t ldout, int64_t rows, int64_t j, uint64_
 int pls_onb_build_projection(const double *Vs, int64_t ldvs, const double *Kzx, int64_t ldkzx, int64_t m, int64_t mk,
                              int64_t n, double *A, int64_t lda, double *At, int64_t ldat, void *stream);
 
-/* Gaussian/identity fast path constants: B = A A^T (Mk x Mk) and c = A y (Mk). */
+/* Gaussian/identity fast path constants: B = A A^T (Mk x Mk), c[0..Mk) = A y and c[Mk] = y^T y (c holds Mk + 1 doubles). */
 int pls_onb_build_gaussian(const pls_onb_desc *basis, const double *y, double *B, int64_t ldb, double *c,
                            void *stream);
 
@@ -237,10 +238,13 @@ int pls_onb_step(const pls_onb_desc *basis, const pls_cost_desc *cost, const dou
 
 /* e(J) = cost_j + 0.5 * sum_m U_mj^2 / lam_m  (per-particle energy; the caller takes the mean over all
  * particles of all ranks).  Replaces PLS.calculate_energy_potential -> OrthonormalBasis.calculate_energy_potential
- * (projected_langevin_sampling.py:125-138, orthonormal.py:110-126). */
+ * (projected_langevin_sampling.py:125-138, orthonormal.py:110-126).
+ * Gaussian/identity with basis->B/c set (and force_generic == 0): cost_j = (u_j^T B u_j - 2 c^T u_j + y^T y) / (2 sigma2)
+ * from ONE Mk x Mk x J contraction instead of the N x Mk x J one. */
 size_t pls_onb_energy_workspace_bytes(const pls_onb_desc *basis, int64_t j, int64_t n_chunk);
 int pls_onb_energy(const pls_onb_desc *basis, const pls_cost_desc *cost, const double *y, const double *U,
-                   int64_t ldu, int64_t j, double *e, void *workspace, size_t workspace_bytes, void *stream);
+                   int64_t ldu, int64_t j, double *e, int32_t force_generic, void *workspace, size_t workspace_bytes,
+                   void *stream);
 
 /* e(J) = cost_j + 0.5 * sum_m U_mj^2 / lam_m with the cost vector handed in (cost may be NULL = zeros).
  * Replaces OrthonormalBasis.calculate_energy_potential(particles, cost) (orthonormal.py:110-126) before its

@@ -93,7 +93,7 @@ class OrthonormalBasis(PLSBasis):
             return
         mk = self.approximation_dimension
         self._B = alloc_matrix(mk, mk, y_dev.device)
-        self._c = torch.empty(mk, dtype=torch.float64, device=y_dev.device)
+        self._c = torch.empty(mk + 1, dtype=torch.float64, device=y_dev.device)  # A y, then y^T y
         L.check(
             L.load().pls_onb_build_gaussian(self._desc(), y_dev.data_ptr(), self._B.data_ptr(), L.ld(self._B),
                                             self._c.data_ptr(), L.stream_ptr()),
@@ -186,18 +186,23 @@ class OrthonormalBasis(PLSBasis):
         )
         return out
 
-    def fused_particle_energy(self, cost, particles: torch.Tensor) -> torch.Tensor:
-        """Per-particle energy with the cost evaluated inside the F GEMM's epilogue (pls_onb_energy)."""
+    def fused_particle_energy(self, cost, particles: torch.Tensor, force_generic: bool = False) -> torch.Tensor:
+        """Per-particle energy (pls_onb_energy): the cost is reduced inside a GEMM epilogue -- the N x Mk x J forward
+        GEMM in general, the Mk x Mk x J quadratic form for Gaussian/identity."""
         u = _rows_contiguous(L.require_gpu_tensor(particles, "particles"))
         j = u.shape[1]
         lib = L.load()
-        desc = self._desc()
+        cd = cost.desc()
+        gaussian = cd.cost == L.COST_GAUSSIAN and cd.link == L.LINK_IDENTITY and not force_generic
+        if gaussian:
+            self.prepare_gaussian(cost.y_device())
+        desc = self._desc(with_gaussian=gaussian)
         ws_bytes = min(lib.pls_onb_energy_workspace_bytes(desc, j, self._n), max(self.workspace_bytes, 4 * j * 8))
         ws = self._workspace(ws_bytes, u.device)
         e = torch.empty(j, dtype=torch.float64, device=u.device)
         L.check(
-            lib.pls_onb_energy(desc, cost.desc(), cost.y_device().data_ptr(), u.data_ptr(), L.ld(u), j, e.data_ptr(),
-                               ws.data_ptr(), ws_bytes, L.stream_ptr()),
+            lib.pls_onb_energy(desc, cd, cost.y_device().data_ptr(), u.data_ptr(), L.ld(u), j, e.data_ptr(),
+                               1 if force_generic else 0, ws.data_ptr(), ws_bytes, L.stream_ptr()),
             "pls_onb_energy",
         )
         return e

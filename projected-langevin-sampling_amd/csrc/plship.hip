@@ -131,6 +131,41 @@ struct EpiCostValue {
   }
 };
 
+// Gaussian fast energy: acc = (B U)_ij;  partial[tile_i][j] = sum over the tile's rows of u_ij * (acc_ij - 2 c_i)
+template <int BI, int BJ, int WI, int WJ>
+struct EpiGaussianQuad {
+  static constexpr int kTag = PLS_TAG_GEMM_COST_VALUE;
+  double *partial;
+  int64_t ldp;
+  const double *U;
+  int64_t ldu;
+  const double *c;
+  template <int TI, int TJ>
+  __device__ void apply(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int wave, int64_t I, int64_t J,
+                        int tile_i, int, double *lds) const {
+    double s = 0.0;
+    epilogue_row_pairs<TI, TJ>(acc, iw, jw, lane, wave, I, J, lds,
+                               [&](int64_t i, int64_t j, double v0, bool hi, double v1) {
+                                 s += U[i * ldu + j] * (v0 - 2.0 * c[i]);
+                                 if (hi) s += U[(i + 4) * ldu + j] * (v1 - 2.0 * c[i + 4]);
+                               });
+    if (WJ == 32) s += __shfl_xor(s, 32);
+    constexpr int NWJ = BJ / WJ, NWI = BI / WI;
+    const int wrow = wave / NWJ, wcol = wave % NWJ;
+    double *red = lds;
+    if (lane < WJ) red[wrow * BJ + wcol * WJ + lane] = s;
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < BJ) {
+      double tot = 0.0;
+#pragma unroll
+      for (int w = 0; w < NWI; ++w) tot += red[w * BJ + t];
+      const int64_t j = (jw - wcol * WJ) + t;
+      if (j < J) partial[(int64_t)tile_i * ldp + j] = tot;
+    }
+  }
+};
+
 struct NoiseP {
   int kind;
   const double *xi;
@@ -366,15 +401,18 @@ __global__ __launch_bounds__(256) void cost_value_partial_kernel(CostP cp, const
 // stage 2: out[col] = (accumulate ? out[col] : 0) + sum_rb partial[rb][col]  (+ prior energy term)
 //   prior_kind 0: none; 1: + 0.5 * sum_m P[m][col]^2 * scale_vec[m]  (ONB: P = U, scale_vec = 1/lam  -> pass lam, inverted here)
 //              2: + scale * sum_m P[m][col]^2                       (IPB: P = W U, scale = M/2)
+//   the partial sum enters as pscale * (sum + *padd) (Gaussian fast energy: pscale = 1/(2 sigma2), padd -> y^T y)
 __global__ __launch_bounds__(256) void column_reduce_kernel(const double *__restrict__ partial, int64_t ldp,
                                                              int64_t nparts, int64_t j, double *__restrict__ out,
                                                              int accumulate, int prior_kind,
                                                              const double *__restrict__ P, int64_t ldpp, int64_t m,
-                                                             const double *__restrict__ lam, double scale) {
+                                                             const double *__restrict__ lam, double scale,
+                                                             double pscale, const double *__restrict__ padd) {
   const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (col >= j) return;
-  double s = accumulate ? out[col] : 0.0;
+  double s = 0.0;
   for (int64_t p = 0; p < nparts; ++p) s += partial[p * ldp + col];
+  s = pscale * (s + (padd ? *padd : 0.0)) + (accumulate ? out[col] : 0.0);
   if (prior_kind == 1) {
     double e = 0.0;
     for (int64_t r = 0; r < m; ++r) {
@@ -568,7 +606,7 @@ static int stream_cost(const double *Lf, int64_t ldlf, int64_t kdim, int64_t n, 
     const bool last = (c == nchunks - 1);
     hipLaunchKernelGGL(column_reduce_kernel, dim3((unsigned)cdiv(j, 256)), dim3(256), 0, st, partial, j,
                        cost_value_partial_rows(rows, j), j, e_out, c == 0 ? 0 : 1, last ? prior_kind : 0, P, ldp, m,
-                       lam, scale);
+                       lam, scale, 1.0, (const double *)nullptr);
     rc = check_launch("column_reduce");
     if (rc) return rc;
   }
@@ -717,7 +755,7 @@ int pls_cost_value(const pls_cost_desc *cost, const double *F, int64_t ldf, cons
     if (rc) return rc;
   }
   hipLaunchKernelGGL(column_reduce_kernel, dim3((unsigned)cdiv(j, 256)), dim3(256), 0, S(stream), partial, j, nparts, j, c,
-                     0, 0, (const double *)nullptr, (int64_t)0, (int64_t)0, (const double *)nullptr, 0.0);
+                     0, 0, (const double *)nullptr, (int64_t)0, (int64_t)0, (const double *)nullptr, 0.0, 1.0, (const double *)nullptr);
   return check_launch("column_reduce");
 }
 
@@ -783,6 +821,9 @@ int pls_onb_build_gaussian(const pls_onb_desc *basis, const double *y, double *B
   if (rc) return rc;
   hipLaunchKernelGGL(matvec_rows_kernel, dim3((unsigned)basis->mk), dim3(256), 0, S(stream), basis->A, basis->lda,
                      basis->n, y, c);
+  rc = check_launch("matvec_rows");
+  if (rc) return rc;
+  hipLaunchKernelGGL(matvec_rows_kernel, dim3(1), dim3(256), 0, S(stream), y, basis->n, basis->n, y, c + basis->mk);  // y^T y
   return check_launch("matvec_rows");
 }
 
@@ -880,13 +921,32 @@ size_t pls_onb_energy_workspace_bytes(const pls_onb_desc *basis, int64_t j, int6
 }
 
 int pls_onb_energy(const pls_onb_desc *basis, const pls_cost_desc *cost, const double *y, const double *U, int64_t ldu,
-                   int64_t j, double *e, void *workspace, size_t workspace_bytes, void *stream) {
+                   int64_t j, double *e, int32_t force_generic, void *workspace, size_t workspace_bytes, void *stream) {
   int rc = validate_onb(basis);
   if (rc) return rc;
   rc = validate_cost(cost);
   if (rc) return rc;
   PLS_REQUIRE(U && e && y && j >= 0 && ldu >= j, "onb_energy: bad arguments");
   if (j == 0) return PLS_OK;
+  if (onb_fast_path(basis, cost, force_generic)) {
+    // cost_j = (u^T B u - 2 c^T u + y^T y) / (2 sigma2): one Mk x Mk x J contraction, reduced per tile then per column
+    const int64_t parts = use_big_tiles(basis->mk, j) ? cdiv(basis->mk, 128) : cdiv(basis->mk, 64);
+    if (!workspace || workspace_bytes < (size_t)parts * j * sizeof(double))
+      return fail(PLS_ERR_WORKSPACE_TOO_SMALL, "onb_energy: workspace %zu bytes too small", workspace_bytes);
+    double *partial = static_cast<double *>(workspace);
+    GemmShape g{basis->B, basis->ldb, U, ldu, basis->mk, j, basis->mk, 0, 0, 0};
+    if (use_big_tiles(basis->mk, j)) {
+      EpiGaussianQuad<128, 128, 64, 64> ep{partial, j, U, ldu, basis->c};
+      rc = launch_gemm_cfg<128, 128, 64, 64>(g, ep, S(stream));
+    } else {
+      EpiGaussianQuad<64, 64, 32, 32> ep{partial, j, U, ldu, basis->c};
+      rc = launch_gemm_cfg<64, 64, 32, 32>(g, ep, S(stream));
+    }
+    if (rc) return rc;
+    hipLaunchKernelGGL(column_reduce_kernel, dim3((unsigned)cdiv(j, 256)), dim3(256), 0, S(stream), partial, j, parts, j, e, 0, 1,
+                       U, ldu, basis->mk, basis->lam, 0.0, 0.5 / cost->p[0], basis->c + basis->mk);
+    return check_launch("column_reduce");
+  }
   // rows per chunk such that the partial buffer ((chunk/64) x j doubles) fits
   const int64_t max_parts = (int64_t)(workspace_bytes / ((size_t)j * sizeof(double)));
   if (!workspace || max_parts < 2)
@@ -905,7 +965,7 @@ int pls_onb_prior_energy(const pls_onb_desc *basis, const double *U, int64_t ldu
   PLS_REQUIRE(U && e && j >= 0 && ldu >= j, "onb_prior_energy: bad arguments");
   if (j == 0) return PLS_OK;
   hipLaunchKernelGGL(column_reduce_kernel, dim3((unsigned)cdiv(j, 256)), dim3(256), 0, S(stream), cost, j,
-                     (int64_t)(cost ? 1 : 0), j, e, 0, 1, U, ldu, basis->mk, basis->lam, 0.0);
+                     (int64_t)(cost ? 1 : 0), j, e, 0, 1, U, ldu, basis->mk, basis->lam, 0.0, 1.0, (const double *)nullptr);
   return check_launch("column_reduce");
 }
 
@@ -1070,7 +1130,7 @@ int pls_ipb_prior_energy(const pls_ipb_desc *basis, const double *U, int64_t ldu
   if (rc) return rc;
   hipLaunchKernelGGL(column_reduce_kernel, dim3((unsigned)cdiv(j, 256)), dim3(256), 0, S(stream), cost, j,
                      (int64_t)(cost ? 1 : 0), j, e, 0, 2, (const double *)V, j, basis->m, (const double *)nullptr,
-                     0.5 * (double)basis->m);
+                     0.5 * (double)basis->m, 1.0, (const double *)nullptr);
   return check_launch("column_reduce");
 }
 
