@@ -272,13 +272,19 @@ static int launch_gemm(const double *L, int64_t ldl, const double *R, int64_t ld
   return launch_gemm_cfg<64, 64, 32, 32>(g, epi, st);
 }
 
-// Split-K plan for the back-projection D (I x J) = L^T R with a long contraction (K = rows of the N chunk):
-// when the output has too few 128x128 tiles to fill 256 CUs twice over, the contraction is cut into slabs that are
-// summed in a fixed order by the update kernel (deterministic, no atomics).  Returns the number of slabs.
+// Split-K plan for the back-projection D (I x J) = L^T R with a long contraction (K = rows of the N chunk).  Two reasons
+// to cut the contraction into slabs (summed in a fixed order by the update kernel: deterministic, no atomics):
+//   occupancy -- too few 128x128 output tiles to put two workgroups on each of the 256 CUs (narrow particle shards);
+//   locality  -- over a very long k-loop the co-resident workgroups drift apart and stop sharing operand panels in
+//                their XCD's L2: at K = 1e5 one slab reads 66 GB through the fabric, 8 slabs 20 GB, at equal speed
+//                (DESIGN.md "tuning log"); slabs of <= 16384 rows keep the drift inside the L2 window.
+// Returns the number of slabs (<= 16).
 static int64_t plan_split_k(int64_t I, int64_t J, int64_t K, int64_t *kchunk) {
   const int64_t tiles = cdiv(I, 128) * cdiv(J, 128);
   int64_t s = 1;
   if (tiles < 512) s = cdiv(512, tiles);
+  const int64_t s_local = cdiv(K, 16384);
+  if (s_local > s) s = s_local;
   if (s > 16) s = 16;
   while (s > 1 && K / s < 1024) --s;  // keep every slab's k-loop long enough to amortise its prologue / epilogue
   int64_t kc = cdiv(cdiv(K, s), 16) * 16;

@@ -102,3 +102,25 @@ def test_predictive_moments_single_process():
     mean, var = distributed.predictive_moments(s, 64)
     assert np.allclose(mean, s.mean(dim=1)) and np.allclose(var, s.var(dim=1))
     assert np.isclose(distributed.mean_over_particles(s[0], 64), s[0].mean().item())
+
+
+def test_checkpoint_format_matches_the_reference(tmp_path, monkeypatch):
+    """experiments/uci/regression/main.py:300-308 / experiments/loaders.py:10-28: same keys, readable by plain torch.load."""
+    from projected_langevin_sampling_amd import checkpoint
+
+    class FakePLS:
+        observation_noise = 0.25
+
+    u = torch.arange(12, dtype=torch.float64).reshape(3, 4)
+    path = str(tmp_path / "pls.pth")
+    checkpoint.save_pls(FakePLS(), u, path, best_lr=1e-3, number_of_epochs=17, noise_step=5, number_of_particles=64)
+    raw = torch.load(path, map_location="cpu")
+    assert set(raw) >= {"particles", "observation_noise", "best_lr", "number_of_epochs"}
+    assert torch.equal(raw["particles"], u) and raw["observation_noise"] == 0.25 and raw["best_lr"] == 1e-3
+    # a file written by the reference (no extra keys, float32 particles) loads too
+    torch.save({"particles": u.float(), "observation_noise": 0.5}, path)
+    monkeypatch.setattr(checkpoint, "_dev", lambda t: t.double())  # CPU-only box: skip the device move
+    p = FakePLS()
+    _, particles, best_lr, epochs = checkpoint.load_pls(p, path)
+    assert particles.dtype == torch.float64 and torch.equal(particles, u) and p.observation_noise == 0.5
+    assert best_lr is None and epochs is None
