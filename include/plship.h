@@ -230,11 +230,14 @@ int pls_onb_particle_update(const pls_onb_desc *basis, const double *U, int64_t 
  * out_mode 0: out = dU (the reference's return value);  out_mode 1: out = U + dU (the caller's
  * `particles += update`, trainers.py:157, fused).  out must not alias U: other workgroups still read U as
  * the GEMM operand, so callers ping-pong two particle buffers.
+ * energy_in (may be NULL; Gaussian/identity fast path only, else PLS_ERR_UNSUPPORTED): receives e_j(U) of the INPUT
+ * particles -- the value pls_onb_energy returns -- as a by-product of the same contraction (B U is what both need), so
+ * a train loop (trainers.py:153-159) pays one launch per step; it then needs cdiv(mk, 64) * j workspace doubles.
  * workspace: pls_onb_step_workspace_bytes(...) bytes (any larger size lets it use bigger N chunks). */
 size_t pls_onb_step_workspace_bytes(const pls_onb_desc *basis, int64_t j, int64_t n_chunk);
 int pls_onb_step(const pls_onb_desc *basis, const pls_cost_desc *cost, const double *y, double *U, int64_t ldu,
                  int64_t j, double eta, const pls_noise_desc *noise, double *out, int64_t ldo, int32_t out_mode,
-                 int32_t force_generic, void *workspace, size_t workspace_bytes, void *stream);
+                 int32_t force_generic, double *energy_in, void *workspace, size_t workspace_bytes, void *stream);
 
 /* e(J) = cost_j + 0.5 * sum_m U_mj^2 / lam_m  (per-particle energy; the caller takes the mean over all
  * particles of all ranks).  Replaces PLS.calculate_energy_potential -> OrthonormalBasis.calculate_energy_potential

@@ -98,7 +98,7 @@ SIGNATURES = {
     "pls_onb_forward": (C.c_int, [_OD, _P, _I64, _I64, _P, _I64, _P]),
     "pls_onb_particle_update": (C.c_int, [_OD, _P, _I64, _P, _I64, _I64, _D, _ND, _P, _I64, _P]),
     "pls_onb_step_workspace_bytes": (_SZ, [_OD, _I64, _I64]),
-    "pls_onb_step": (C.c_int, [_OD, _CD, _P, _P, _I64, _I64, _D, _ND, _P, _I64, _I32, _I32, _P, _SZ, _P]),
+    "pls_onb_step": (C.c_int, [_OD, _CD, _P, _P, _I64, _I64, _D, _ND, _P, _I64, _I32, _I32, _P, _P, _SZ, _P]),
     "pls_onb_energy_workspace_bytes": (_SZ, [_OD, _I64, _I64]),
     "pls_onb_energy": (C.c_int, [_OD, _CD, _P, _P, _I64, _I64, _P, _I32, _P, _SZ, _P]),
     "pls_onb_prior_energy": (C.c_int, [_OD, _P, _I64, _I64, _P, _P, _P]),

@@ -153,9 +153,16 @@ class OrthonormalBasis(PLSBasis):
     def supports_fused_step(self) -> bool:
         return True
 
+    def supports_input_energy(self, cost) -> bool:
+        """True if fused_step can return the energy of its input particles for free (Gaussian/identity fast path)."""
+        cd = cost.desc()
+        return cd.cost == L.COST_GAUSSIAN and cd.link == L.LINK_IDENTITY
+
     def fused_step(self, cost, particles: torch.Tensor, step_size: float, out: torch.Tensor | None = None,
-                   new_state: bool = False, noise: NoiseSpec | None = None, force_generic: bool = False) -> torch.Tensor:
-        """One whole Langevin step in libplship (pls_onb_step): returns dU, or U + dU when new_state."""
+                   new_state: bool = False, noise: NoiseSpec | None = None, force_generic: bool = False,
+                   input_energy: torch.Tensor | None = None) -> torch.Tensor:
+        """One whole Langevin step in libplship (pls_onb_step): returns dU, or U + dU when new_state.
+        ``input_energy`` (J,) receives the per-particle energy of ``particles`` as a by-product (fast path only)."""
         u = _rows_contiguous(L.require_gpu_tensor(particles, "particles"))
         j = u.shape[1]
         if out is None:
@@ -172,6 +179,9 @@ class OrthonormalBasis(PLSBasis):
         desc = self._desc(with_gaussian=gaussian)
         if gaussian:
             ws, ws_bytes = None, 0
+            if input_energy is not None:
+                ws_bytes = ((self.approximation_dimension + 63) // 64) * j * 8
+                ws = self._workspace(ws_bytes, u.device)
         else:
             need_min = lib.pls_onb_step_workspace_bytes(desc, j, 128)
             need_full = lib.pls_onb_step_workspace_bytes(desc, j, self._n)
@@ -180,8 +190,8 @@ class OrthonormalBasis(PLSBasis):
         nd = (noise if noise is not None else self._draw_noise_spec(None)).desc()
         L.check(
             lib.pls_onb_step(desc, cd, y.data_ptr(), u.data_ptr(), L.ld(u), j, float(step_size), nd, out.data_ptr(), L.ld(out),
-                             L.OUT_NEW_STATE if new_state else L.OUT_DELTA, 1 if force_generic else 0, L.ptr(ws), ws_bytes,
-                             L.stream_ptr()),
+                             L.OUT_NEW_STATE if new_state else L.OUT_DELTA, 1 if force_generic else 0, L.ptr(input_energy),
+                             L.ptr(ws), ws_bytes, L.stream_ptr()),
             "pls_onb_step",
         )
         return out

@@ -131,7 +131,8 @@ struct EpiCostValue {
   }
 };
 
-// Gaussian fast energy: acc = (B U)_ij;  partial[tile_i][j] = sum over the tile's rows of u_ij * (acc_ij - 2 c_i)
+// Gaussian fast energy: acc = (B U)_ij;  partial[tile_i][j] = sum over the tile's rows of
+//   pscale * u_ij * (acc_ij - 2 c_i) + 0.5 * u_ij^2 / lam_i       (cost quadratic form + prior energy of those rows)
 template <int BI, int BJ, int WI, int WJ>
 struct EpiGaussianQuad {
   static constexpr int kTag = PLS_TAG_GEMM_COST_VALUE;
@@ -139,15 +140,20 @@ struct EpiGaussianQuad {
   int64_t ldp;
   const double *U;
   int64_t ldu;
-  const double *c;
+  const double *c, *lam;
+  double pscale;
   template <int TI, int TJ>
   __device__ void apply(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int wave, int64_t I, int64_t J,
                         int tile_i, int, double *lds) const {
     double s = 0.0;
     epilogue_row_pairs<TI, TJ>(acc, iw, jw, lane, wave, I, J, lds,
                                [&](int64_t i, int64_t j, double v0, bool hi, double v1) {
-                                 s += U[i * ldu + j] * (v0 - 2.0 * c[i]);
-                                 if (hi) s += U[(i + 4) * ldu + j] * (v1 - 2.0 * c[i + 4]);
+                                 const double u0 = U[i * ldu + j];
+                                 s += pscale * u0 * (v0 - 2.0 * c[i]) + 0.5 * u0 * u0 / lam[i];
+                                 if (hi) {
+                                   const double u1 = U[(i + 4) * ldu + j];
+                                   s += pscale * u1 * (v1 - 2.0 * c[i + 4]) + 0.5 * u1 * u1 / lam[i + 4];
+                                 }
                                });
     if (WJ == 32) s += __shfl_xor(s, 32);
     constexpr int NWJ = BJ / WJ, NWI = BI / WI;
@@ -204,9 +210,16 @@ struct EpiLangevinGaussian {
   double eta, inv_noise, sq2eta;
   int add_u;
   NoiseP nz;
+  // optional by-product: energy partials of the INPUT particles (acc = B U is exactly what their cost needs):
+  // epart[tile_i][j] = sum over the tile's rows of 0.5*inv_noise * u (acc - 2 c_i) + 0.5 u^2 / lam_i
+  double *epart;
+  int64_t ldp;
+  int nwj, bj;  // tile geometry of the launch (waves along j, tile width), set by the launcher
   template <int TI, int TJ>
   __device__ void apply(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int wave, int64_t I, int64_t J,
-                        int, int, double *lds) const {
+                        int tile_i, int, double *lds) const {
+    double es = 0.0;
+    const double pscale = 0.5 * inv_noise;
     epilogue_row_pairs<TI, TJ>(
         acc, iw, jw, lane, wave, I, J, lds, [&](int64_t i, int64_t j, double v0, bool hi, double v1) {
           double z0 = 0.0, z1 = 0.0;
@@ -220,13 +233,31 @@ struct EpiLangevinGaussian {
             const double u = U[i * ldu + j];
             const double d = -eta * inv_noise * (v0 - c[i]) - eta * u / lam[i] + sq2eta * z0;
             out[i * ldo + j] = add_u ? u + d : d;
+            es += pscale * u * (v0 - 2.0 * c[i]) + 0.5 * u * u / lam[i];
           }
           if (hi) {
             const double u = U[(i + 4) * ldu + j];
             const double d = -eta * inv_noise * (v1 - c[i + 4]) - eta * u / lam[i + 4] + sq2eta * z1;
             out[(i + 4) * ldo + j] = add_u ? u + d : d;
+            es += pscale * u * (v1 - 2.0 * c[i + 4]) + 0.5 * u * u / lam[i + 4];
           }
         });
+    if (epart) {  // wave-uniform; fixed-order cross-wave sum like EpiCostValue
+      constexpr int WJ = TJ * 16;
+      if (WJ == 32) es += __shfl_xor(es, 32);
+      const int wrow = wave / nwj, wcol = wave % nwj;
+      const int nwi = (int)(blockDim.x >> 6) / nwj;
+      double *red = lds;
+      if (lane < WJ) red[wrow * bj + wcol * WJ + lane] = es;
+      __syncthreads();
+      const int t = threadIdx.x;
+      if (t < bj) {
+        double tot = 0.0;
+        for (int w = 0; w < nwi; ++w) tot += red[w * bj + t];
+        const int64_t j = (jw - wcol * WJ) + t;
+        if (j < J) epart[(int64_t)tile_i * ldp + j] = tot;
+      }
+    }
   }
 };
 
@@ -475,6 +506,17 @@ __global__ __launch_bounds__(256) void langevin_update_kernel(double *out, int64
       }
     }
   }
+}
+
+// e[col] = sum_p partial[p][col] + yscale * (*yty)
+__global__ __launch_bounds__(256) void gaussian_energy_finish_kernel(const double *__restrict__ partial, int64_t ldp,
+                                                                      int64_t nparts, int64_t j, double *__restrict__ e,
+                                                                      double yscale, const double *__restrict__ yty) {
+  const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (col >= j) return;
+  double s = 0.0;
+  for (int64_t p = 0; p < nparts; ++p) s += partial[p * ldp + col];
+  e[col] = s + yscale * (*yty);
 }
 
 __global__ __launch_bounds__(256) void link_transform_kernel(int link, double jitter, const double *__restrict__ in,
@@ -878,7 +920,7 @@ size_t pls_onb_step_workspace_bytes(const pls_onb_desc *basis, int64_t j, int64_
 
 int pls_onb_step(const pls_onb_desc *basis, const pls_cost_desc *cost, const double *y, double *U, int64_t ldu,
                  int64_t j, double eta, const pls_noise_desc *noise, double *out, int64_t ldo, int32_t out_mode,
-                 int32_t force_generic, void *workspace, size_t workspace_bytes, void *stream) {
+                 int32_t force_generic, double *energy_in, void *workspace, size_t workspace_bytes, void *stream) {
   int rc = validate_onb(basis);
   if (rc) return rc;
   rc = validate_cost(cost);
@@ -895,9 +937,26 @@ int pls_onb_step(const pls_onb_desc *basis, const pls_cost_desc *cost, const dou
   const NoiseP nz = make_noisep(noise);
   hipStream_t st = S(stream);
   if (onb_fast_path(basis, cost, force_generic)) {
-    EpiLangevinGaussian e{out, ldo, U, ldu, basis->c, basis->lam, eta, 1.0 / cost->p[0], sqrt(2.0 * eta), out_mode, nz};
-    return launch_gemm(basis->B, basis->ldb, U, ldu, basis->mk, j, basis->mk, e, st);
+    const bool big = use_big_tiles(basis->mk, j);
+    double *epart = nullptr;
+    if (energy_in) {
+      const int64_t parts = big ? cdiv(basis->mk, 128) : cdiv(basis->mk, 64);
+      if (!workspace || workspace_bytes < (size_t)parts * j * sizeof(double))
+        return fail(PLS_ERR_WORKSPACE_TOO_SMALL, "onb_step: energy by-product needs %zu workspace bytes",
+                    (size_t)parts * j * sizeof(double));
+      epart = static_cast<double *>(workspace);
+    }
+    EpiLangevinGaussian e{out, ldo, U, ldu, basis->c, basis->lam, eta, 1.0 / cost->p[0], sqrt(2.0 * eta), out_mode, nz,
+                          epart, j, 2, big ? 128 : 64};
+    rc = launch_gemm(basis->B, basis->ldb, U, ldu, basis->mk, j, basis->mk, e, st);
+    if (rc || !energy_in) return rc;
+    const int64_t parts = big ? cdiv(basis->mk, 128) : cdiv(basis->mk, 64);
+    hipLaunchKernelGGL(gaussian_energy_finish_kernel, dim3((unsigned)cdiv(j, 256)), dim3(256), 0, st, epart, j, parts, j,
+                       energy_in, 0.5 / cost->p[0], basis->c + basis->mk);
+    return check_launch("gaussian_energy_finish");
   }
+  if (energy_in)
+    return fail(PLS_ERR_UNSUPPORTED, "onb_step: the input-energy by-product exists on the Gaussian/identity fast path only");
   const size_t d_bytes = align_up((size_t)basis->mk * j * sizeof(double), 256);
   const int64_t max_slabs = onb_max_slabs(basis->mk, j, basis->n);
   const int64_t min_rows = basis->n < 128 ? basis->n : 128;
@@ -942,15 +1001,16 @@ int pls_onb_energy(const pls_onb_desc *basis, const pls_cost_desc *cost, const d
     double *partial = static_cast<double *>(workspace);
     GemmShape g{basis->B, basis->ldb, U, ldu, basis->mk, j, basis->mk, 0, 0, 0};
     if (use_big_tiles(basis->mk, j)) {
-      EpiGaussianQuad<128, 128, 64, 64> ep{partial, j, U, ldu, basis->c};
+      EpiGaussianQuad<128, 128, 64, 64> ep{partial, j, U, ldu, basis->c, basis->lam, 0.5 / cost->p[0]};
       rc = launch_gemm_cfg<128, 128, 64, 64>(g, ep, S(stream));
     } else {
-      EpiGaussianQuad<64, 64, 32, 32> ep{partial, j, U, ldu, basis->c};
+      EpiGaussianQuad<64, 64, 32, 32> ep{partial, j, U, ldu, basis->c, basis->lam, 0.5 / cost->p[0]};
       rc = launch_gemm_cfg<64, 64, 32, 32>(g, ep, S(stream));
     }
     if (rc) return rc;
-    hipLaunchKernelGGL(column_reduce_kernel, dim3((unsigned)cdiv(j, 256)), dim3(256), 0, S(stream), partial, j, parts, j, e, 0, 1,
-                       U, ldu, basis->mk, basis->lam, 0.0, 0.5 / cost->p[0], basis->c + basis->mk);
+    // e_j = sum of the tile partials + y^T y / (2 sigma2): enters as 1.0 * (sum + padd) with padd pre-scaled on the fly
+    hipLaunchKernelGGL(gaussian_energy_finish_kernel, dim3((unsigned)cdiv(j, 256)), dim3(256), 0, S(stream), partial, j, parts, j,
+                       e, 0.5 / cost->p[0], basis->c + basis->mk);
     return check_launch("column_reduce");
   }
   // rows per chunk such that the partial buffer ((chunk/64) x j doubles) fits

@@ -450,10 +450,27 @@ def test_config1_train_pls_trajectory(P):
     assert len(e_got) == len(e_want) == steps
     assert relerr(u_got, u_want) < 1e-8
     assert np.allclose(e_got, e_want, rtol=1e-9)
-    # early stop rule: a tiny patience stops both at the same index
-    _, e1 = O.train_pls(O.PLS(ob, oc), u0.clone(), steps, eta, 2.5 * eta, noises=noises)
-    _, e2 = P.pkg.train_pls(P.pkg.PLS(gb, gc), cu(u0), steps, eta, 2.5 * eta, noises=[cu(t) for t in noises])
-    assert len(e1) == len(e2)
+    # early stop rule: a tiny patience stops both at the same index, with the same particles
+    uw, e1 = O.train_pls(O.PLS(ob, oc), u0.clone(), steps, eta, 2.5 * eta, noises=noises)
+    ug, e2 = P.pkg.train_pls(P.pkg.PLS(gb, gc), cu(u0), steps, eta, 2.5 * eta, noises=[cu(t) for t in noises])
+    assert len(e1) == len(e2) and np.allclose(e1, e2, rtol=1e-9) and relerr(ug, uw) < 1e-8
+    # the pipelined loop (energy as a by-product of the next step) == the plain loop, incl. torch's RNG state afterwards
+    from projected_langevin_sampling_amd import trainers
+
+    torch.manual_seed(7)
+    ua, ea = P.pkg.train_pls(P.pkg.PLS(gb, gc), cu(u0), 60, eta, 4 * eta)
+    state_a = torch.get_rng_state()
+    torch.manual_seed(7)
+    pls_plain = P.pkg.PLS(gb, gc)
+    ub, eb, es = cu(u0), [], trainers.EarlyStopper(patience=4 * eta)
+    for _ in range(60):
+        pls_plain.step_(ub, eta)
+        e = pls_plain.calculate_energy_potential(ub)
+        if es.should_stop(e, eta):
+            break
+        eb.append(e)
+    assert len(ea) == len(eb) and np.allclose(ea, eb, rtol=1e-9) and relerr(ua, ub) < 1e-12
+    assert torch.equal(state_a, torch.get_rng_state())
 
 
 def test_user_defined_python_cost_goes_through_unfused_entry_points(P):
