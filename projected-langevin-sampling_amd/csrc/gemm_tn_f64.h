@@ -371,15 +371,23 @@ __global__ __launch_bounds__((BI / WI) * (BJ / WJ) * 64, MINW) void gemm_tn_f64_
 //     Box-Muller -- exists once, not once per accumulator register),
 //   * every global store / load of the epilogue is a contiguous row segment of WJ doubles,
 //   * rows i and i+4 (one Philox pair, philox.h) are handed to the functor together.
-// fn(i_lo, j, v_lo, hi_valid, v_hi) is called for every column j < J and row pair (i_lo, i_lo + 4) with i_lo < I.
+// fn(i_lo, j, v_lo, hi_valid, v_hi, rc) is called for every column j < J and row pair (i_lo, i_lo + 4) with i_lo < I.
+// Per-row constants (y_i, c_i, 1/lambda_i) are loaded ONCE per wave into lane registers (lane l <- row iw + l, see
+// load_row_constants) and handed over as rc = {k0[i_lo], k0[i_lo+4], k1[i_lo], k1[i_lo+4]}: a cross-lane read
+// (done with all lanes active, before the edge predicate) instead of a dependent global load in every iteration of the
+// row loop -- that chain cost ~9 us per tile.
 constexpr int EPI_PAD = 2;  // doubles; keeps the 4 rows a ds_write_b64 touches on different banks
 
 template <int WJ>
 constexpr int epi_lds_doubles_per_wave() { return 16 * (WJ + EPI_PAD); }
 
+struct RowConsts {
+  double k0_lo, k0_hi, k1_lo, k1_hi;
+};
+
 template <int TI, int TJ, class Fn>
 __device__ __forceinline__ void epilogue_row_pairs(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int wave,
-                                                   int64_t I, int64_t J, double *lds, Fn &&fn) {
+                                                   int64_t I, int64_t J, double *lds, double k0, double k1, Fn &&fn) {
   constexpr int WJ = TJ * 16;
   constexpr int STRIDE = WJ + EPI_PAD;
   constexpr int RPI = 64 / WJ;  // row pairs handled per iteration by the 64 lanes (1 for WJ = 64, 2 for WJ = 32)
@@ -400,7 +408,9 @@ __device__ __forceinline__ void epilogue_row_pairs(const AccFrag<TI, TJ> &acc, i
       const int rr = (p >> 2) * 8 + (p & 3);       // rows rr and rr + 4
       const int64_t i_lo = iw + ta * 16 + rr;
       const double v_lo = w[rr * STRIDE + col], v_hi = w[(rr + 4) * STRIDE + col];
-      if (i_lo < I && j < J) fn(i_lo, j, v_lo, i_lo + 4 < I, v_hi);
+      const int lr = ta * 16 + rr;
+      const RowConsts rc{__shfl(k0, lr), __shfl(k0, lr + 4), __shfl(k1, lr), __shfl(k1, lr + 4)};
+      if (i_lo < I && j < J) fn(i_lo, j, v_lo, i_lo + 4 < I, v_hi, rc);
     }
     __syncthreads();
   };
@@ -415,6 +425,11 @@ __device__ __forceinline__ void epilogue_row_pairs(const AccFrag<TI, TJ> &acc, i
   static_assert(TI <= 8, "extend the pass list");
 }
 
+// lane l of a wave holds the per-row constant of row iw + l (0 beyond I)
+__device__ __forceinline__ double load_row_constants(const double *vec, int64_t iw, int lane, int64_t I) {
+  return (iw + lane < I) ? vec[iw + lane] : 0.0;
+}
+
 struct EpiStore {  // C = alpha * acc + beta * C   (split-K: slab `split` of C, slabs `slab` doubles apart)
   static constexpr int kTag = 1;  // PLS_TAG_GEMM_STORE
   double *C0;
@@ -426,14 +441,14 @@ struct EpiStore {  // C = alpha * acc + beta * C   (split-K: slab `split` of C, 
                         int, int split, double *lds) const {
     double *C = C0 + (int64_t)split * slab;
     if (beta == 0.0) {
-      epilogue_row_pairs<TI, TJ>(acc, iw, jw, lane, wave, I, J, lds,
-                                 [&](int64_t i, int64_t j, double v0, bool hi, double v1) {
+      epilogue_row_pairs<TI, TJ>(acc, iw, jw, lane, wave, I, J, lds, 0.0, 0.0,
+                                 [&](int64_t i, int64_t j, double v0, bool hi, double v1, const RowConsts &) {
                                    C[i * ldc + j] = alpha * v0;
                                    if (hi) C[(i + 4) * ldc + j] = alpha * v1;
                                  });
     } else {
-      epilogue_row_pairs<TI, TJ>(acc, iw, jw, lane, wave, I, J, lds,
-                                 [&](int64_t i, int64_t j, double v0, bool hi, double v1) {
+      epilogue_row_pairs<TI, TJ>(acc, iw, jw, lane, wave, I, J, lds, 0.0, 0.0,
+                                 [&](int64_t i, int64_t j, double v0, bool hi, double v1, const RowConsts &) {
                                    C[i * ldc + j] = alpha * v0 + beta * C[i * ldc + j];
                                    if (hi) C[(i + 4) * ldc + j] = alpha * v1 + beta * C[(i + 4) * ldc + j];
                                  });

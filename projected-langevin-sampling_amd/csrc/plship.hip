@@ -89,10 +89,11 @@ struct EpiCostDeriv {
   template <int TI, int TJ>
   __device__ void apply(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int wave, int64_t I, int64_t J,
                         int, int, double *lds) const {
-    epilogue_row_pairs<TI, TJ>(acc, iw, jw, lane, wave, I, J, lds,
-                               [&](int64_t i, int64_t j, double v0, bool hi, double v1) {
-                                 G[i * ldg + j] = cost_deriv(cp, y[i], v0);
-                                 if (hi) G[(i + 4) * ldg + j] = cost_deriv(cp, y[i + 4], v1);
+    const double yl = load_row_constants(y, iw, lane, I);
+    epilogue_row_pairs<TI, TJ>(acc, iw, jw, lane, wave, I, J, lds, yl, 0.0,
+                               [&](int64_t i, int64_t j, double v0, bool hi, double v1, const RowConsts &rc) {
+                                 G[i * ldg + j] = cost_deriv(cp, rc.k0_lo, v0);
+                                 if (hi) G[(i + 4) * ldg + j] = cost_deriv(cp, rc.k0_hi, v1);
                                });
   }
 };
@@ -109,10 +110,11 @@ struct EpiCostValue {
   __device__ void apply(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int wave, int64_t I, int64_t J,
                         int tile_i, int, double *lds) const {
     double s = 0.0;  // this lane's column, summed over the rows it is handed (fixed order)
-    epilogue_row_pairs<TI, TJ>(acc, iw, jw, lane, wave, I, J, lds,
-                               [&](int64_t i, int64_t, double v0, bool hi, double v1) {
-                                 s += cost_value(cp, y[i], v0);
-                                 if (hi) s += cost_value(cp, y[i + 4], v1);
+    const double yl = load_row_constants(y, iw, lane, I);
+    epilogue_row_pairs<TI, TJ>(acc, iw, jw, lane, wave, I, J, lds, yl, 0.0,
+                               [&](int64_t, int64_t, double v0, bool hi, double v1, const RowConsts &rc) {
+                                 s += cost_value(cp, rc.k0_lo, v0);
+                                 if (hi) s += cost_value(cp, rc.k0_hi, v1);
                                });
     if (WJ == 32) s += __shfl_xor(s, 32);  // two lane halves share the 32 columns
     constexpr int NWJ = BJ / WJ, NWI = BI / WI;
@@ -146,13 +148,16 @@ struct EpiGaussianQuad {
   __device__ void apply(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int wave, int64_t I, int64_t J,
                         int tile_i, int, double *lds) const {
     double s = 0.0;
-    epilogue_row_pairs<TI, TJ>(acc, iw, jw, lane, wave, I, J, lds,
-                               [&](int64_t i, int64_t j, double v0, bool hi, double v1) {
+    const double cl = load_row_constants(c, iw, lane, I);
+    const double laml = load_row_constants(lam, iw, lane, I);
+    const double hil = (iw + lane < I) ? 0.5 / laml : 0.0;  // 0.5 / lambda_i
+    epilogue_row_pairs<TI, TJ>(acc, iw, jw, lane, wave, I, J, lds, cl, hil,
+                               [&](int64_t i, int64_t j, double v0, bool hi, double v1, const RowConsts &rc) {
                                  const double u0 = U[i * ldu + j];
-                                 s += pscale * u0 * (v0 - 2.0 * c[i]) + 0.5 * u0 * u0 / lam[i];
+                                 s += pscale * u0 * (v0 - 2.0 * rc.k0_lo) + u0 * u0 * rc.k1_lo;
                                  if (hi) {
                                    const double u1 = U[(i + 4) * ldu + j];
-                                   s += pscale * u1 * (v1 - 2.0 * c[i + 4]) + 0.5 * u1 * u1 / lam[i + 4];
+                                   s += pscale * u1 * (v1 - 2.0 * rc.k0_hi) + u1 * u1 * rc.k1_hi;
                                  }
                                });
     if (WJ == 32) s += __shfl_xor(s, 32);
@@ -220,8 +225,12 @@ struct EpiLangevinGaussian {
                         int tile_i, int, double *lds) const {
     double es = 0.0;
     const double pscale = 0.5 * inv_noise;
+    const double cl = load_row_constants(c, iw, lane, I);
+    const double laml = load_row_constants(lam, iw, lane, I);
+    const double ilaml = (iw + lane < I) ? 1.0 / laml : 0.0;
     epilogue_row_pairs<TI, TJ>(
-        acc, iw, jw, lane, wave, I, J, lds, [&](int64_t i, int64_t j, double v0, bool hi, double v1) {
+        acc, iw, jw, lane, wave, I, J, lds, cl, ilaml,
+        [&](int64_t i, int64_t j, double v0, bool hi, double v1, const RowConsts &rc) {
           double z0 = 0.0, z1 = 0.0;
           if (nz.kind == PLS_NOISE_PHILOX) {
             normal_pair(nz.seed, nz.step, i, nz.j_offset + j, z0, z1);  // rows i and i + 4 share one Philox call
@@ -230,16 +239,16 @@ struct EpiLangevinGaussian {
             if (hi) z1 = nz.xi[(i + 4) * nz.ldxi + j];
           }
           {
-            const double u = U[i * ldu + j];
-            const double d = -eta * inv_noise * (v0 - c[i]) - eta * u / lam[i] + sq2eta * z0;
+            const double u = U[i * ldu + j], ci = rc.k0_lo, il = rc.k1_lo;
+            const double d = -eta * inv_noise * (v0 - ci) - eta * u * il + sq2eta * z0;
             out[i * ldo + j] = add_u ? u + d : d;
-            es += pscale * u * (v0 - 2.0 * c[i]) + 0.5 * u * u / lam[i];
+            es += pscale * u * (v0 - 2.0 * ci) + 0.5 * u * u * il;
           }
           if (hi) {
-            const double u = U[(i + 4) * ldu + j];
-            const double d = -eta * inv_noise * (v1 - c[i + 4]) - eta * u / lam[i + 4] + sq2eta * z1;
+            const double u = U[(i + 4) * ldu + j], ci = rc.k0_hi, il = rc.k1_hi;
+            const double d = -eta * inv_noise * (v1 - ci) - eta * u * il + sq2eta * z1;
             out[(i + 4) * ldo + j] = add_u ? u + d : d;
-            es += pscale * u * (v1 - 2.0 * c[i + 4]) + 0.5 * u * u / lam[i + 4];
+            es += pscale * u * (v1 - 2.0 * ci) + 0.5 * u * u * il;
           }
         });
     if (epart) {  // wave-uniform; fixed-order cross-wave sum like EpiCostValue
