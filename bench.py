@@ -169,11 +169,13 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU; (the modulo only matters for the development rehearsal of several ranks on a one-GPU box)
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
     import torch.distributed as dist
 
     if world > 1 or "RANK" in os.environ:
-        dist.init_process_group("nccl", rank=rank, world_size=world)  # RCCL; used for the barrier / max-time only
+        # RCCL ("nccl") in production; PLS_BENCH_BACKEND=gloo lets a one-GPU box rehearse the multi-rank control flow
+        dist.init_process_group(os.environ.get("PLS_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
 
     import projected_langevin_sampling_amd as pkg
     from projected_langevin_sampling_amd import distributed as D

@@ -740,10 +740,8 @@ int pls_kernel_gram(int32_t kernel_kind, const double *x1, int64_t n1, const dou
   PLS_REQUIRE(ldout >= n2, "kernel_gram: ldout < n2");
   PLS_REQUIRE(kernel_kind != PLS_KERNEL_RBF_ARD || lengthscale, "kernel_gram: RBF needs lengthscale");
   if (n1 == 0 || n2 == 0) return PLS_OK;
-  dim3 grid((unsigned)cdiv(n2, 512), (unsigned)cdiv(n1, 8));
-  PLS_REQUIRE(cdiv(n1, 8) <= 65535 * 1024LL, "kernel_gram: n1 too large");
-  // gridDim.y limit is 65535: loop over slabs of rows if needed
-  const int64_t max_rows = 65535LL * 8;
+  PLS_REQUIRE(cdiv(n2, 512) <= 0x7fffffff, "kernel_gram: n2 too large");
+  const int64_t max_rows = 65535LL * 8;  // gridDim.y <= 65535, 8 rows per block: taller Gram matrices go in row slabs
   for (int64_t r0 = 0; r0 < n1; r0 += max_rows) {
     const int64_t rows = (n1 - r0 < max_rows) ? n1 - r0 : max_rows;
     dim3 g2((unsigned)cdiv(n2, 512), (unsigned)cdiv(rows, 8));
@@ -760,7 +758,6 @@ int pls_kernel_gram(int32_t kernel_kind, const double *x1, int64_t n1, const dou
     int rc = check_launch("kernel_gram");
     if (rc) return rc;
   }
-  (void)grid;
   return PLS_OK;
 }
 

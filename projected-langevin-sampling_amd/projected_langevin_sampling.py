@@ -92,8 +92,9 @@ class PLS:
 
     def calculate_energy_potential(self, particles: torch.Tensor) -> float:
         """Average energy potential (:125-138); returns a Python float (device sync, like the reference)."""
-        if self._fused() or hasattr(self.basis, "particle_energy_potential"):
+        if hasattr(self.basis, "particle_energy_potential"):
             return self.particle_energy_potential(particles).mean().item()
+        # a user-defined basis that only implements the reference's abstract interface
         assert (
             particles.shape[0] == self.basis.approximation_dimension
         ), f"Particles have shape {particles.shape} but requires ({self.basis.approximation_dimension}, J) dimension."
