@@ -724,3 +724,65 @@ def test_temper_scale_vs_oracle(P):
     torch.manual_seed(3)
     d = t(xc)
     assert relerr(torch.diag(d.covariance_matrix), t.scale * v) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------------------
+# 8. BASELINE.json configs[2] / configs[3] shapes (non-Gaussian costs, one rank's J-shard): the step must be the
+#    gradient of the energy -- a size-independent property that ties the step kernels to the energy kernels
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize(
+    "name,n,m,j,d",
+    [("poisson/square", 50_000, 512, 2048, 1), ("bernoulli/sigmoid", 200_000, 2048, 1024, 8)],
+)
+def test_full_size_drift_is_the_energy_gradient(P, name, n, m, j, d):
+    g = torch.Generator().manual_seed(5)
+    x = torch.linspace(-3, 3, n).reshape(-1, 1) if d == 1 else torch.rand(n, d, generator=g) * 2 - 1
+    z = x[torch.randperm(n, generator=g)[:m]].clone()
+    w = torch.randn(d, generator=g)
+    fstar = torch.sin(2.0 * (x @ w))
+    ls = (0.5 + torch.rand(d, generator=g)) * (0.02 if d == 1 else 1.0)
+    gb = P.basis.OrthonormalBasis(P.pkg.PLSKernel(P.pkg.ARDKernel(ls, 1.0), z), z, x, eigenvalue_threshold=1e-6,
+                                  verbose=False, keep_gram=False)
+    mk = gb.approximation_dimension
+    assert mk >= 100, f"kept only {mk} of {m} directions"  # (the RBF spectrum of a 1-D input decays fast)
+    if name.startswith("poisson"):
+        gc = P.costs.PoissonCost(torch.poisson((2.0 * fstar) ** 2 + 0.1, generator=g), P.links.SquareLinkFunction())
+    else:
+        gc = P.costs.BernoulliCost((torch.rand(n, generator=g) < torch.sigmoid(2 * fstar)).double(), P.links.SigmoidLinkFunction())
+    pls = P.pkg.PLS(gb, gc)
+    # particles scaled like the prior (u_m ~ sqrt(lambda_m)) ...
+    u = (torch.randn(mk, j, generator=g) * torch.sqrt(gb.eigenvalues.cpu())[:, None]).cuda()
+    v = (torch.randn(mk, j, generator=g) * torch.sqrt(gb.eigenvalues.cpu())[:, None]).cuda()
+    if name.startswith("poisson"):
+        # ... and, for the Poisson cost, shifted so that f = A^T u stays away from its pole at f = 0 (-2 y log|f|): the
+        # projection of the constant function, e = A 1, gives a positive f0 = A^T e; particles = 3 e / mean(f0) + small
+        from projected_langevin_sampling_amd import _ops
+
+        e = _ops.gemm_tn(gb._At, torch.ones(n, 1, dtype=torch.float64, device="cuda"))  # (mk, 1)
+        f0 = gb.calculate_untransformed_train_prediction_samples(e)
+        e = e * (3.0 / f0.mean())
+        u = e + 0.02 * u
+        fmin = gb.calculate_untransformed_train_prediction_samples(u[:, :64].contiguous()).min().item()
+        assert fmin > 0.5, f"test construction: f reaches {fmin}"
+        v = 0.02 * v
+    eta = 1.0
+    drift = gb.fused_step(gc, u, eta, noise=P.basis.NoiseSpec(none=True))  # = -eta * grad_U E  (per particle)
+    # directional derivative of the per-particle energy along v, central difference
+    eps = 1e-5
+    e_p = pls.particle_energy_potential(u + eps * v)
+    e_m = pls.particle_energy_potential(u - eps * v)
+    fd = (e_p - e_m) / (2 * eps)
+    an = -(drift * v).sum(dim=0) / eta
+    finite = torch.isfinite(fd) & torch.isfinite(an)
+    assert finite.float().mean().item() > 0.99
+    rel = ((fd - an).abs() / an.abs().clamp_min(1e-12))[finite]
+    assert rel.median().item() < 1e-6, f"{name}: median rel diff {rel.median().item():.2e}"
+    assert (rel < 1e-3).float().mean().item() > 0.98, f"{name}: {((rel < 1e-3).float().mean().item()):.3f} of particles agree"
+    # J-shard invariance and N-chunk invariance at this size
+    full = gb.fused_step(gc, u, 1e-6, noise=P.basis.NoiseSpec(seed=3, step=1))
+    half = gb.fused_step(gc, u[:, j // 2:].contiguous(), 1e-6, noise=P.basis.NoiseSpec(seed=3, step=1, j_offset=j // 2))
+    assert relerr(half, full[:, j // 2:]) < 1e-11
+    gb.workspace_bytes = P.pkg._lib.load().pls_onb_step_workspace_bytes(gb._desc(), j, 8192)
+    gb._ws.clear()
+    chunked = gb.fused_step(gc, u, 1e-6, noise=P.basis.NoiseSpec(seed=3, step=1))
+    assert relerr(chunked, full) < 1e-11
