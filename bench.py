@@ -155,6 +155,7 @@ def main():
     ap.add_argument("--workspace-gb", type=float, default=8.0, help="cap of the per-step G-chunk workspace")
     ap.add_argument("--converge-steps", type=int, default=4000,
                     help="step cap of the wall-clock-to-converged-energy run (0 = skip it)")
+    ap.add_argument("--ipb-steps", type=int, default=3, help="timed steps of the inducing-point-basis extra (0 = skip)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="development aid: run rank 0's particle shard of an N-GPU job on ONE GPU (no collectives); "
                          "the JSON line is marked emulated and is not a scaling result")
@@ -348,6 +349,35 @@ def main():
             "relaxation_rate_min": rho.min().item(), "stiffness_max": rho.max().item(),
         }
         log(f"train_pls: {len(energies)} steps in {wall:.2f} s, energy {energies[0]:.4g} -> {energies[-1]:.4g}")
+    # ---- inducing-point basis: same data, same cost, one rank's shard ----
+    if args.ipb_steps > 0:
+        from projected_langevin_sampling_amd.basis import InducingPointBasis
+
+        t_ipb = time.perf_counter()
+        ipb = InducingPointBasis(kernel, z, y[: z.shape[0]], x)
+        ipb.workspace_bytes = basis.workspace_bytes
+        D.attach_shard(ipb, j_total, rank, shard_world)
+        torch.cuda.synchronize()
+        t_ipb = time.perf_counter() - t_ipb
+        a = torch.normal(0.0, 1.0, size=(cfg["m"], j_loc), generator=torch.Generator().manual_seed(1), dtype=torch.float64).cuda()
+        b = torch.empty_like(a)
+        eta_i = 1e-9  # timing only: k(Z,Z)^-1 is stiff, the dynamics are not the point here
+        for w in range(1 + args.ipb_steps):
+            if w == 1:
+                barrier()
+                t0 = time.perf_counter()
+            ipb.fused_step(cost, a, eta_i, out=b, new_state=True, noise=NoiseSpec(seed=7, step=w, j_offset=j0))
+            a, b = b, a
+        barrier()
+        dti = (time.perf_counter() - t0) / args.ipb_steps
+        out["inducing_point_basis"] = {
+            "ms_per_step": dti * 1e3, "steps": args.ipb_steps, "setup_s": round(t_ipb, 2),
+            "step": "V = K_ZZ^-1 U (MFMA) -> F = K_XZ V -> d cost/d f -> K_ZX G -> e = L_c xi (Philox + MFMA) -> update",
+            "flop_per_step": 4.0 * n * cfg["m"] * j_loc + 4.0 * cfg["m"] ** 2 * j_loc,
+            "tflops": (4.0 * n * cfg["m"] * j_loc + 4.0 * cfg["m"] ** 2 * j_loc) / dti / 1e12,
+        }
+        log(f"inducing-point basis: {dti * 1e3:.2f} ms/step")
+        del ipb, a, b
     # ---- CPU baseline (rank 0, N=1 only) ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         lam_all, vec_all = basis.eigenvalues.cpu(), basis.eigenvectors.cpu()

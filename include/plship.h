@@ -192,6 +192,13 @@ int pls_link_transform(int32_t link, double jitter, const double *in, int64_t ld
 int pls_row_power_sums(const double *S, int64_t lds, int64_t rows, int64_t cols, const double *shift, int32_t power,
                        double *out, void *stream);
 
+/* out[r][k] = q[k]-quantile of row r of S (rows x cols), linear interpolation between order statistics at position
+ * q * (cols - 1): the value torch.quantile(S, q, dim=1) returns (conformalise/pls.py:36-45, :57-62).  One workgroup
+ * sorts one row in LDS (bitonic), so cols <= 16384; q: nq values in [0, 1] (device).  A row that contains a NaN yields
+ * NaN, like torch. */
+int pls_row_quantiles(const double *S, int64_t lds, int64_t rows, int64_t cols, const double *q, int32_t nq, double *out,
+                      int64_t ldout, void *stream);
+
 /* out(rows x J) standard normals from the library's counter-based generator (same stream the fused
  * step uses).  Replaces torch.normal at basis/base.py:55-63 and samplers.py:30-35 for on-device runs. */
 int pls_normal_fill(double *out, int64_t ldout, int64_t rows, int64_t j, uint64_t seed, uint64_t step,

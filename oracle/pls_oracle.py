@@ -503,6 +503,25 @@ def temper_scale(y_calibration, mean, variance) -> float:
     return 2 * torch.mean(torch.div(torch.square(y_calibration - mean), variance)).item()
 
 
+def conformal_uncalibrated(samples, coverage):
+    """conformalise/pls.py:24-45: per-x quantiles 0.5 -/+ coverage/2 over the particle axis."""
+    return (torch.quantile(samples, q=0.5 - coverage / 2, dim=1), torch.quantile(samples, q=0.5 + coverage / 2, dim=1))
+
+
+def conformal_predict_coverage(samples_fn, x_calibration, y_calibration, x, coverage):
+    """conformalise/base.py:58-114 with samples_fn(x) -> (N*, J) prediction samples (conformalise/pls.py:36-41)."""
+    n = x_calibration.shape[0]
+    lo_c, up_c = conformal_uncalibrated(samples_fn(x_calibration), coverage)
+    scores = torch.max(torch.stack([lo_c - y_calibration, y_calibration - up_c], dim=1), dim=1).values
+    calibration = torch.quantile(scores, float(np.clip((n + 1) * coverage / n, 0.0, 1.0))).item()
+    lo, up = conformal_uncalibrated(samples_fn(x), coverage)
+    median = torch.quantile(samples_fn(x), q=0.5, dim=1)
+    return (
+        torch.min(torch.stack([lo - calibration, median], dim=1), dim=1).values,
+        torch.max(torch.stack([up + calibration, median], dim=1), dim=1).values,
+    )
+
+
 # --------------------------------------------------------------------------------------
 # PLS facade + training loop
 # --------------------------------------------------------------------------------------

@@ -92,6 +92,7 @@ SIGNATURES = {
     "pls_cost_value": (C.c_int, [_CD, _P, _I64, _P, _I64, _I64, _P, _P, _SZ, _P]),
     "pls_link_transform": (C.c_int, [_I32, _D, _P, _I64, _I64, _I64, _P, _P, _I64, _P]),
     "pls_row_power_sums": (C.c_int, [_P, _I64, _I64, _I64, _P, _I32, _P, _P]),
+    "pls_row_quantiles": (C.c_int, [_P, _I64, _I64, _I64, _P, _I32, _P, _I64, _P]),
     "pls_normal_fill": (C.c_int, [_P, _I64, _I64, _I64, _U64, _U64, _I64, _P]),
     "pls_onb_build_projection": (C.c_int, [_P, _I64, _P, _I64, _I64, _I64, _I64, _P, _I64, _P, _I64, _P]),
     "pls_onb_build_gaussian": (C.c_int, [_OD, _P, _P, _I64, _P, _P]),

@@ -39,3 +39,18 @@ def row_power_sums(s: torch.Tensor, power: int, shift: torch.Tensor | None = Non
         "pls_row_power_sums",
     )
     return out
+
+
+def row_quantiles(s: torch.Tensor, qs) -> torch.Tensor:
+    """(rows, len(qs)) quantiles over dim 1 with torch.quantile's linear interpolation (pls_row_quantiles)."""
+    L.require_gpu_tensor(s, "samples")
+    s = s if s.stride(1) == 1 else s.contiguous()
+    rows, cols = s.shape
+    q = torch.as_tensor(list(qs), dtype=torch.float64).to(s.device)
+    out = torch.empty((rows, q.numel()), dtype=torch.float64, device=s.device)
+    L.check(
+        L.load().pls_row_quantiles(s.data_ptr(), L.ld(s), rows, cols, q.data_ptr(), q.numel(), out.data_ptr(), q.numel(),
+                                   L.stream_ptr()),
+        "pls_row_quantiles",
+    )
+    return out

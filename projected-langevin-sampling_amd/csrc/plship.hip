@@ -562,6 +562,55 @@ __global__ __launch_bounds__(256) void row_power_sums_kernel(const double *__res
   if (threadIdx.x == 0) out[blockIdx.x] = red[0];
 }
 
+// per-row quantiles: the row is sorted in LDS (bitonic network over the next power of two, +inf padding)
+__global__ __launch_bounds__(256) void row_quantiles_kernel(const double *__restrict__ samples, int64_t lds_, int64_t cols,
+                                                             int npad, const double *__restrict__ q, int nq,
+                                                             double *__restrict__ out, int64_t ldout) {
+  extern __shared__ __attribute__((aligned(16))) double qbuf[];
+  __shared__ int has_nan;
+  const int tid = threadIdx.x;
+  const double *row = samples + (int64_t)blockIdx.x * lds_;
+  if (tid == 0) has_nan = 0;
+  __syncthreads();
+  bool nan_seen = false;
+  for (int k = tid; k < npad; k += 256) {
+    const double v = (k < cols) ? row[k] : __builtin_inf();
+    nan_seen |= (v != v);
+    qbuf[k] = v;
+  }
+  if (nan_seen) has_nan = 1;
+  __syncthreads();
+  for (int size = 2; size <= npad; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < (npad >> 1); t += 256) {
+        const int pos = 2 * t - (t & (stride - 1));
+        const int partner = pos + stride;
+        const bool up = (pos & size) == 0;
+        const double a = qbuf[pos], b = qbuf[partner];
+        if ((a > b) == up) {
+          qbuf[pos] = b;
+          qbuf[partner] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int k = tid; k < nq; k += 256) {
+    double r;
+    if (has_nan) {
+      r = __builtin_nan("");
+    } else {
+      const double pos = q[k] * (double)(cols - 1);
+      const double lo_f = floor(pos);
+      const int lo = (int)lo_f;
+      const int hi = (lo + 1 < cols) ? lo + 1 : (int)cols - 1;
+      const double w = pos - lo_f, a = qbuf[lo], b = qbuf[hi];
+      r = (w < 0.5) ? a + w * (b - a) : b - (b - a) * (1.0 - w);  // torch.lerp's two-sided form
+    }
+    out[(int64_t)blockIdx.x * ldout + k] = r;
+  }
+}
+
 __global__ __launch_bounds__(256) void normal_fill_kernel(double *__restrict__ out, int64_t ldo, int64_t rows,
                                                            int64_t j, uint64_t seed, uint64_t step, int64_t j_offset) {
   const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -831,6 +880,28 @@ int pls_row_power_sums(const double *samples, int64_t lds, int64_t rows, int64_t
   if (rows == 0) return PLS_OK;
   hipLaunchKernelGGL(row_power_sums_kernel, dim3((unsigned)rows), dim3(256), 0, S(stream), samples, lds, cols, shift, power, out);
   return check_launch("row_power_sums");
+}
+
+int pls_row_quantiles(const double *samples, int64_t lds, int64_t rows, int64_t cols, const double *q, int32_t nq, double *out,
+                      int64_t ldout, void *stream) {
+  PLS_REQUIRE(samples && q && out, "row_quantiles: NULL pointer");
+  PLS_REQUIRE(rows >= 0 && cols >= 1 && lds >= cols && nq >= 1 && ldout >= nq, "row_quantiles: bad sizes");
+  PLS_REQUIRE(rows <= 0x7fffffff, "row_quantiles: too many rows");
+  if (cols > 16384) return fail(PLS_ERR_UNSUPPORTED, "row_quantiles: %lld samples per row > 16384 (one LDS sort per row)", (long long)cols);
+  if (rows == 0) return PLS_OK;
+  int npad = 2;
+  while (npad < cols) npad <<= 1;
+  const size_t bytes = (size_t)npad * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(row_quantiles_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * (int)sizeof(double));
+    if (e != hipSuccess) return fail(PLS_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(row_quantiles_kernel, dim3((unsigned)rows), dim3(256), bytes, S(stream), samples, lds, cols, npad, q, (int)nq,
+                     out, ldout);
+  return check_launch("row_quantiles");
 }
 
 int pls_normal_fill(double *out, int64_t ldout, int64_t rows, int64_t j, uint64_t seed, uint64_t step, int64_t j_offset,

@@ -284,3 +284,12 @@ def test_prediction_goldens(G):
     torch.manual_seed(1)
     got = onb.predict_untransformed_samples(u, x, noise=None)
     assert torch.allclose(got, t32(pg["onb_predict_sampled_seed1"]), rtol=1e-3)
+
+
+def test_conformalise_goldens(G):
+    c = G["conformalise"]
+    u, xc, yc = t32(c["particles"]), t32(c["x_calibration"]), t32(c["y_calibration"])
+    samples_fn = lambda x: x @ torch.ones((x.shape[1], u.shape[0])) @ u  # mockers/basis.py:83-97
+    assert torch.allclose(torch.quantile(samples_fn(xc), q=0.5, dim=1), t32(c["median"]))
+    lo, up = O.conformal_predict_coverage(samples_fn, xc, yc, xc, 0.95)
+    assert np.allclose(torch.mean(up - lo).item(), c["average_interval_width_095"])
