@@ -385,9 +385,10 @@ struct RowConsts {
   double k0_lo, k0_hi, k1_lo, k1_hi;
 };
 
-template <int TI, int TJ, class Fn>
+template <int TI, int TJ, int NCONST = 2, class Fn>
 __device__ __forceinline__ void epilogue_row_pairs(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int wave,
                                                    int64_t I, int64_t J, double *lds, double k0, double k1, Fn &&fn) {
+  // NCONST: how many of the per-row constant registers (k0, k1) the functor uses (their cross-lane reads are skipped otherwise)
   constexpr int WJ = TJ * 16;
   constexpr int STRIDE = WJ + EPI_PAD;
   constexpr int RPI = 64 / WJ;  // row pairs handled per iteration by the 64 lanes (1 for WJ = 64, 2 for WJ = 32)
@@ -396,32 +397,53 @@ __device__ __forceinline__ void epilogue_row_pairs(const AccFrag<TI, TJ> &acc, i
   const int q = lane >> 4, c16 = lane & 15;
   const int col = lane % WJ, sub = lane / WJ;
   const int64_t j = jw + col;
-  auto pass = [&](auto ta_tag) {
+  // One copy of the per-element code: the slab loop and the row loop are run-time loops (`unroll 1`); only the
+  // register -> LDS write needs compile-time accumulator indices, so it sits in a wave-uniform switch.  (Fully unrolled,
+  // the cost/Box-Muller code was inlined 64 times -- ~0.5 MB of instructions per kernel, every epilogue an I-cache miss
+  // streak: 24 us per tile instead of 11.)
+  auto write_slab = [&](auto ta_tag) {
     constexpr int ta = decltype(ta_tag)::value;
+    if constexpr (ta < TI) {
 #pragma unroll
-    for (int tb = 0; tb < TJ; ++tb)
+      for (int tb = 0; tb < TJ; ++tb)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) w[(4 * r + q) * STRIDE + tb * 16 + c16] = acc.v[ta][tb][r];
+        for (int r = 0; r < 4; ++r) w[(4 * r + q) * STRIDE + tb * 16 + c16] = acc.v[ta][tb][r];
+    }
+  };
+#pragma unroll 1
+  for (int ta = 0; ta < TI; ++ta) {
+    switch (ta) {
+      case 0: write_slab(std::integral_constant<int, 0>{}); break;
+      case 1: write_slab(std::integral_constant<int, 1>{}); break;
+      case 2: write_slab(std::integral_constant<int, 2>{}); break;
+      case 3: write_slab(std::integral_constant<int, 3>{}); break;
+      case 4: write_slab(std::integral_constant<int, 4>{}); break;
+      case 5: write_slab(std::integral_constant<int, 5>{}); break;
+      case 6: write_slab(std::integral_constant<int, 6>{}); break;
+      default: write_slab(std::integral_constant<int, 7>{}); break;
+    }
     __syncthreads();
+#pragma unroll 1
     for (int it = 0; it < 8 / RPI; ++it) {
-      const int p = it * RPI + sub;                // pair index 0..7 inside the 16-row slab
-      const int rr = (p >> 2) * 8 + (p & 3);       // rows rr and rr + 4
+      const int p = it * RPI + sub;           // pair index 0..7 inside the 16-row slab
+      const int rr = (p >> 2) * 8 + (p & 3);  // rows rr and rr + 4
       const int64_t i_lo = iw + ta * 16 + rr;
       const double v_lo = w[rr * STRIDE + col], v_hi = w[(rr + 4) * STRIDE + col];
       const int lr = ta * 16 + rr;
-      const RowConsts rc{__shfl(k0, lr), __shfl(k0, lr + 4), __shfl(k1, lr), __shfl(k1, lr + 4)};
+      RowConsts rc{0.0, 0.0, 0.0, 0.0};
+      if constexpr (NCONST >= 1) {
+        rc.k0_lo = __shfl(k0, lr);
+        rc.k0_hi = __shfl(k0, lr + 4);
+      }
+      if constexpr (NCONST >= 2) {
+        rc.k1_lo = __shfl(k1, lr);
+        rc.k1_hi = __shfl(k1, lr + 4);
+      }
+      (void)lr;
       if (i_lo < I && j < J) fn(i_lo, j, v_lo, i_lo + 4 < I, v_hi, rc);
     }
     __syncthreads();
-  };
-  if constexpr (TI >= 1) pass(std::integral_constant<int, 0>{});
-  if constexpr (TI >= 2) pass(std::integral_constant<int, 1>{});
-  if constexpr (TI >= 3) pass(std::integral_constant<int, 2>{});
-  if constexpr (TI >= 4) pass(std::integral_constant<int, 3>{});
-  if constexpr (TI >= 5) pass(std::integral_constant<int, 4>{});
-  if constexpr (TI >= 6) pass(std::integral_constant<int, 5>{});
-  if constexpr (TI >= 7) pass(std::integral_constant<int, 6>{});
-  if constexpr (TI >= 8) pass(std::integral_constant<int, 7>{});
+  }
   static_assert(TI <= 8, "extend the pass list");
 }
 
@@ -441,13 +463,13 @@ struct EpiStore {  // C = alpha * acc + beta * C   (split-K: slab `split` of C, 
                         int, int split, double *lds) const {
     double *C = C0 + (int64_t)split * slab;
     if (beta == 0.0) {
-      epilogue_row_pairs<TI, TJ>(acc, iw, jw, lane, wave, I, J, lds, 0.0, 0.0,
+      epilogue_row_pairs<TI, TJ, 0>(acc, iw, jw, lane, wave, I, J, lds, 0.0, 0.0,
                                  [&](int64_t i, int64_t j, double v0, bool hi, double v1, const RowConsts &) {
                                    C[i * ldc + j] = alpha * v0;
                                    if (hi) C[(i + 4) * ldc + j] = alpha * v1;
                                  });
     } else {
-      epilogue_row_pairs<TI, TJ>(acc, iw, jw, lane, wave, I, J, lds, 0.0, 0.0,
+      epilogue_row_pairs<TI, TJ, 0>(acc, iw, jw, lane, wave, I, J, lds, 0.0, 0.0,
                                  [&](int64_t i, int64_t j, double v0, bool hi, double v1, const RowConsts &) {
                                    C[i * ldc + j] = alpha * v0 + beta * C[i * ldc + j];
                                    if (hi) C[(i + 4) * ldc + j] = alpha * v1 + beta * C[(i + 4) * ldc + j];

@@ -90,7 +90,7 @@ struct EpiCostDeriv {
   __device__ void apply(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int wave, int64_t I, int64_t J,
                         int, int, double *lds) const {
     const double yl = load_row_constants(y, iw, lane, I);
-    epilogue_row_pairs<TI, TJ>(acc, iw, jw, lane, wave, I, J, lds, yl, 0.0,
+    epilogue_row_pairs<TI, TJ, 1>(acc, iw, jw, lane, wave, I, J, lds, yl, 0.0,
                                [&](int64_t i, int64_t j, double v0, bool hi, double v1, const RowConsts &rc) {
                                  G[i * ldg + j] = cost_deriv(cp, rc.k0_lo, v0);
                                  if (hi) G[(i + 4) * ldg + j] = cost_deriv(cp, rc.k0_hi, v1);
@@ -111,7 +111,7 @@ struct EpiCostValue {
                         int tile_i, int, double *lds) const {
     double s = 0.0;  // this lane's column, summed over the rows it is handed (fixed order)
     const double yl = load_row_constants(y, iw, lane, I);
-    epilogue_row_pairs<TI, TJ>(acc, iw, jw, lane, wave, I, J, lds, yl, 0.0,
+    epilogue_row_pairs<TI, TJ, 1>(acc, iw, jw, lane, wave, I, J, lds, yl, 0.0,
                                [&](int64_t, int64_t, double v0, bool hi, double v1, const RowConsts &rc) {
                                  s += cost_value(cp, rc.k0_lo, v0);
                                  if (hi) s += cost_value(cp, rc.k0_hi, v1);
