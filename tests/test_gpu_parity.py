@@ -850,3 +850,35 @@ def test_conformalise_vs_oracle(P):
     lo_w, up_w = O.conformal_predict_coverage(o_samples, xc, yc, xs, 0.9)
     lo_g, up_g = ConformalisePLS(xc, yc, FrozenPLS(), cu(u)).predict_coverage(xs, 0.9)
     assert relerr(lo_g, lo_w) < 1e-9 and relerr(up_g, up_w) < 1e-9
+
+
+# ------------------------------------------------------------------------------------------------------------
+# 10. the launch functions neither allocate nor synchronise: a step can be captured into a hipGraph and replayed
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("force_generic", [False, True])
+def test_step_is_hipgraph_capturable(P, force_generic):
+    pr = make_problem(600, 24, 128, 3, seed=61)
+    ob, gb = build_onb(P, pr)
+    mk = ob.approximation_dimension
+    gc = P.costs.GaussianCost(0.3, pr["y"], P.links.IdentityLinkFunction())
+    u = cu(pr["u"][:mk].contiguous())
+    out_eager = torch.empty_like(u)
+    out_graph = torch.empty_like(u)
+    spec = P.basis.NoiseSpec(seed=17, step=4)
+    gb.fused_step(gc, u, 1e-3, out=out_eager, noise=spec, force_generic=force_generic)  # also warms up (workspace, attributes)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            gb.fused_step(gc, u, 1e-3, out=out_graph, noise=spec, force_generic=force_generic)
+    out_graph.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out_graph, out_eager)
+    u.mul_(0.5)  # the graph reads the live particle buffer: replay follows its contents
+    gb.fused_step(gc, u, 1e-3, out=out_eager, noise=spec, force_generic=force_generic)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out_graph, out_eager)
