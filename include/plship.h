@@ -97,6 +97,10 @@ typedef struct {
   uint64_t seed;    /* PLS_NOISE_PHILOX */
   uint64_t step;    /* PLS_NOISE_PHILOX: step counter, so every step draws fresh noise */
   int64_t j_offset; /* global index of local column 0 (J-sharding: results do not depend on the GPU count) */
+  /* PLS_NOISE_PHILOX, optional: a DEVICE counter read at run time; the step used is *step_base + step.  Launch arguments
+   * are frozen into a captured hipGraph, this word is not: a graph of K steps (step = 0..K-1) followed by
+   * pls_counter_add(step_base, K) draws fresh noise on every replay. */
+  const uint64_t *step_base;
 } pls_noise_desc;
 
 /* Orthonormal basis state (reference: basis/orthonormal.py:22-68), produced by the setup calls below.
@@ -198,6 +202,9 @@ int pls_row_power_sums(const double *S, int64_t lds, int64_t rows, int64_t cols,
  * NaN, like torch. */
 int pls_row_quantiles(const double *S, int64_t lds, int64_t rows, int64_t cols, const double *q, int32_t nq, double *out,
                       int64_t ldout, void *stream);
+
+/* *counter += increment on the stream (device word; see pls_noise_desc.step_base). */
+int pls_counter_add(uint64_t *counter, uint64_t increment, void *stream);
 
 /* out(rows x J) standard normals from the library's counter-based generator (same stream the fused
  * step uses).  Replaces torch.normal at basis/base.py:55-63 and samplers.py:30-35 for on-device runs. */

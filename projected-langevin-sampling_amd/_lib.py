@@ -43,6 +43,7 @@ class NoiseDesc(C.Structure):
         ("seed", C.c_uint64),
         ("step", C.c_uint64),
         ("j_offset", C.c_int64),
+        ("step_base", C.c_void_p),
     ]
 
 
@@ -93,6 +94,7 @@ SIGNATURES = {
     "pls_link_transform": (C.c_int, [_I32, _D, _P, _I64, _I64, _I64, _P, _P, _I64, _P]),
     "pls_row_power_sums": (C.c_int, [_P, _I64, _I64, _I64, _P, _I32, _P, _P]),
     "pls_row_quantiles": (C.c_int, [_P, _I64, _I64, _I64, _P, _I32, _P, _I64, _P]),
+    "pls_counter_add": (C.c_int, [_P, _U64, _P]),
     "pls_normal_fill": (C.c_int, [_P, _I64, _I64, _I64, _U64, _U64, _I64, _P]),
     "pls_onb_build_projection": (C.c_int, [_P, _I64, _P, _I64, _I64, _I64, _I64, _P, _I64, _P, _I64, _P]),
     "pls_onb_build_gaussian": (C.c_int, [_OD, _P, _P, _I64, _P, _P]),

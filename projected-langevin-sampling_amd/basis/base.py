@@ -19,8 +19,10 @@ class NoiseSpec:
     philox:   libplship's counter-based stream keyed by (seed, step, row, j_offset + column)."""
 
     def __init__(self, injected: torch.Tensor | None = None, seed: int | None = None, step: int = 0, j_offset: int = 0,
-                 none: bool = False):
+                 none: bool = False, step_base: torch.Tensor | None = None):
         self.injected, self.seed, self.step, self.j_offset, self.none = injected, seed, step, j_offset, none
+        #: optional device int64 scalar added to ``step`` at kernel run time (lets a captured graph draw fresh noise)
+        self.step_base = step_base
 
     def desc(self) -> L.NoiseDesc:
         d = L.NoiseDesc()
@@ -32,6 +34,9 @@ class NoiseSpec:
             d.kind, d.xi, d.ldxi = L.NOISE_INJECTED, xi.data_ptr(), L.ld(xi)
         else:
             d.kind, d.seed, d.step, d.j_offset = L.NOISE_PHILOX, int(self.seed) & (2**64 - 1), int(self.step), int(self.j_offset)
+            if self.step_base is not None:
+                assert self.step_base.device.type == "cuda" and self.step_base.dtype == torch.int64 and self.step_base.numel() == 1
+                d.step_base = self.step_base.data_ptr()
         return d
 
 

@@ -183,6 +183,8 @@ struct NoiseP {
   int64_t ldxi;
   uint64_t seed, step;
   int64_t j_offset;
+  const uint64_t *step_base;  // optional device counter added to `step` at run time (graph replays)
+  __device__ uint64_t live_step() const { return step_base ? step + *step_base : step; }
 };
 
 static NoiseP make_noisep(const pls_noise_desc *n) {
@@ -193,6 +195,7 @@ static NoiseP make_noisep(const pls_noise_desc *n) {
     p.ldxi = 0;
     p.seed = p.step = 0;
     p.j_offset = 0;
+    p.step_base = nullptr;
     return p;
   }
   p.kind = n->kind;
@@ -201,6 +204,7 @@ static NoiseP make_noisep(const pls_noise_desc *n) {
   p.seed = n->seed;
   p.step = n->step;
   p.j_offset = n->j_offset;
+  p.step_base = n->step_base;
   return p;
 }
 
@@ -228,12 +232,13 @@ struct EpiLangevinGaussian {
     const double cl = load_row_constants(c, iw, lane, I);
     const double laml = load_row_constants(lam, iw, lane, I);
     const double ilaml = (iw + lane < I) ? 1.0 / laml : 0.0;
+    const uint64_t nstep = nz.live_step();
     epilogue_row_pairs<TI, TJ>(
         acc, iw, jw, lane, wave, I, J, lds, cl, ilaml,
         [&](int64_t i, int64_t j, double v0, bool hi, double v1, const RowConsts &rc) {
           double z0 = 0.0, z1 = 0.0;
           if (nz.kind == PLS_NOISE_PHILOX) {
-            normal_pair(nz.seed, nz.step, i, nz.j_offset + j, z0, z1);  // rows i and i + 4 share one Philox call
+            normal_pair(nz.seed, nstep, i, nz.j_offset + j, z0, z1);  // rows i and i + 4 share one Philox call
           } else if (nz.kind == PLS_NOISE_INJECTED) {
             z0 = nz.xi[i * nz.ldxi + j];
             if (hi) z1 = nz.xi[(i + 4) * nz.ldxi + j];
@@ -498,7 +503,7 @@ __global__ __launch_bounds__(256) void langevin_update_kernel(double *out, int64
     if (ib >= rows) continue;
     double z0 = 0.0, z1 = 0.0;
     if (nz.kind == PLS_NOISE_PHILOX) {
-      normal_pair(nz.seed, nz.step, ib, nz.j_offset + col, z0, z1);
+      normal_pair(nz.seed, nz.live_step(), ib, nz.j_offset + col, z0, z1);
     } else if (nz.kind == PLS_NOISE_INJECTED) {
       z0 = nz.xi[ib * nz.ldxi + col];
       if (ib + 4 < rows) z1 = nz.xi[(ib + 4) * nz.ldxi + col];
@@ -611,10 +616,14 @@ __global__ __launch_bounds__(256) void row_quantiles_kernel(const double *__rest
   }
 }
 
+__global__ __launch_bounds__(256) void counter_add_kernel(uint64_t *counter, uint64_t increment) { *counter += increment; }
+
 __global__ __launch_bounds__(256) void normal_fill_kernel(double *__restrict__ out, int64_t ldo, int64_t rows,
-                                                           int64_t j, uint64_t seed, uint64_t step, int64_t j_offset) {
+                                                           int64_t j, uint64_t seed, uint64_t step, int64_t j_offset,
+                                                           const uint64_t *__restrict__ step_base) {
   const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (col >= j) return;
+  if (step_base) step += *step_base;
   const int64_t npairs = cdiv(rows, 8) * 4;
   for (int64_t pr = blockIdx.y; pr < npairs; pr += gridDim.y) {
     const int64_t ib = (pr >> 2) * 8 + (pr & 3);
@@ -910,8 +919,14 @@ int pls_normal_fill(double *out, int64_t ldout, int64_t rows, int64_t j, uint64_
   PLS_REQUIRE(rows >= 0 && j >= 0 && ldout >= j, "normal_fill: bad sizes");
   if (rows == 0 || j == 0) return PLS_OK;
   hipLaunchKernelGGL(normal_fill_kernel, dim3((unsigned)cdiv(j, 256), rows_grid(cdiv(rows, 8) * 4)), dim3(256), 0,
-                     S(stream), out, ldout, rows, j, seed, step, j_offset);
+                     S(stream), out, ldout, rows, j, seed, step, j_offset, (const uint64_t *)nullptr);
   return check_launch("normal_fill");
+}
+
+int pls_counter_add(uint64_t *counter, uint64_t increment, void *stream) {
+  PLS_REQUIRE(counter != nullptr, "counter_add: NULL pointer");
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, S(stream), counter, increment);
+  return check_launch("counter_add");
 }
 
 // ---- orthonormal basis -----------------------------------------------------------------------------------------
@@ -1146,7 +1161,7 @@ static int ipb_finish(const pls_ipb_desc *basis, const double *U, int64_t ldu, c
   if (nz.kind == PLS_NOISE_PHILOX) {
     if (!basis->LcT) return fail(PLS_ERR_INVALID_ARGUMENT, "ipb: Philox noise needs the Cholesky factor LcT");
     hipLaunchKernelGGL(normal_fill_kernel, dim3((unsigned)cdiv(j, 256), rows_grid(cdiv(basis->m, 8) * 4)), dim3(256), 0, st,
-                       xi_buf, j, basis->m, j, nz.seed, nz.step, nz.j_offset);
+                       xi_buf, j, basis->m, j, nz.seed, nz.step, nz.j_offset, nz.step_base);
     int rc = check_launch("normal_fill");
     if (rc) return rc;
     // e = Lc xi :  L[k][i] = LcT[k][i] = Lc[i][k]

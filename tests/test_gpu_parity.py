@@ -882,3 +882,30 @@ def test_step_is_hipgraph_capturable(P, force_generic):
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(out_graph, out_eager)
+
+
+def test_captured_multi_step_graph_draws_fresh_noise_and_matches_eager(P):
+    from projected_langevin_sampling_amd.graph import CapturedSteps
+
+    pr = make_problem(500, 20, 96, 2, seed=71)
+    ob, gb = build_onb(P, pr)
+    mk = ob.approximation_dimension
+    gc = P.costs.GaussianCost(0.3, pr["y"], P.links.IdentityLinkFunction())
+    pls = P.pkg.PLS(gb, gc)
+    u0 = cu(pr["u"][:mk].contiguous())
+    eta, k, seed = 1e-3, 3, 99
+    run = CapturedSteps(pls, u0.clone(), eta, steps_per_replay=k, seed=seed)
+    run.replay(2)  # 6 steps
+    torch.cuda.synchronize()
+    assert run.steps_done == 2 * k
+    # eager run with the same (seed, step) sequence
+    cur, nxt = u0.clone(), torch.empty_like(u0)
+    for s in range(2 * k):
+        gb.fused_step(gc, cur, eta, out=nxt, new_state=True, noise=P.basis.NoiseSpec(seed=seed, step=s))
+        cur, nxt = nxt, cur
+    assert torch.equal(run.particles, cur)
+    # fresh noise per replay: the second replay did not repeat the first one's increments
+    run2 = CapturedSteps(pls, u0.clone(), eta, steps_per_replay=k, seed=seed)
+    a = run2.replay(1).clone()
+    b = run2.replay(1).clone()
+    assert not torch.equal(a - u0, b - a)
