@@ -324,6 +324,25 @@ def main():
                          "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
                          "traffic": None, "avg_launch_ms": k["avg_ms"]},
         }
+        # the same K steps as a captured hipGraph (10 steps per replay): what the launch overhead costs on small shards
+        from projected_langevin_sampling_amd.graph import CapturedSteps
+
+        gsteps = 10
+        run_g = CapturedSteps(pkg.PLS(basis, cost), ping.clone(), eta, steps_per_replay=gsteps, seed=4321)
+        run_g.replay(2)
+        barrier()
+        t0 = time.perf_counter()
+        reps = max(fsteps // gsteps, 5)
+        run_g.replay(reps)
+        barrier()
+        dtg = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dtg], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dtg = tt.item()
+        out["gaussian_fast_path"]["hipgraph_ms_per_step"] = dtg / (reps * gsteps) * 1e3
+        out["gaussian_fast_path"]["hipgraph_steps_per_s"] = reps * gsteps / dtg
+        del run_g
     # ---- wall-clock to converged energy: the reference's train_pls loop (step, energy, early stop) ----
     if cfg["cost"] == "gaussian" and args.converge_steps > 0:
         from projected_langevin_sampling_amd.trainers import train_pls
