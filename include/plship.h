@@ -299,6 +299,25 @@ int pls_ipb_energy(const pls_ipb_desc *basis, const pls_cost_desc *cost, const d
 int pls_ipb_prior_energy(const pls_ipb_desc *basis, const double *U, int64_t ldu, int64_t j, const double *cost,
                          double *e, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Setup before the path: greedy conditional-variance inducing-point selection
+ * ------------------------------------------------------------------------------------------- */
+
+/* Picks m rows of x (N x D, row-major) by the partial pivoted Cholesky / greedy DPP-MAP rule of
+ * src/inducing_point_selectors/conditional_variance.py:27-120 (the caller has already applied the reference's random
+ * permutation, :58-61): start from argmax of the jittered kernel diagonal, then repeatedly
+ *   e = (round20(k(X, x_j)) + jitter * [n == j] - c[:i, j] . c[:i, :]) / sqrt(d_j);  c[i, :] = e;  d = max(d - e^2, 0)
+ * and take the largest remaining d among the points not chosen yet (:101-106); stop early once sum(d) < threshold
+ * (:108-113).  No N x N Gram matrix is formed (the reference builds one just to read its diagonal, :64-69).
+ * indices: m int64 (device), count: 1 int64 (device) = number of points selected (m unless the threshold stopped it).
+ * Nothing synchronises: the pivot of every iteration stays on the device.  Ties are broken towards the smaller index.
+ * workspace: pls_select_inducing_workspace_bytes(n, m) bytes. */
+size_t pls_select_inducing_workspace_bytes(int64_t n, int64_t m);
+int pls_select_inducing_conditional_variance(int32_t kernel_kind, const double *x, int64_t n, int64_t d,
+                                             const double *lengthscale, double outputscale, int64_t m, double jitter,
+                                             double threshold, int64_t *indices, int64_t *count, void *workspace,
+                                             size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

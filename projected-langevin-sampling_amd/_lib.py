@@ -106,6 +106,8 @@ SIGNATURES = {
     "pls_onb_energy": (C.c_int, [_OD, _CD, _P, _P, _I64, _I64, _P, _I32, _P, _SZ, _P]),
     "pls_onb_prior_energy": (C.c_int, [_OD, _P, _I64, _I64, _P, _P, _P]),
     "pls_ipb_prior_energy": (C.c_int, [_ID, _P, _I64, _I64, _P, _P, _P, _SZ, _P]),
+    "pls_select_inducing_workspace_bytes": (_SZ, [_I64, _I64]),
+    "pls_select_inducing_conditional_variance": (C.c_int, [_I32, _P, _I64, _I64, _P, _D, _I64, _D, _D, _P, _P, _P, _SZ, _P]),
     "pls_ipb_forward": (C.c_int, [_ID, _P, _I64, _I64, _P, _I64, _P, _SZ, _P]),
     "pls_ipb_particle_update": (C.c_int, [_ID, _P, _I64, _P, _I64, _I64, _D, _ND, _P, _I64, _P, _SZ, _P]),
     "pls_ipb_step_workspace_bytes": (_SZ, [_ID, _I64, _I64]),

@@ -651,6 +651,164 @@ __global__ __launch_bounds__(256) void matvec_rows_kernel(const double *__restri
   if (threadIdx.x == 0) c[blockIdx.x] = red[0];
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// greedy conditional-variance inducing-point selection (reference: src/inducing_point_selectors/conditional_variance.py)
+// ---------------------------------------------------------------------------------------------------------------
+struct CvState {       // device-resident scalars of the selection loop
+  int64_t pivot;       // index chosen for the current iteration
+  double pivot_d;      // d[pivot] before this iteration's update
+  int64_t count;       // points selected so far
+  int64_t stopped;     // the threshold test fired: later iterations are no-ops
+};
+
+__device__ inline double cv_kernel_eval(int kind, const double *__restrict__ x, int64_t a, int64_t b, int d,
+                                        const double *__restrict__ inv_ls, double outputscale) {
+  double s = 0.0;
+  if (kind == PLS_KERNEL_RBF_ARD) {
+    for (int k = 0; k < d; ++k) {
+      const double e = (x[a * d + k] - x[b * d + k]) * inv_ls[k];
+      s = fma(e, e, s);
+    }
+    return outputscale * exp(-0.5 * s);
+  }
+  for (int k = 0; k < d; ++k) s = fma(x[a * d + k], x[b * d + k], s);
+  return s;
+}
+
+constexpr int CV_BLOCK = 256;
+
+// d[n] = k(x_n, x_n) + jitter; chosen[n] = 0
+__global__ __launch_bounds__(CV_BLOCK) void cv_init_kernel(int kind, const double *__restrict__ x, int64_t n, int d,
+                                                            const double *__restrict__ lengthscale, double outputscale,
+                                                            double jitter, double *__restrict__ di,
+                                                            unsigned char *__restrict__ chosen, CvState *st) {
+  __shared__ double inv_ls[64];
+  if ((int)threadIdx.x < d) inv_ls[threadIdx.x] = (kind == PLS_KERNEL_RBF_ARD) ? 1.0 / lengthscale[threadIdx.x] : 1.0;
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * CV_BLOCK + threadIdx.x;
+  if (i == 0) {
+    st->count = 0;
+    st->stopped = 0;
+  }
+  if (i >= n) return;
+  di[i] = cv_kernel_eval(kind, x, i, i, d, inv_ls, outputscale) + jitter;
+  chosen[i] = 0;
+}
+
+// stage 1 of the pivot search: per block the largest d among the not-yet-chosen points (smaller index wins ties) and sum(d)
+__global__ __launch_bounds__(CV_BLOCK) void cv_argmax_partial_kernel(const double *__restrict__ di,
+                                                                      const unsigned char *__restrict__ chosen, int64_t n,
+                                                                      double *__restrict__ pval, int64_t *__restrict__ pidx,
+                                                                      double *__restrict__ psum) {
+  __shared__ double sv[CV_BLOCK], ss[CV_BLOCK];
+  __shared__ int64_t si[CV_BLOCK];
+  double best = -1.0, sum = 0.0;
+  int64_t bi = -1;
+  for (int64_t i = (int64_t)blockIdx.x * CV_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * CV_BLOCK) {
+    const double v = di[i];
+    sum += v;
+    if (!chosen[i] && v > best) {
+      best = v;
+      bi = i;
+    }
+  }
+  sv[threadIdx.x] = best;
+  si[threadIdx.x] = bi;
+  ss[threadIdx.x] = sum;
+  __syncthreads();
+  for (int w = CV_BLOCK / 2; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) {
+      const double ov = sv[threadIdx.x + w];
+      const int64_t oi = si[threadIdx.x + w];
+      if (oi >= 0 && (ov > sv[threadIdx.x] || (ov == sv[threadIdx.x] && (si[threadIdx.x] < 0 || oi < si[threadIdx.x])))) {
+        sv[threadIdx.x] = ov;
+        si[threadIdx.x] = oi;
+      }
+      ss[threadIdx.x] += ss[threadIdx.x + w];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    pval[blockIdx.x] = sv[0];
+    pidx[blockIdx.x] = si[0];
+    psum[blockIdx.x] = ss[0];
+  }
+}
+
+// stage 2: one block; records the pivot (and its d), appends it to `indices`, applies the threshold rule
+//   first != 0: the very first pick (argmax of the diagonal, no threshold test, conditional_variance.py:70)
+__global__ __launch_bounds__(CV_BLOCK) void cv_argmax_final_kernel(const double *__restrict__ pval,
+                                                                    const int64_t *__restrict__ pidx,
+                                                                    const double *__restrict__ psum, int nparts,
+                                                                    const double *__restrict__ di,
+                                                                    unsigned char *__restrict__ chosen, int64_t *indices,
+                                                                    int64_t m, double threshold, int first, CvState *st) {
+  __shared__ double sv[CV_BLOCK], ss[CV_BLOCK];
+  __shared__ int64_t si[CV_BLOCK];
+  double best = -1.0, sum = 0.0;
+  int64_t bi = -1;
+  for (int p = threadIdx.x; p < nparts; p += CV_BLOCK) {
+    const double v = pval[p];
+    const int64_t i = pidx[p];
+    sum += psum[p];
+    if (i >= 0 && (v > best || (v == best && (bi < 0 || i < bi)))) {
+      best = v;
+      bi = i;
+    }
+  }
+  sv[threadIdx.x] = best;
+  si[threadIdx.x] = bi;
+  ss[threadIdx.x] = sum;
+  __syncthreads();
+  for (int w = CV_BLOCK / 2; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) {
+      const double ov = sv[threadIdx.x + w];
+      const int64_t oi = si[threadIdx.x + w];
+      if (oi >= 0 && (ov > sv[threadIdx.x] || (ov == sv[threadIdx.x] && (si[threadIdx.x] < 0 || oi < si[threadIdx.x])))) {
+        sv[threadIdx.x] = ov;
+        si[threadIdx.x] = oi;
+      }
+      ss[threadIdx.x] += ss[threadIdx.x + w];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && !st->stopped) {
+    if (st->count < m && si[0] >= 0) {
+      st->pivot = si[0];
+      st->pivot_d = di[si[0]];
+      indices[st->count] = si[0];
+      chosen[si[0]] = 1;
+      st->count += 1;
+    }
+    // conditional_variance.py:108-113: after picking, stop if tr(Kff - Qff) = sum(d) fell below the threshold
+    if (!first && ss[0] < threshold) st->stopped = 1;
+  }
+}
+
+// one greedy iteration i (0-based): e = (round20(k(X, x_j)) + jitter [n == j] - c[:i, j] . c[:i, n]) / sqrt(d_j)
+__global__ __launch_bounds__(CV_BLOCK) void cv_update_kernel(int kind, const double *__restrict__ x, int64_t n, int d,
+                                                              const double *__restrict__ lengthscale, double outputscale,
+                                                              double jitter, int64_t iter, double *__restrict__ ci,
+                                                              double *__restrict__ di, const CvState *__restrict__ st) {
+  __shared__ double inv_ls[64];
+  if ((int)threadIdx.x < d) inv_ls[threadIdx.x] = (kind == PLS_KERNEL_RBF_ARD) ? 1.0 / lengthscale[threadIdx.x] : 1.0;
+  __syncthreads();
+  if (st->stopped || st->count != iter + 1) return;  // (stopped early, or ran out of candidates)
+  const int64_t j = st->pivot;
+  const double dj = sqrt(st->pivot_d);
+  const int64_t col = (int64_t)blockIdx.x * CV_BLOCK + threadIdx.x;
+  if (col >= n) return;
+  double g = cv_kernel_eval(kind, x, col, j, d, inv_ls, outputscale);
+  g = rint(g * 1e20) / 1e20;  // np.round(., 20) (conditional_variance.py:93)
+  if (col == j) g += jitter;
+  double dot = 0.0;
+  for (int64_t t = 0; t < iter; ++t) dot = fma(ci[t * n + j], ci[t * n + col], dot);
+  const double e = (g - dot) / dj;
+  ci[iter * n + col] = e;
+  const double nd = di[col] - e * e;
+  di[col] = nd > 0.0 ? nd : 0.0;
+}
+
 static unsigned rows_grid(int64_t items) { return (unsigned)(items < 1 ? 1 : (items > 1024 ? 1024 : items)); }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1290,6 +1448,59 @@ int pls_ipb_prior_energy(const pls_ipb_desc *basis, const double *U, int64_t ldu
                      (int64_t)(cost ? 1 : 0), j, e, 0, 2, (const double *)V, j, basis->m, (const double *)nullptr,
                      0.5 * (double)basis->m, 1.0, (const double *)nullptr);
   return check_launch("column_reduce");
+}
+
+size_t pls_select_inducing_workspace_bytes(int64_t n, int64_t m) {
+  if (n <= 0 || m <= 1) return 0;
+  const size_t nparts = 1024;
+  return align_up((size_t)(m - 1) * n * sizeof(double), 256) + align_up((size_t)n * sizeof(double), 256) +
+         align_up((size_t)n, 256) + align_up(nparts * (2 * sizeof(double) + sizeof(int64_t)), 256) + 256;
+}
+
+int pls_select_inducing_conditional_variance(int32_t kernel_kind, const double *x, int64_t n, int64_t d,
+                                             const double *lengthscale, double outputscale, int64_t m, double jitter,
+                                             double threshold, int64_t *indices, int64_t *count, void *workspace,
+                                             size_t workspace_bytes, void *stream) {
+  PLS_REQUIRE(kernel_kind == PLS_KERNEL_RBF_ARD || kernel_kind == PLS_KERNEL_LINEAR, "unknown kernel kind %d", kernel_kind);
+  PLS_REQUIRE(x && indices && count, "select_inducing: NULL pointer");
+  PLS_REQUIRE(m > 1, "select_inducing: Must have at least 2 inducing points");  // conditional_variance.py:57
+  PLS_REQUIRE(n >= m && d >= 1 && d <= 64, "select_inducing: need n >= m and 1 <= d <= 64");
+  PLS_REQUIRE(kernel_kind != PLS_KERNEL_RBF_ARD || lengthscale, "select_inducing: RBF needs lengthscale");
+  const size_t need = pls_select_inducing_workspace_bytes(n, m);
+  if (!workspace || workspace_bytes < need)
+    return fail(PLS_ERR_WORKSPACE_TOO_SMALL, "select_inducing: workspace %zu < %zu bytes", workspace_bytes, need);
+  char *w = static_cast<char *>(workspace);
+  double *ci = reinterpret_cast<double *>(w);
+  w += align_up((size_t)(m - 1) * n * sizeof(double), 256);
+  double *di = reinterpret_cast<double *>(w);
+  w += align_up((size_t)n * sizeof(double), 256);
+  unsigned char *chosen = reinterpret_cast<unsigned char *>(w);
+  w += align_up((size_t)n, 256);
+  const int nparts = (int)(cdiv(n, CV_BLOCK) < 1024 ? cdiv(n, CV_BLOCK) : 1024);
+  double *pval = reinterpret_cast<double *>(w);
+  double *psum = pval + 1024;
+  int64_t *pidx = reinterpret_cast<int64_t *>(psum + 1024);
+  w += align_up((size_t)1024 * (2 * sizeof(double) + sizeof(int64_t)), 256);
+  CvState *st = reinterpret_cast<CvState *>(w);
+  hipStream_t s = S(stream);
+  const unsigned gn = (unsigned)cdiv(n, CV_BLOCK);
+  hipLaunchKernelGGL(cv_init_kernel, dim3(gn), dim3(CV_BLOCK), 0, s, kernel_kind, x, n, (int)d, lengthscale, outputscale, jitter,
+                     di, chosen, st);
+  int rc = check_launch("cv_init");
+  if (rc) return rc;
+  for (int64_t it = 0; it < m; ++it) {
+    hipLaunchKernelGGL(cv_argmax_partial_kernel, dim3((unsigned)nparts), dim3(CV_BLOCK), 0, s, di, chosen, n, pval, pidx, psum);
+    hipLaunchKernelGGL(cv_argmax_final_kernel, dim3(1), dim3(CV_BLOCK), 0, s, pval, pidx, psum, nparts, di, chosen, indices, m,
+                       threshold, it == 0 ? 1 : 0, st);
+    if (it + 1 < m)
+      hipLaunchKernelGGL(cv_update_kernel, dim3(gn), dim3(CV_BLOCK), 0, s, kernel_kind, x, n, (int)d, lengthscale, outputscale,
+                         jitter, it, ci, di, st);
+    rc = check_launch("cv_iteration");
+    if (rc) return rc;
+  }
+  hipError_t e = hipMemcpyAsync(count, &st->count, sizeof(int64_t), hipMemcpyDeviceToDevice, s);
+  if (e != hipSuccess) return fail(PLS_ERR_HIP, "select_inducing: %s", hipGetErrorString(e));
+  return PLS_OK;
 }
 
 }  // extern "C"

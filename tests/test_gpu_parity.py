@@ -909,3 +909,76 @@ def test_captured_multi_step_graph_draws_fresh_noise_and_matches_eager(P):
     a = run2.replay(1).clone()
     b = run2.replay(1).clone()
     assert not torch.equal(a - u0, b - a)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# 11. inducing-point selection: greedy conditional variance on the GPU vs the numpy restatement
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,m,d", [(200, 12, 2), (1000, 40, 3), (5000, 64, 8)])
+def test_conditional_variance_selector_matches_oracle(P, n, m, d):
+    from oracle import selectors_oracle as SO
+    from projected_langevin_sampling_amd.inducing_point_selectors import ConditionalVarianceInducingPointSelector
+
+    g = torch.Generator().manual_seed(n + m)
+    x = torch.rand(n, d, generator=g) * 2 - 1
+    ls = 0.4 + torch.rand(d, generator=g)
+    np.random.seed(7)
+    x_sel, idx = ConditionalVarianceInducingPointSelector()(x, m, P.pkg.ARDKernel(ls, 1.7))
+    np.random.seed(7)
+    x_want, idx_want, _, _ = SO.conditional_variance_select(x.numpy(), m, SO.rbf_ard(ls.numpy(), 1.7))
+    assert idx.shape == (m,) and len(set(idx.tolist())) == m
+    assert np.array_equal(x_sel.numpy(), x.numpy()[idx.numpy()])
+    got = idx.numpy()
+    if not np.array_equal(got, idx_want):
+        # the two greedy runs may part ways only where the two candidates' residual variances tie to rounding
+        # (with short lengthscales in 8-D most residual variances are EXACTLY equal early on: the reference then takes
+        # whatever numpy's argsort puts last, libplship the smallest index)
+        t = int(np.argmax(got != idx_want))
+        di = SO.residual_variances(x.numpy(), list(idx_want[:t]), SO.rbf_ard(ls.numpy(), 1.7))
+        a, b = di[got[t]], di[idx_want[t]]
+        assert abs(a - b) <= 1e-9 * max(a, b), f"pick {t}: residual variances {a} vs {b} are not a tie"
+    # and every GPU pick is the greedy choice given its own prefix (oracle recurrence along the GPU's sequence)
+    xp = x.numpy()
+    for t in range(1, m, max(1, m // 8)):
+        di = SO.residual_variances(xp, list(got[:t]), SO.rbf_ard(ls.numpy(), 1.7))
+        rest = np.ones(n, dtype=bool)
+        rest[got[:t]] = False
+        assert di[got[t]] >= di[rest].max() * (1 - 1e-9), f"pick {t} is not the largest residual variance"
+
+
+def test_conditional_variance_selector_threshold_and_errors(P):
+    from projected_langevin_sampling_amd.inducing_point_selectors import (
+        ConditionalVarianceInducingPointSelector, RandomInducingPointSelector)
+
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(300, 2, generator=g)
+    k = P.pkg.ARDKernel([2.0, 2.0], 1.0)  # long lengthscale: a few points explain everything
+    np.random.seed(1)
+    xs, idx = ConditionalVarianceInducingPointSelector(threshold=1e-2)(x, 50, k)
+    assert 2 <= idx.shape[0] < 50 and xs.shape[0] == idx.shape[0]
+    with pytest.raises(AssertionError):
+        ConditionalVarianceInducingPointSelector()(x, 1, k)
+    xr, ir = RandomInducingPointSelector()(x, 10, None)
+    assert xr.shape == (10, 2) and torch.equal(xr, x[ir])
+
+
+def test_conditional_variance_selector_full_size_properties(P):
+    """BASELINE.json configs[1] size (N = 1e5, M = 1024): the selection is a partial pivoted Cholesky -- unique pivots,
+    non-increasing pivot variances, and k(Z, Z) of the chosen points is far better conditioned than a random subset's."""
+    from projected_langevin_sampling_amd.inducing_point_selectors import ConditionalVarianceInducingPointSelector
+
+    g = torch.Generator().manual_seed(0)
+    n, m, d = 100_000, 1024, 8
+    x = torch.rand(n, d, generator=g) * 2 - 1
+    ls = 0.5 + torch.rand(d, generator=g)
+    np.random.seed(0)
+    z, idx = ConditionalVarianceInducingPointSelector()(x, m, P.pkg.ARDKernel(ls, 1.0))
+    assert len(set(idx.tolist())) == m and torch.equal(z, x[idx])
+    kzz = P.pkg.ARDKernel(ls, 1.0)(z, z).cpu()
+    kzz_rand = P.pkg.ARDKernel(ls, 1.0)(x[:m], x[:m]).cpu()
+    ev, ev_rand = torch.linalg.eigvalsh(kzz), torch.linalg.eigvalsh(kzz_rand)
+    assert ev.min() > ev_rand.min()  # greedy picks spread out: larger smallest eigenvalue than the random subset
+    # pivoted-Cholesky identity: the product of the pivot variances is det k(Z,Z) -> compare log-determinants
+    chol = torch.linalg.cholesky(kzz + 1e-12 * torch.eye(m))
+    pivots = torch.diagonal(chol) ** 2  # in selection order these are the residual variances at pick time
+    assert (pivots[1:] <= pivots[:-1] * (1 + 1e-9)).float().mean().item() > 0.98
