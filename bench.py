@@ -156,6 +156,7 @@ def main():
     ap.add_argument("--converge-steps", type=int, default=4000,
                     help="step cap of the wall-clock-to-converged-energy run (0 = skip it)")
     ap.add_argument("--ipb-steps", type=int, default=3, help="timed steps of the inducing-point-basis extra (0 = skip)")
+    ap.add_argument("--select-inducing", action="store_true", help="also time the greedy inducing-point selection (setup)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="development aid: run rank 0's particle shard of an N-GPU job on ONE GPU (no collectives); "
                          "the JSON line is marked emulated and is not a scaling result")
@@ -368,6 +369,26 @@ def main():
             "relaxation_rate_min": rho.min().item(), "stiffness_max": rho.max().item(),
         }
         log(f"train_pls: {len(energies)} steps in {wall:.2f} s, energy {energies[0]:.4g} -> {energies[-1]:.4g}")
+    # ---- setup extra: greedy conditional-variance inducing-point selection at this N, M ----
+    if rank == 0 and args.select_inducing:
+        import numpy as np
+        from projected_langevin_sampling_amd.inducing_point_selectors import ConditionalVarianceInducingPointSelector
+
+        np.random.seed(0)
+        sel = ConditionalVarianceInducingPointSelector()
+        sel(x[:4096], 16, kernel.base_kernel)  # warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _, idx_sel = sel(x, cfg["m"], kernel.base_kernel)
+        torch.cuda.synchronize()
+        t_sel = time.perf_counter() - t0
+        alg_bytes = 8.0 * n * cfg["m"] * (cfg["m"] - 1) / 2 * 1.0  # the c[:i, n] reads of the recurrence dominate
+        out["inducing_point_selection"] = {
+            "seconds": t_sel, "selected": int(idx_sel.shape[0]), "algorithmic_GB": alg_bytes / 1e9,
+            "achieved_GBps": alg_bytes / t_sel / 1e9, "bound": "hbm",
+            "note": "partial pivoted Cholesky of k(X,X): M iterations of an N-long recurrence, 3 launches each, no host sync",
+        }
+        log(f"inducing-point selection: {t_sel:.3f} s")
     # ---- inducing-point basis: same data, same cost, one rank's shard ----
     if args.ipb_steps > 0:
         from projected_langevin_sampling_amd.basis import InducingPointBasis

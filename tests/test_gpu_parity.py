@@ -982,3 +982,36 @@ def test_conditional_variance_selector_full_size_properties(P):
     chol = torch.linalg.cholesky(kzz + 1e-12 * torch.eye(m))
     pivots = torch.diagonal(chol) ** 2  # in selection order these are the residual variances at pick time
     assert (pivots[1:] <= pivots[:-1] * (1 + 1e-9)).float().mean().item() > 0.98
+
+
+# ------------------------------------------------------------------------------------------------------------
+# 12. step-size search runner end to end on the device
+# ------------------------------------------------------------------------------------------------------------
+def test_train_pls_runner_end_to_end(P):
+    from projected_langevin_sampling_amd.runners import train_pls_runner
+
+    pr = make_problem(400, 16, 64, 1, seed=81)
+    ob, gb = build_onb(P, pr, threshold=1e-4)
+    gc = P.costs.GaussianCost(0.05, pr["y"], P.links.IdentityLinkFunction())
+    pls = P.pkg.PLS(gb, gc)
+    u0 = pls.initialise_particles(64, seed=0)
+    u0_copy = u0.clone()
+    kw = dict(pls=pls, particle_name="t", x_train=pr["x"], y_train=pr["y"], simulation_duration=2e-3, maximum_number_of_steps=400,
+              early_stopper_patience=1.0, number_of_step_searches=4, step_size_upper=2e-4,
+              minimum_change_in_energy_potential=1e-9, seed=5, particles=u0)
+    out_a, lr_a, n_a = train_pls_runner(metric_to_optimise="loss", **kw)
+    out_b, lr_b, n_b = train_pls_runner(metric_to_optimise="loss", **kw)
+    steps = np.logspace(np.log10(2e-4), np.log10(2e-3 / 400), 4)
+    assert lr_a in steps and n_a == int(2e-3 / lr_a) and torch.isfinite(out_a).all()
+    assert torch.equal(u0, u0_copy)                       # the initial particles are cloned, never modified
+    assert lr_a == lr_b and torch.equal(out_a, out_b)     # set_seed(seed) before every candidate: the search is reproducible
+    out_c, lr_c, _ = train_pls_runner(metric_to_optimise="mse", **kw)
+    assert lr_c in steps and torch.isfinite(out_c).all()
+    # the chosen run really is the best by its metric among the candidates
+    from projected_langevin_sampling_amd.utils import set_seed
+    finals = []
+    for s in steps:
+        set_seed(5)
+        _, e = P.pkg.train_pls(pls, u0.clone(), int(2e-3 / s), s, 1.0)
+        finals.append(e[-1] if e else float("inf"))
+    assert lr_a == steps[int(np.argmin(finals))]

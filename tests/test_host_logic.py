@@ -124,3 +124,43 @@ def test_checkpoint_format_matches_the_reference(tmp_path, monkeypatch):
     _, particles, best_lr, epochs = checkpoint.load_pls(p, path)
     assert particles.dtype == torch.float64 and torch.equal(particles, u) and p.observation_noise == 0.5
     assert best_lr is None and epochs is None
+
+
+def test_step_size_search_skeleton_matches_the_reference_rules():
+    """experiments/runners.py:331-446 with a scripted training function: which candidates run, which is kept, when it stops."""
+    from projected_langevin_sampling_amd.runners import train_pls_runner
+
+    calls = []
+    # energies per candidate step size (index): 0 diverges (nan particles), 1 and 2 converge, 3 equals 2 -> search stops after 3
+    script = {0: ([5.0], float("nan")), 1: ([9.0, 4.0], 1.0), 2: ([9.0, 3.0], 2.0), 3: ([9.0, 3.0000001], 3.0), 4: ([1.0], 4.0)}
+
+    def fake_train(pls, particles, number_of_epochs, step_size, early_stopper_patience):
+        i = len(calls)
+        calls.append((step_size, number_of_epochs, torch.initial_seed()))
+        energies, fill = script[i]
+        return torch.full_like(particles, fill), list(energies)
+
+    p0 = torch.zeros(2, 3)
+    out, best_lr, n_energy = train_pls_runner(
+        pls=None, particle_name="t", x_train=None, y_train=None, simulation_duration=1.0, maximum_number_of_steps=1000,
+        early_stopper_patience=1.0, number_of_step_searches=5, step_size_upper=0.1, minimum_change_in_energy_potential=1e-6,
+        seed=11, particles=p0, metric_to_optimise="loss", train_fn=fake_train)
+    steps = np.logspace(np.log10(0.1), np.log10(1e-3), 5)
+    assert len(calls) == 4 and np.allclose([c[0] for c in calls], steps[:4])  # stopped after the 4th (relative change < 1e-6)
+    assert [c[1] for c in calls] == [int(1.0 / s) for s in steps[:4]] and all(c[2] == 11 for c in calls)
+    assert best_lr == steps[2] and n_energy == 2 and torch.all(out == 2.0)  # candidate 3's energy is not lower than 2's
+    assert torch.all(p0 == 0)  # the caller's particles are never modified
+    with pytest.raises(NotImplementedError):
+        train_pls_runner(None, "t", None, None, 1.0, 10, 1.0, 2, 0.1, 1e-3, 0, p0, metric_to_optimise="bogus", train_fn=fake_train)
+
+
+def test_metrics_match_their_definitions():
+    from projected_langevin_sampling_amd import metrics
+
+    m, v, y = torch.tensor([1.0, 2.0]), torch.tensor([0.5, 2.0]), torch.tensor([1.5, 0.0])
+    d = torch.distributions.MultivariateNormal(m, covariance_matrix=torch.diag(v))
+    assert np.isclose(metrics.calculate_mae(d, y), 1.25) and np.isclose(metrics.calculate_mse(d, y), (0.25 + 4.0) / 2)
+    want = (0.5 * (torch.log(2 * torch.pi * v) + (y - m) ** 2 / v)).mean().item()
+    assert np.isclose(metrics.calculate_nll(d, y), want)
+    b = torch.distributions.Bernoulli(probs=torch.tensor([0.9, 0.2]))
+    assert np.isclose(metrics.calculate_nll(b, torch.tensor([1.0, 0.0])), -(np.log(0.9) + np.log(0.8)) / 2)
