@@ -36,7 +36,23 @@ struct GemmShape {
   int64_t I, J, K;
   int nti, ntj;
   int64_t kchunk;  // split-K: block (x, y) contracts k in [y * kchunk, min(K, (y + 1) * kchunk)); gridDim.y slabs
+#ifdef PLS_STAMP
+  unsigned long long *stamps;  // diagnostic build only: 4 s_memtime stamps per workgroup (never read by the kernel)
+#endif
 };
+
+#ifdef PLS_STAMP
+#define PLS_STAMP_AT(slot)                                                                             \
+  do {                                                                                                 \
+    if (g.stamps && threadIdx.x == 0) {                                                                \
+      unsigned long long t_;                                                                           \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                       \
+      g.stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + (slot)] = t_;                        \
+    }                                                                                                  \
+  } while (0)
+#else
+#define PLS_STAMP_AT(slot) do {} while (0)
+#endif
 
 // blockIdx.x -> (tile_i, tile_j)
 __device__ inline void gemm_tile_coords(int bid, int nti, int ntj, int &ti, int &tj) {
@@ -237,6 +253,7 @@ __device__ __forceinline__ void gemm_tn_mainloop(const GemmShape &g, int64_t i0,
     }
   }
   __syncthreads();
+  PLS_STAMP_AT(1);
 
   int64_t kt = 0;
   if (DMA) {
@@ -338,6 +355,7 @@ __global__ __launch_bounds__((BI / WI) * (BJ / WJ) * 64, MINW) void gemm_tn_f64_
     g.K = (g.K - k0 < g.kchunk) ? g.K - k0 : g.kchunk;
   }
 
+  PLS_STAMP_AT(0);
   AccFrag<TI, TJ> acc;
 #pragma unroll
   for (int a = 0; a < TI; ++a)
@@ -359,9 +377,11 @@ __global__ __launch_bounds__((BI / WI) * (BJ / WJ) * 64, MINW) void gemm_tn_f64_
     gemm_tn_mainloop<BI, BJ, WI, WJ, BK, false, true, false>(g, i0, j0, lds, acc);
   }
 
+  PLS_STAMP_AT(2);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wi = (wave / (BJ / WJ)) * WI, wj = (wave % (BJ / WJ)) * WJ;
   epi.template apply<TI, TJ>(acc, i0 + wi, j0 + wj, lane, wave, g.I, g.J, tile_i, split, lds);
+  PLS_STAMP_AT(3);
 }
 
 // ---- epilogues ------------------------------------------------------------------------------------------------
@@ -422,7 +442,11 @@ __device__ __forceinline__ void epilogue_row_pairs(const AccFrag<TI, TJ> &acc, i
       case 6: write_slab(std::integral_constant<int, 6>{}); break;
       default: write_slab(std::integral_constant<int, 7>{}); break;
     }
-    __syncthreads();
+    // No workgroup barrier here or after the row loop: the slab is private to this wave and a wave's LDS operations
+    // execute in issue order, so its reads see its own writes.  (A __syncthreads() would also wait vmcnt(0), i.e. for
+    // the global stores of the previous slab to COMPLETE: with the write path loaded by the co-resident workgroup that
+    // made the epilogue 165k cycles per tile instead of 14k -- measured with tools/stamp_probe.py.)
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll 1
     for (int it = 0; it < 8 / RPI; ++it) {
       const int p = it * RPI + sub;           // pair index 0..7 inside the 16-row slab
@@ -442,7 +466,7 @@ __device__ __forceinline__ void epilogue_row_pairs(const AccFrag<TI, TJ> &acc, i
       (void)lr;
       if (i_lo < I && j < J) fn(i_lo, j, v_lo, i_lo + 4 < I, v_hi, rc);
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
   }
   static_assert(TI <= 8, "extend the pass list");
 }

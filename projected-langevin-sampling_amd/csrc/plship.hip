@@ -119,7 +119,8 @@ struct EpiCostValue {
     if (WJ == 32) s += __shfl_xor(s, 32);  // two lane halves share the 32 columns
     constexpr int NWJ = BJ / WJ, NWI = BI / WI;
     const int wrow = wave / NWJ, wcol = wave % NWJ;
-    double *red = lds;  // [NWI][BJ]; epilogue_row_pairs ended with a barrier, its slabs are dead
+    double *red = lds;  // [NWI][BJ]; overlaps the waves' slabs: wait until every wave has left its row loops
+    __syncthreads();
     if (lane < WJ) red[wrow * BJ + wcol * WJ + lane] = s;
     __syncthreads();
     const int t = threadIdx.x;
@@ -163,7 +164,8 @@ struct EpiGaussianQuad {
     if (WJ == 32) s += __shfl_xor(s, 32);
     constexpr int NWJ = BJ / WJ, NWI = BI / WI;
     const int wrow = wave / NWJ, wcol = wave % NWJ;
-    double *red = lds;
+    double *red = lds;  // overlaps the waves' slabs: wait until every wave has left its row loops
+    __syncthreads();
     if (lane < WJ) red[wrow * BJ + wcol * WJ + lane] = s;
     __syncthreads();
     const int t = threadIdx.x;
@@ -261,7 +263,8 @@ struct EpiLangevinGaussian {
       if (WJ == 32) es += __shfl_xor(es, 32);
       const int wrow = wave / nwj, wcol = wave % nwj;
       const int nwi = (int)(blockDim.x >> 6) / nwj;
-      double *red = lds;
+      double *red = lds;  // overlaps the waves' slabs: wait until every wave has left its row loops
+      __syncthreads();
       if (lane < WJ) red[wrow * bj + wcol * WJ + lane] = es;
       __syncthreads();
       const int t = threadIdx.x;
@@ -274,6 +277,11 @@ struct EpiLangevinGaussian {
     }
   }
 };
+
+#ifdef PLS_STAMP
+static unsigned long long *g_stamp_buffer = nullptr;  // diagnostic build only (tools/stamp_probe.py)
+extern "C" void pls_debug_set_stamp_buffer(unsigned long long *p) { g_stamp_buffer = p; }
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------
 // GEMM launcher
@@ -291,6 +299,9 @@ static int launch_gemm_cfg(GemmShape g, const Epi &epi, hipStream_t st) {
     if (e != hipSuccess) return fail(PLS_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_set = true;
   }
+#ifdef PLS_STAMP
+  g.stamps = g_stamp_buffer;
+#endif
   g.nti = (int)cdiv(g.I, BI);
   g.ntj = (int)cdiv(g.J, BJ);
   const int64_t nwg = (int64_t)g.nti * g.ntj;
