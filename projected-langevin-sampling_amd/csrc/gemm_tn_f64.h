@@ -42,12 +42,21 @@ struct GemmShape {
 };
 
 #ifdef PLS_STAMP
+// 6 slots per workgroup: 4 s_memtime stamps, HW_ID, XCC_ID
 #define PLS_STAMP_AT(slot)                                                                             \
   do {                                                                                                 \
     if (g.stamps && threadIdx.x == 0) {                                                                \
       unsigned long long t_;                                                                           \
       asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                       \
-      g.stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + (slot)] = t_;                        \
+      unsigned long long *w_ = g.stamps + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 6;           \
+      w_[(slot)] = t_;                                                                                 \
+      if ((slot) == 0) {                                                                               \
+        unsigned h_, x_;                                                                               \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(h_));                               \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x_));                              \
+        w_[4] = h_;                                                                                    \
+        w_[5] = x_;                                                                                    \
+      }                                                                                                \
     }                                                                                                  \
   } while (0)
 #else
@@ -260,6 +269,9 @@ __device__ __forceinline__ void gemm_tn_mainloop(const GemmShape &g, int64_t i0,
     // Rotated pipeline.  Per step: issue the DMA of the next tile; run k-quads 0..2 (their fragments prefetched one
     // quad ahead); drain the DMA and cross the barrier; fetch the NEXT step's first fragments from the other buffer;
     // only then issue the last quad's 16 MFMAs, which cover the barrier skew and that fetch's LDS latency.
+    // (Issuing the DMA of step k+2 right after the barrier of step k -- a full step of latency budget instead of
+    // three quarters -- measured 3% SLOWER, tools/ab_gemm.py: the eight DMA issues delay the fragment fetch the last
+    // quad's MFMAs wait for.)
     auto read_frag = [&](int buf, int kq, double (&a)[TI], double (&b)[TJ]) {
       const double *l = Ls + buf * BK * SL + (kq * 4 + q) * SL + wi + c16;
       const double *r = Rs + buf * BK * SR + (kq * 4 + q) * SR + wj + c16;
@@ -279,28 +291,44 @@ __device__ __forceinline__ void gemm_tn_mainloop(const GemmShape &g, int64_t i0,
     if (nk_full > 1) {
       double fa[TI], fb[TJ], ga[TI], gb[TJ];
       read_frag(0, 0, fa, fb);
-      auto body = [&](auto buf_tag) {  // buf is a compile-time constant: LDS addresses fold into instruction offsets
+      // first = true: the very first 16 MFMAs of the tile take a literal zero as their C operand instead of reading
+      // zero-initialised accumulators (64 v_mov per wave that would each queue behind a 64-cycle MFMA of the
+      // co-resident workgroup: ~4k cycles of prologue per tile)
+      auto body = [&](auto buf_tag, auto first_tag) {  // buf is a compile-time constant: LDS addresses fold
         constexpr int buf = decltype(buf_tag)::value;
+        constexpr bool first = decltype(first_tag)::value;
         dma_load(buf ^ 1);
         read_frag(buf, 1, ga, gb);
-        mfma_block(fa, fb);  // quad 0
+        if constexpr (first) {
+#pragma unroll
+          for (int ta = 0; ta < TI; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < TJ; ++tb)
+              acc.v[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ta], fb[tb], double4_t{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+        } else {
+          mfma_block(fa, fb);  // quad 0
+        }
         read_frag(buf, 2, fa, fb);
         mfma_block(ga, gb);  // quad 1
         read_frag(buf, 3, ga, gb);
         mfma_block(fa, fb);  // quad 2
         __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();  // vmcnt(0): the DMA has landed; barrier: every wave is done reading `buf`
+        __syncthreads();  // vmcnt(0): the DMA of step k+1 has landed; barrier: every wave is done reading `buf`
         __builtin_amdgcn_sched_barrier(0);
         read_frag(buf ^ 1, 0, fa, fb);      // next step's quad 0
         __builtin_amdgcn_sched_barrier(0);  // keep that fetch AHEAD of the 16 MFMAs that hide its latency
         mfma_block(ga, gb);                 // quad 3 of this step
       };
-      for (; kt + 2 < nk_full; kt += 2) {
-        body(std::integral_constant<int, 0>{});
-        body(std::integral_constant<int, 1>{});
+      using i0_t = std::integral_constant<int, 0>;
+      using i1_t = std::integral_constant<int, 1>;
+      // steps 0 .. nk_full - 2 run through body (each prefetches the following full step); the first one is peeled
+      body(i0_t{}, std::true_type{});
+      for (kt = 1; kt + 2 < nk_full; kt += 2) {
+        body(i1_t{}, std::false_type{});
+        body(i0_t{}, std::false_type{});
       }
       if (kt + 1 < nk_full) {
-        body(std::integral_constant<int, 0>{});
+        body(i1_t{}, std::false_type{});
         ++kt;
       }
       // fa/fb hold quad 0 of step kt (the last full step, or the one before the tail): finish it here
@@ -338,6 +366,9 @@ __device__ __forceinline__ void gemm_tn_mainloop(const GemmShape &g, int64_t i0,
     __syncthreads();
   }
 }
+
+// largest leading dimension (doubles) the direct epilogue addresses with 32-bit byte offsets (67 rows * ld * 8 < 2^31)
+constexpr int64_t kDirectMaxLd = (int64_t)1 << 21;
 
 template <int BI, int BJ, int WI, int WJ, int BK, int MINW, class Epilogue>
 __global__ __launch_bounds__((BI / WI) * (BJ / WJ) * 64, MINW) void gemm_tn_f64_kernel(GemmShape g, Epilogue epi) {
@@ -380,6 +411,15 @@ __global__ __launch_bounds__((BI / WI) * (BJ / WJ) * 64, MINW) void gemm_tn_f64_
   PLS_STAMP_AT(2);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wi = (wave / (BJ / WJ)) * WI, wj = (wave % (BJ / WJ)) * WJ;
+  if constexpr (Epilogue::kDirect) {
+    // interior tile: registers -> global without the LDS transpose (see epilogue_direct)
+    if (!edge && epi.direct_ld() < kDirectMaxLd) {
+      const int wu = __builtin_amdgcn_readfirstlane(wave);
+      epi.template apply_direct<TI, TJ>(acc, i0 + (wu / (BJ / WJ)) * WI, j0 + (wu % (BJ / WJ)) * WJ, lane, split);
+      PLS_STAMP_AT(3);
+      return;
+    }
+  }
   epi.template apply<TI, TJ>(acc, i0 + wi, j0 + wj, lane, wave, g.I, g.J, tile_i, split, lds);
   PLS_STAMP_AT(3);
 }
@@ -476,12 +516,63 @@ __device__ __forceinline__ double load_row_constants(const double *vec, int64_t 
   return (iw + lane < I) ? vec[iw + lane] : 0.0;
 }
 
+// ---- direct epilogue (interior tiles, cheap per-element work) ----------------------------------------------------
+// The f64 MFMA and the vector ALU share an issue port: every VALU instruction of an epilogue waits behind a 64-cycle
+// MFMA of the co-resident workgroup, and takes its own cycles from the matrix pipe.  So the epilogues whose per-element
+// work is a few flops leave the registers directly in the MFMA layout: register r of block (ta, tb) holds rows
+// 16 ta + 4 r + (lane >> 4), column 16 tb + (lane & 15) -- one buffer_store_dwordx2 writes four 128-byte row segments.
+// Addressing costs no VALU: a buffer descriptor at the wave's corner, ONE lane offset register, and the row/column
+// block as a scalar offset.  fn(v, slot, tb) returns the value to store; slot = 4 ta + r indexes the 16 row groups.
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+
+template <int TI, int TJ, class Fn>
+__device__ __forceinline__ void epilogue_direct(const AccFrag<TI, TJ> &acc, double *wave_corner, int64_t ld, int lane,
+                                                Fn &&fn) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(wave_corner, 0, 0x7FFFFFF0, 0x00020000);
+  const int voff = (int)(((int64_t)(lane >> 4) * ld + (lane & 15)) * 8);
+  const int ld4 = (int)(ld * 32);  // bytes per 4 rows
+#pragma unroll
+  for (int ta = 0; ta < TI; ++ta)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int tb = 0; tb < TJ; ++tb) {
+        const double v = fn(acc.v[ta][tb][r], ta * 4 + r, tb, rs, voff, (ta * 4 + r) * ld4 + tb * 128);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, v), rs, voff, (ta * 4 + r) * ld4 + tb * 128, 0);
+      }
+#else
+  (void)acc, (void)wave_corner, (void)ld, (void)lane, (void)fn;
+#endif
+}
+
 struct EpiStore {  // C = alpha * acc + beta * C   (split-K: slab `split` of C, slabs `slab` doubles apart)
   static constexpr int kTag = 1;  // PLS_TAG_GEMM_STORE
+  static constexpr bool kDirect = true;
   double *C0;
   int64_t ldc;
   double alpha, beta;
   int64_t slab;
+  __device__ int64_t direct_ld() const { return ldc; }
+  template <int TI, int TJ>
+  __device__ void apply_direct(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int split) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double *corner = C0 + (int64_t)split * slab + iw * ldc + jw;
+    if (beta == 0.0 && alpha == 1.0) {  // (the usual case: no VALU instruction at all)
+      epilogue_direct<TI, TJ>(acc, corner, ldc, lane, [&](double v, int, int, __amdgpu_buffer_rsrc_t, int, int) { return v; });
+    } else if (beta == 0.0) {
+      epilogue_direct<TI, TJ>(acc, corner, ldc, lane,
+                              [&](double v, int, int, __amdgpu_buffer_rsrc_t, int, int) { return alpha * v; });
+    } else {
+      epilogue_direct<TI, TJ>(acc, corner, ldc, lane, [&](double v, int, int, __amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+        const double c = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0));
+        return alpha * v + beta * c;
+      });
+    }
+#else
+    (void)acc, (void)iw, (void)jw, (void)lane, (void)split;
+#endif
+  }
   template <int TI, int TJ>
   __device__ void apply(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int wave, int64_t I, int64_t J,
                         int, int split, double *lds) const {

@@ -82,6 +82,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 // G = d cost / d f (acc = F tile); rows of this launch are rows [row0, row0 + I) of y.
 struct EpiCostDeriv {
   static constexpr int kTag = PLS_TAG_GEMM_COST_DERIV;
+  static constexpr bool kDirect = false;
   double *G;
   int64_t ldg;
   const double *y;
@@ -98,10 +99,50 @@ struct EpiCostDeriv {
   }
 };
 
+// Gaussian cost with the identity link (gaussian.py:86-88): G = (acc - y_i) / sigma2, evaluated as
+// fma(acc, 1/sigma2, -y_i/sigma2) in every tile shape, so that the result does not depend on the launch geometry.  Interior tiles take the direct path.
+struct EpiGaussDeriv {
+  static constexpr int kTag = PLS_TAG_GEMM_COST_DERIV;
+  static constexpr bool kDirect = true;
+  double *G;
+  int64_t ldg;
+  const double *y;
+  double inv_noise;
+  __device__ int64_t direct_ld() const { return ldg; }
+  template <int TI, int TJ>
+  __device__ void apply(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int wave, int64_t I, int64_t J,
+                        int, int, double *lds) const {
+    const double yl = load_row_constants(y, iw, lane, I);
+    epilogue_row_pairs<TI, TJ, 1>(acc, iw, jw, lane, wave, I, J, lds, yl, 0.0,
+                               [&](int64_t i, int64_t j, double v0, bool hi, double v1, const RowConsts &rc) {
+                                 G[i * ldg + j] = fma(v0, inv_noise, -inv_noise * rc.k0_lo);
+                                 if (hi) G[(i + 4) * ldg + j] = fma(v1, inv_noise, -inv_noise * rc.k0_hi);
+                               });
+  }
+  template <int TI, int TJ>
+  __device__ void apply_direct(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // y of the 16 row groups this lane's registers belong to: rows iw + 4 s + (lane >> 4), s = 0..4 TI - 1
+    const __amdgpu_buffer_rsrc_t ys =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(y + iw), 0, 0x7FFFFFF0, 0x00020000);
+    const int yoff = (lane >> 4) * 8;
+    double yv[4 * TI];  // -y_i / sigma2: one fma per element, v / sigma2 - y_i / sigma2 (abs. error <= ulp(y / sigma2))
+#pragma unroll
+    for (int s = 0; s < 4 * TI; ++s)
+      yv[s] = -inv_noise * __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(ys, yoff, s * 32, 0));
+    epilogue_direct<TI, TJ>(acc, G + iw * ldg + jw, ldg, lane,
+                            [&](double v, int slot, int, __amdgpu_buffer_rsrc_t, int, int) { return fma(v, inv_noise, yv[slot]); });
+#else
+    (void)acc, (void)iw, (void)jw, (void)lane;
+#endif
+  }
+};
+
 // partial[tile_i][j] = sum over the tile's rows of cost(y_i, acc_ij); deterministic order.
 template <int BI, int BJ, int WI, int WJ>
 struct EpiCostValue {
   static constexpr int kTag = PLS_TAG_GEMM_COST_VALUE;
+  static constexpr bool kDirect = false;
   double *partial;
   int64_t ldp;
   const double *y;
@@ -139,6 +180,7 @@ struct EpiCostValue {
 template <int BI, int BJ, int WI, int WJ>
 struct EpiGaussianQuad {
   static constexpr int kTag = PLS_TAG_GEMM_COST_VALUE;
+  static constexpr bool kDirect = false;
   double *partial;
   int64_t ldp;
   const double *U;
@@ -213,6 +255,7 @@ static NoiseP make_noisep(const pls_noise_desc *n) {
 // Gaussian/identity fast path: acc = (B U)_ij;  out = [U +] -eta*(acc - c_i)/sigma2 - eta*U_ij/lam_i + sqrt(2 eta)*xi_ij
 struct EpiLangevinGaussian {
   static constexpr int kTag = PLS_TAG_GEMM_LANGEVIN_GAUSSIAN;
+  static constexpr bool kDirect = false;
   double *out;
   int64_t ldo;
   const double *U;
@@ -865,8 +908,14 @@ static int stream_drift(const double *Lf, int64_t ldlf, const double *Lb, int64_
   *slabs_used = nslab;
   for (int64_t r0 = 0, c = 0; r0 < n; r0 += n_chunk, ++c) {
     const int64_t rows = (n - r0 < n_chunk) ? (n - r0) : n_chunk;
-    EpiCostDeriv e1{Gbuf, j, y + r0, cp};
-    int rc = launch_gemm(Lf + r0, ldlf, V, ldv, rows, j, kdim, e1, st);
+    int rc;
+    if (cp.cost == PLS_COST_GAUSSIAN && cp.link == PLS_LINK_IDENTITY) {
+      EpiGaussDeriv e1{Gbuf, j, y + r0, 1.0 / cp.p0};
+      rc = launch_gemm(Lf + r0, ldlf, V, ldv, rows, j, kdim, e1, st);
+    } else {
+      EpiCostDeriv e1{Gbuf, j, y + r0, cp};
+      rc = launch_gemm(Lf + r0, ldlf, V, ldv, rows, j, kdim, e1, st);
+    }
     if (rc) return rc;
     // slab s accumulates rows [s * kchunk, (s + 1) * kchunk) of every chunk; the first chunk has the planned row count,
     // so it writes (beta = 0) every slab; a shorter last chunk simply leaves its missing slabs untouched
