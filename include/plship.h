@@ -151,7 +151,9 @@ typedef enum {
   PLS_TAG_GEMM_LANGEVIN_GAUSSIAN = 4,/* gemm_tn_f64, B U with the whole Langevin update in the epilogue */
   PLS_TAG_LANGEVIN_UPDATE = 5,
   PLS_TAG_KERNEL_GRAM = 6,
-  PLS_TAG_OTHER = 7
+  PLS_TAG_OTHER = 7,
+  PLS_TAG_SMALL_RANK_DRIFT = 8,      /* small_rank_kernel: F, d cost / d f and the back-projection in one pass (rank <= 128) */
+  PLS_TAG_SMALL_RANK_VALUE = 9       /* small_rank_kernel: F and the per-column cost sums in one pass */
 } pls_kernel_tag;
 int pls_timeline_begin(int32_t capacity);
 int pls_timeline_end(float *ms, int32_t *tags, int32_t capacity, int32_t *count);

@@ -141,7 +141,7 @@ def load() -> C.CDLL:
 
 
 TAG_NAMES = {1: "gemm_store", 2: "gemm_cost_deriv", 3: "gemm_cost_value", 4: "gemm_langevin_gaussian",
-             5: "langevin_update", 6: "kernel_gram", 7: "other"}
+             5: "langevin_update", 6: "kernel_gram", 7: "other", 8: "small_rank_drift", 9: "small_rank_value"}
 
 
 class Timeline:

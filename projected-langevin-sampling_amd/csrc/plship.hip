@@ -13,6 +13,7 @@
 #include "cost_device.h"
 #include "gemm_tn_f64.h"
 #include "philox.h"
+#include "small_rank.h"
 
 namespace plship {
 
@@ -411,22 +412,54 @@ static int launch_gemm_cost_value(const double *L, int64_t ldl, const double *R,
 // HBM-bound kernels
 // ---------------------------------------------------------------------------------------------------------------
 
-// k(x1, x2): one thread per output pair of columns; x1 row and the inverse lengthscales live in registers / LDS.
-// Writes are 16-B per lane, coalesced along n2 (the kernel is bound by the 8*n1*n2 bytes it writes).
-template <int D_MAX>
-__global__ __launch_bounds__(256) void kernel_gram_kernel(int kind, const double *__restrict__ x1, int64_t n1,
+// exp(x) for x <= 0 (the RBF exponent): n = rint(x log2 e), r = x - n ln 2 (two-piece ln 2), degree-13 Taylor polynomial
+// in Horner form (|r| <= 0.347: truncation 4e-18 relative), scaled by 2^n with v_ldexp (gradual underflow as libm).
+// Within 1 ulp of the correctly rounded value; about half the instructions of the library exp (no special-case
+// ladder, constants in scalar registers).
+__device__ __forceinline__ double exp_nonpos(double x) {
+  const double n = rint(x * 1.4426950408889634074);
+  double r = fma(n, -6.93147180369123816490e-01, x);
+  r = fma(n, -1.90821492927058770002e-10, r);
+  double p = 1.6059043836821613e-10;  // 1/13!
+  p = fma(p, r, 2.0876756987868098e-09);
+  p = fma(p, r, 2.5052108385441720e-08);
+  p = fma(p, r, 2.7557319223985893e-07);
+  p = fma(p, r, 2.7557319223985888e-06);
+  p = fma(p, r, 2.4801587301587302e-05);
+  p = fma(p, r, 1.9841269841269841e-04);
+  p = fma(p, r, 1.3888888888888889e-03);
+  p = fma(p, r, 8.3333333333333332e-03);
+  p = fma(p, r, 4.1666666666666664e-02);
+  p = fma(p, r, 1.6666666666666666e-01);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  const double v = ldexp(p, (int)n);
+  return (x < -745.2) ? 0.0 : v;
+}
+
+// k(x1, x2): a block covers GRAM_ROWS rows x 512 columns; a thread owns one PAIR of columns (its two x2 points stay in
+// registers, pre-scaled by 1/lengthscale) and walks down the rows, whose pre-scaled x1 points sit in LDS (broadcast
+// reads).  Writes are 16 B per lane, 4 KiB contiguous per row and block: the kernel is bound by the 8*n1*n2 bytes it
+// writes once the per-element work is ~35 fp64 instructions (D = 8).
+constexpr int GRAM_ROWS = 64;
+// D_MAX: the input dimension rounded up to a power of two; the padding coordinates are zero on both sides, so the
+// unrolled coordinate loops need no `k < d` test.
+template <int KIND, int D_MAX>
+__global__ __launch_bounds__(256) void kernel_gram_kernel(const double *__restrict__ x1, int64_t n1,
                                                            const double *__restrict__ x2, int64_t n2, int d,
                                                            const double *__restrict__ lengthscale, double outputscale,
                                                            double *__restrict__ out, int64_t ldout) {
   __shared__ double inv_ls[D_MAX];
-  __shared__ double a_s[8][D_MAX];  // 8 rows of x1 per block (pre-scaled)
+  __shared__ __attribute__((aligned(16))) double a_s[GRAM_ROWS][D_MAX];  // rows of x1 (pre-scaled, zero-padded)
   const int t = threadIdx.x;
-  const int64_t row0 = (int64_t)blockIdx.y * 8;
-  if (t < d) inv_ls[t] = (kind == PLS_KERNEL_RBF_ARD) ? 1.0 / lengthscale[t] : 1.0;
+  const int64_t row0 = (int64_t)blockIdx.y * GRAM_ROWS;
+  const int nrows = (int)((n1 - row0 < GRAM_ROWS) ? (n1 - row0) : GRAM_ROWS);
+  if (t < D_MAX) inv_ls[t] = (t < d) ? ((KIND == PLS_KERNEL_RBF_ARD) ? 1.0 / lengthscale[t] : 1.0) : 0.0;
   __syncthreads();
-  for (int e = t; e < 8 * d; e += 256) {
-    const int r = e / d, k = e % d;
-    a_s[r][k] = (row0 + r < n1) ? x1[(row0 + r) * d + k] * inv_ls[k] : 0.0;
+  for (int e = t; e < nrows * D_MAX; e += 256) {
+    const int r = e / D_MAX, k = e % D_MAX;
+    a_s[r][k] = (k < d) ? x1[(row0 + r) * d + k] * inv_ls[k] : 0.0;
   }
   __syncthreads();
   const int64_t col = ((int64_t)blockIdx.x * 256 + t) * 2;
@@ -439,31 +472,28 @@ __global__ __launch_bounds__(256) void kernel_gram_kernel(int kind, const double
     b1[k] = (k < d && two) ? x2[(col + 1) * d + k] * inv_ls[k] : 0.0;
   }
   const bool vec = two && ((ldout & 1) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
-#pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    if (row0 + r >= n1) break;
+  double *dst = out + row0 * ldout + col;
+#pragma unroll 2
+  for (int r = 0; r < nrows; ++r, dst += ldout) {
     double s0 = 0.0, s1 = 0.0;
-    if (kind == PLS_KERNEL_RBF_ARD) {
+    if (KIND == PLS_KERNEL_RBF_ARD) {
 #pragma unroll
       for (int k = 0; k < D_MAX; ++k) {
-        if (k < d) {
-          const double e0 = a_s[r][k] - b0[k], e1 = a_s[r][k] - b1[k];
-          s0 = fma(e0, e0, s0);
-          s1 = fma(e1, e1, s1);
-        }
+        const double a = a_s[r][k];
+        const double e0 = a - b0[k], e1 = a - b1[k];
+        s0 = fma(e0, e0, s0);
+        s1 = fma(e1, e1, s1);
       }
-      s0 = outputscale * exp(-0.5 * s0);
-      s1 = outputscale * exp(-0.5 * s1);
+      s0 = outputscale * exp_nonpos(-0.5 * s0);
+      s1 = outputscale * exp_nonpos(-0.5 * s1);
     } else {
 #pragma unroll
       for (int k = 0; k < D_MAX; ++k) {
-        if (k < d) {
-          s0 = fma(a_s[r][k], b0[k], s0);
-          s1 = fma(a_s[r][k], b1[k], s1);
-        }
+        const double a = a_s[r][k];
+        s0 = fma(a, b0[k], s0);
+        s1 = fma(a, b1[k], s1);
       }
     }
-    double *dst = out + (row0 + r) * ldout + col;
     if (vec) {
       *reinterpret_cast<double2_t *>(dst) = double2_t{s0, s1};
     } else {
@@ -471,6 +501,22 @@ __global__ __launch_bounds__(256) void kernel_gram_kernel(int kind, const double
       if (two) dst[1] = s1;
     }
   }
+}
+
+template <int KIND>
+static void launch_gram(dim3 grid, hipStream_t st, const double *x1, int64_t rows, const double *x2, int64_t n2, int d,
+                        const double *lengthscale, double outputscale, double *out, int64_t ldout) {
+#define PLS_GRAM_CASE(DM)                                                                                         \
+  hipLaunchKernelGGL((kernel_gram_kernel<KIND, DM>), grid, dim3(256), 0, st, x1, rows, x2, n2, d, lengthscale, \
+                     outputscale, out, ldout)
+  if (d <= 1) PLS_GRAM_CASE(1);
+  else if (d <= 2) PLS_GRAM_CASE(2);
+  else if (d <= 4) PLS_GRAM_CASE(4);
+  else if (d <= 8) PLS_GRAM_CASE(8);
+  else if (d <= 16) PLS_GRAM_CASE(16);
+  else if (d <= 32) PLS_GRAM_CASE(32);
+  else PLS_GRAM_CASE(64);
+#undef PLS_GRAM_CASE
 }
 
 // elementwise cost derivative (un-fused entry point)
@@ -890,6 +936,55 @@ static int validate_noise(const pls_noise_desc *n, int64_t rows) {
   return PLS_OK;
 }
 
+// ---- small projection ranks: fused kernels (small_rank.h) -------------------------------------------------------
+static bool small_rank_ok(const double *Lb, int64_t ldlb, int64_t kdim) {
+  return kdim >= 1 && kdim <= 128 && (ldlb & 1) == 0 && (reinterpret_cast<uintptr_t>(Lb) & 15) == 0;
+}
+
+template <int MODE, int COST, int LINK>
+static int launch_small_rank_cl(const SmallRankP &p, int64_t nsplit, hipStream_t st) {
+  const int kb = (int)cdiv(p.K, 16);
+  dim3 grid((unsigned)cdiv(p.J, 64), (unsigned)nsplit);
+  LaunchScope scope(MODE == SR_MODE_DRIFT ? PLS_TAG_SMALL_RANK_DRIFT : PLS_TAG_SMALL_RANK_VALUE, st);
+#define PLS_SR_CASE(KB)                                                                                               \
+  case KB: {                                                                                                          \
+    static bool attr_set = false;                                                                                     \
+    if (!attr_set) {                                                                                                  \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&small_rank_kernel<KB, MODE, COST, LINK>),    \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sr_lds_bytes<KB>());       \
+      if (e != hipSuccess) return fail(PLS_ERR_HIP, "small_rank: hipFuncSetAttribute: %s", hipGetErrorString(e));    \
+      attr_set = true;                                                                                                \
+    }                                                                                                                 \
+    hipLaunchKernelGGL((small_rank_kernel<KB, MODE, COST, LINK>), grid, dim3(256), sr_lds_bytes<KB>(), st, p);       \
+  } break;
+  switch (kb) {
+    PLS_SR_CASE(1)
+    PLS_SR_CASE(2)
+    PLS_SR_CASE(3)
+    PLS_SR_CASE(4)
+    PLS_SR_CASE(5)
+    PLS_SR_CASE(6)
+    PLS_SR_CASE(7)
+    PLS_SR_CASE(8)
+    default: return fail(PLS_ERR_INVALID_ARGUMENT, "small_rank: rank %d > 128", p.K);
+  }
+#undef PLS_SR_CASE
+  return check_launch("small_rank");
+}
+
+// the cost/link pairs the reference's experiments use get their own instantiation; anything else the run-time switch
+template <int MODE>
+static int launch_small_rank(const SmallRankP &p, int64_t nsplit, hipStream_t st) {
+  const int c = p.cp.cost, l = p.cp.link;
+  if (c == PLS_COST_GAUSSIAN && l == PLS_LINK_IDENTITY) return launch_small_rank_cl<MODE, PLS_COST_GAUSSIAN, PLS_LINK_IDENTITY>(p, nsplit, st);
+  if (c == PLS_COST_POISSON && l == PLS_LINK_SQUARE) return launch_small_rank_cl<MODE, PLS_COST_POISSON, PLS_LINK_SQUARE>(p, nsplit, st);
+  if (c == PLS_COST_BERNOULLI && l == PLS_LINK_SIGMOID) return launch_small_rank_cl<MODE, PLS_COST_BERNOULLI, PLS_LINK_SIGMOID>(p, nsplit, st);
+  if (c == PLS_COST_BERNOULLI && l == PLS_LINK_PROBIT) return launch_small_rank_cl<MODE, PLS_COST_BERNOULLI, PLS_LINK_PROBIT>(p, nsplit, st);
+  if (c == PLS_COST_STUDENT_T && l == PLS_LINK_IDENTITY) return launch_small_rank_cl<MODE, PLS_COST_STUDENT_T, PLS_LINK_IDENTITY>(p, nsplit, st);
+  if (c == PLS_COST_MULTIMODAL && l == PLS_LINK_IDENTITY) return launch_small_rank_cl<MODE, PLS_COST_MULTIMODAL, PLS_LINK_IDENTITY>(p, nsplit, st);
+  return launch_small_rank_cl<MODE, -1, -1>(p, nsplit, st);
+}
+
 // Streams N in chunks:  G_c = cost'(Lf[:, chunk]^T V)  ->  D (+)= Lb[chunk, :]^T G_c.
 //   Lf (K x N, ldlf): forward operand (A or Kzx), V (K x J) particles in the basis the forward map expects
 //   Lb (N x K, ldlb): back-projection operand (At or Kxz)
@@ -898,6 +993,15 @@ static int stream_drift(const double *Lf, int64_t ldlf, const double *Lb, int64_
                         const double *V, int64_t ldv, int64_t j, const CostP &cp, const double *y, double *D,
                         int64_t ldd, int64_t max_slabs, int64_t slab_stride, int64_t *slabs_used, double *Gbuf,
                         int64_t n_chunk, hipStream_t st) {
+  if (small_rank_ok(Lb, ldlb, kdim)) {  // few basis functions: G stays in registers (small_rank.h)
+    int64_t rows_per_split = 0;
+    const int64_t ns = small_rank_splits(j, n, &rows_per_split);
+    if (ns <= max_slabs) {
+      SmallRankP p{Lb, ldlb, V, ldv, y, n, j, (int)kdim, rows_per_split, D, ldd, slab_stride, cp};
+      *slabs_used = ns;
+      return launch_small_rank<SR_MODE_DRIFT>(p, ns, st);
+    }
+  }
   // one split-K plan for every chunk (slab s accumulates over the chunks; the update kernel sums the slabs)
   int64_t kchunk = 0;
   int64_t nslab = plan_split_k(kdim, j, n < n_chunk ? n : n_chunk, &kchunk);
@@ -927,10 +1031,22 @@ static int stream_drift(const double *Lf, int64_t ldlf, const double *Lb, int64_
 }
 
 // c_j partials over N chunks -> cost_out[j] (deterministic)
-static int stream_cost(const double *Lf, int64_t ldlf, int64_t kdim, int64_t n, const double *V, int64_t ldv,
-                       int64_t j, const CostP &cp, const double *y, double *partial, int64_t n_chunk, double *e_out,
-                       int prior_kind, const double *P, int64_t ldp, int64_t m, const double *lam, double scale,
-                       hipStream_t st) {
+static int stream_cost(const double *Lf, int64_t ldlf, const double *Lb, int64_t ldlb, int64_t kdim, int64_t n,
+                       const double *V, int64_t ldv, int64_t j, const CostP &cp, const double *y, double *partial,
+                       int64_t partial_rows, int64_t n_chunk, double *e_out, int prior_kind, const double *P, int64_t ldp,
+                       int64_t m, const double *lam, double scale, hipStream_t st) {
+  if (Lb && small_rank_ok(Lb, ldlb, kdim)) {  // few basis functions: one fused pass, F never written
+    int64_t rows_per_split = 0;
+    const int64_t ns = small_rank_splits(j, n, &rows_per_split);
+    if (ns <= partial_rows) {
+      SmallRankP p{Lb, ldlb, V, ldv, y, n, j, (int)kdim, rows_per_split, partial, j, j, cp};
+      int rc = launch_small_rank<SR_MODE_VALUE>(p, ns, st);
+      if (rc) return rc;
+      hipLaunchKernelGGL(column_reduce_kernel, dim3((unsigned)cdiv(j, 256)), dim3(256), 0, st, partial, j, ns, j, e_out, 0,
+                         prior_kind, P, ldp, m, lam, scale, 1.0, (const double *)nullptr);
+      return check_launch("column_reduce");
+    }
+  }
   int64_t nchunks = cdiv(n, n_chunk);
   for (int64_t r0 = 0, c = 0; r0 < n; r0 += n_chunk, ++c) {
     const int64_t rows = (n - r0 < n_chunk) ? (n - r0) : n_chunk;
@@ -1017,20 +1133,15 @@ int pls_kernel_gram(int32_t kernel_kind, const double *x1, int64_t n1, const dou
   PLS_REQUIRE(kernel_kind != PLS_KERNEL_RBF_ARD || lengthscale, "kernel_gram: RBF needs lengthscale");
   if (n1 == 0 || n2 == 0) return PLS_OK;
   PLS_REQUIRE(cdiv(n2, 512) <= 0x7fffffff, "kernel_gram: n2 too large");
-  const int64_t max_rows = 65535LL * 8;  // gridDim.y <= 65535, 8 rows per block: taller Gram matrices go in row slabs
+  const int64_t max_rows = 65535LL * GRAM_ROWS;  // gridDim.y <= 65535: taller Gram matrices go in row slabs
   for (int64_t r0 = 0; r0 < n1; r0 += max_rows) {
     const int64_t rows = (n1 - r0 < max_rows) ? n1 - r0 : max_rows;
-    dim3 g2((unsigned)cdiv(n2, 512), (unsigned)cdiv(rows, 8));
+    dim3 g2((unsigned)cdiv(n2, 512), (unsigned)cdiv(rows, GRAM_ROWS));
     LaunchScope scope(PLS_TAG_KERNEL_GRAM, S(stream));
-    if (d <= 8)
-      hipLaunchKernelGGL(kernel_gram_kernel<8>, g2, dim3(256), 0, S(stream), kernel_kind, x1 + r0 * d, rows, x2, n2, (int)d,
-                         lengthscale, outputscale, out + r0 * ldout, ldout);
-    else if (d <= 16)
-      hipLaunchKernelGGL(kernel_gram_kernel<16>, g2, dim3(256), 0, S(stream), kernel_kind, x1 + r0 * d, rows, x2, n2, (int)d,
-                         lengthscale, outputscale, out + r0 * ldout, ldout);
+    if (kernel_kind == PLS_KERNEL_RBF_ARD)
+      launch_gram<PLS_KERNEL_RBF_ARD>(g2, S(stream), x1 + r0 * d, rows, x2, n2, (int)d, lengthscale, outputscale, out + r0 * ldout, ldout);
     else
-      hipLaunchKernelGGL(kernel_gram_kernel<64>, g2, dim3(256), 0, S(stream), kernel_kind, x1 + r0 * d, rows, x2, n2, (int)d,
-                         lengthscale, outputscale, out + r0 * ldout, ldout);
+      launch_gram<PLS_KERNEL_LINEAR>(g2, S(stream), x1 + r0 * d, rows, x2, n2, (int)d, lengthscale, outputscale, out + r0 * ldout, ldout);
     int rc = check_launch("kernel_gram");
     if (rc) return rc;
   }
@@ -1217,7 +1328,13 @@ static bool onb_fast_path(const pls_onb_desc *b, const pls_cost_desc *c, int for
 
 static int64_t onb_max_slabs(int64_t mk, int64_t j, int64_t n) {
   int64_t kc;
-  return plan_split_k(mk, j, n, &kc);
+  int64_t s = plan_split_k(mk, j, n, &kc);
+  if (mk <= 128) {  // the fused small-rank kernel cuts the rows into its own slabs
+    int64_t rows;
+    const int64_t sr = small_rank_splits(j, n, &rows);
+    if (sr > s) s = sr;
+  }
+  return s;
 }
 
 size_t pls_onb_step_workspace_bytes(const pls_onb_desc *basis, int64_t j, int64_t n_chunk) {
@@ -1330,8 +1447,9 @@ int pls_onb_energy(const pls_onb_desc *basis, const pls_cost_desc *cost, const d
   int64_t n_chunk = max_parts * 64;
   if (n_chunk > basis->n) n_chunk = basis->n;
   else n_chunk = n_chunk / 128 * 128;
-  return stream_cost(basis->A, basis->lda, basis->mk, basis->n, U, ldu, j, make_costp(cost), y,
-                     static_cast<double *>(workspace), n_chunk, e, 1, U, ldu, basis->mk, basis->lam, 0.0, S(stream));
+  return stream_cost(basis->A, basis->lda, basis->At, basis->ldat, basis->mk, basis->n, U, ldu, j, make_costp(cost), y,
+                     static_cast<double *>(workspace), max_parts, n_chunk, e, 1, U, ldu, basis->mk, basis->lam, 0.0,
+                     S(stream));
 }
 
 int pls_onb_prior_energy(const pls_onb_desc *basis, const double *U, int64_t ldu, int64_t j, const double *cost,
@@ -1488,8 +1606,8 @@ int pls_ipb_energy(const pls_ipb_desc *basis, const pls_cost_desc *cost, const d
   else n_chunk = n_chunk / 128 * 128;
   rc = pls_gemm_tn(basis->W, basis->ldw, U, ldu, V, j, basis->m, j, basis->m, 1.0, 0.0, stream);
   if (rc) return rc;
-  return stream_cost(basis->Kzx, basis->ldkzx, basis->m, basis->n, V, j, j, make_costp(cost), y, partial, n_chunk, e, 2, V,
-                     j, basis->m, nullptr, 0.5 * (double)basis->m, S(stream));
+  return stream_cost(basis->Kzx, basis->ldkzx, basis->Kxz, basis->ldkxz, basis->m, basis->n, V, j, j, make_costp(cost), y,
+                     partial, max_parts, n_chunk, e, 2, V, j, basis->m, nullptr, 0.5 * (double)basis->m, S(stream));
 }
 
 int pls_ipb_prior_energy(const pls_ipb_desc *basis, const double *U, int64_t ldu, int64_t j, const double *cost,
