@@ -140,6 +140,14 @@ typedef struct {
 const char *pls_last_error(void);
 int pls_abi_version(void);
 
+/* Process-wide tuning options (the defaults are what bench.py measures; tests flip them to reach both code paths).
+ *   PLS_OPT_SMALL_RANK_MAX: bases with at most this many functions (0..128, default 128) take the fused small-rank
+ *   kernels (F, d cost / d f and the back-projection in ONE pass: the N x J matrices F and G are never written);
+ *   larger ranks, or 0, take the two-GEMM path.  Results agree to rounding, not bit for bit. */
+typedef enum pls_option { PLS_OPT_SMALL_RANK_MAX = 1 } pls_option;
+int pls_set_option(int32_t option, int64_t value);
+int64_t pls_get_option(int32_t option); /* -1 for an unknown option */
+
 /* Per-launch timeline (measurement only; off by default, zero cost when off).  Between begin and end, every
  * kernel the calling thread launches through this library is bracketed by two HIP events recorded on the
  * launch's own stream.  pls_timeline_end synchronises on them and returns, per launch, its duration in

@@ -84,6 +84,8 @@ _CD, _ND, _OD, _ID = C.POINTER(CostDesc), C.POINTER(NoiseDesc), C.POINTER(OnbDes
 SIGNATURES = {
     "pls_last_error": (C.c_char_p, []),
     "pls_abi_version": (C.c_int, []),
+    "pls_set_option": (C.c_int, [_I32, _I64]),
+    "pls_get_option": (C.c_int64, [_I32]),
     "pls_timeline_begin": (C.c_int, [_I32]),
     "pls_timeline_end": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_int32), _I32, C.POINTER(C.c_int32)]),
     "pls_kernel_gram": (C.c_int, [_I32, _P, _I64, _P, _I64, _I64, _P, _D, _P, _I64, _P]),
@@ -140,6 +142,7 @@ def load() -> C.CDLL:
     return lib
 
 
+OPT_SMALL_RANK_MAX = 1
 TAG_NAMES = {1: "gemm_store", 2: "gemm_cost_deriv", 3: "gemm_cost_value", 4: "gemm_langevin_gaussian",
              5: "langevin_update", 6: "kernel_gram", 7: "other", 8: "small_rank_drift", 9: "small_rank_value"}
 

@@ -71,6 +71,40 @@ class OrthonormalBasis(PLSBasis):
         self._c = None
         self._gauss_key = None
 
+    @classmethod
+    def from_projection(cls, projection: torch.Tensor, eigenvalues: torch.Tensor,
+                        poison_padding: bool = False) -> "OrthonormalBasis":
+        """A basis given directly by its projection A = V~^T k(Z,X) (M_k, N) and eigenvalues (M_k,): everything on the
+        per-step path works (forward, update, fused step, energy); prediction needs the kernel and is unavailable.
+        ``poison_padding`` fills the alignment padding of the device copies with NaN (tests: padding must never be
+        read as data)."""
+        a = L.require_gpu_tensor(projection, "projection")
+        lam = L.require_gpu_tensor(eigenvalues, "eigenvalues").contiguous()
+        mk, n = a.shape
+        assert lam.shape == (mk,), "one eigenvalue per row of the projection"
+        self = cls.__new__(cls)
+        PLSBasis.__init__(self, additional_predictive_noise_distribution=None)
+        self.kernel = None
+        self.x_induce = None
+        self.base_gram_induce = None
+        self.base_gram_induce_train = None
+        self.eigenvalues = lam
+        self.eigenvectors = None
+        self.scaled_eigenvectors = None
+        self._scaled_eigenvectors_lam = None
+        self._n = n
+        self._A = alloc_matrix(mk, n, a.device)
+        self._At = alloc_matrix(n, mk, a.device)
+        if poison_padding:
+            self._A._base.fill_(float("nan"))
+            self._At._base.fill_(float("nan"))
+        self._A.copy_(a)
+        self._At.copy_(a.T)
+        self._B = None
+        self._c = None
+        self._gauss_key = None
+        return self
+
     @property
     def approximation_dimension(self) -> int:
         return self.eigenvalues.shape[0]  # :70-76

@@ -2,6 +2,7 @@
 // Everything here enqueues work on the caller's stream; nothing allocates or synchronises.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -937,8 +938,10 @@ static int validate_noise(const pls_noise_desc *n, int64_t rows) {
 }
 
 // ---- small projection ranks: fused kernels (small_rank.h) -------------------------------------------------------
+static std::atomic<int64_t> g_small_rank_max{128};  // pls_set_option(PLS_OPT_SMALL_RANK_MAX)
+
 static bool small_rank_ok(const double *Lb, int64_t ldlb, int64_t kdim) {
-  return kdim >= 1 && kdim <= 128 && (ldlb & 1) == 0 && (reinterpret_cast<uintptr_t>(Lb) & 15) == 0;
+  return kdim >= 1 && kdim <= g_small_rank_max.load() && (ldlb & 1) == 0 && (reinterpret_cast<uintptr_t>(Lb) & 15) == 0;
 }
 
 template <int MODE, int COST, int LINK>
@@ -1082,6 +1085,23 @@ extern "C" {
 
 const char *pls_last_error(void) { return g_last_error.c_str(); }
 int pls_abi_version(void) { return PLSHIP_ABI_VERSION; }
+
+int pls_set_option(int32_t option, int64_t value) {
+  switch (option) {
+    case PLS_OPT_SMALL_RANK_MAX:
+      PLS_REQUIRE(value >= 0 && value <= 128, "set_option: small-rank limit %lld outside 0..128", (long long)value);
+      g_small_rank_max.store(value);
+      return PLS_OK;
+    default: return fail(PLS_ERR_INVALID_ARGUMENT, "set_option: unknown option %d", (int)option);
+  }
+}
+
+int64_t pls_get_option(int32_t option) {
+  switch (option) {
+    case PLS_OPT_SMALL_RANK_MAX: return g_small_rank_max.load();
+    default: return -1;
+  }
+}
 
 int pls_timeline_begin(int32_t capacity) {
   PLS_REQUIRE(capacity > 0 && capacity <= (1 << 20), "timeline_begin: capacity must be in (0, 2^20]");
@@ -1329,7 +1349,7 @@ static bool onb_fast_path(const pls_onb_desc *b, const pls_cost_desc *c, int for
 static int64_t onb_max_slabs(int64_t mk, int64_t j, int64_t n) {
   int64_t kc;
   int64_t s = plan_split_k(mk, j, n, &kc);
-  if (mk <= 128) {  // the fused small-rank kernel cuts the rows into its own slabs
+  if (mk <= 128) {  // the fused small-rank kernel cuts the rows into its own slabs (sized independently of the option)
     int64_t rows;
     const int64_t sr = small_rank_splits(j, n, &rows);
     if (sr > s) s = sr;

@@ -322,8 +322,21 @@ def step_tolerance(ob, oc, u, eta, noise, want, solve_cond=1.0):
 SHAPES = [(512, 32, 64, 3), (100, 10, 64, 1), (1000, 40, 3, 5), (333, 17, 1, 2), (2100, 130, 260, 4)]
 
 
+@pytest.fixture(params=["small_rank", "two_gemm"])
+def rank_path(request, P):
+    """Bases with <= 128 functions take the fused small-rank kernels by default; `two_gemm` switches them off so the
+    same cases also run through the GEMM + epilogue path (pls_set_option, include/plship.h)."""
+    lib = P.pkg._lib.load()
+    L = P.pkg._lib
+    prev = lib.pls_get_option(L.OPT_SMALL_RANK_MAX)
+    assert prev == 128
+    L.check(lib.pls_set_option(L.OPT_SMALL_RANK_MAX, 128 if request.param == "small_rank" else 0), "pls_set_option")
+    yield request.param
+    L.check(lib.pls_set_option(L.OPT_SMALL_RANK_MAX, prev), "pls_set_option")
+
+
 @pytest.mark.parametrize("n,m,j,d", SHAPES)
-def test_onb_step_all_costs(P, n, m, j, d):
+def test_onb_step_all_costs(P, rank_path, n, m, j, d):
     pr = make_problem(n, m, j, d, seed=n + m)
     ob, gb = build_onb(P, pr)
     mk = ob.approximation_dimension
@@ -363,7 +376,7 @@ def test_onb_step_all_costs(P, n, m, j, d):
             assert gb._B is not None
 
 
-def test_onb_step_chunked_and_split_k(P):
+def test_onb_step_chunked_and_split_k(P, rank_path):
     """N streamed in several chunks (small workspace) with the back-projection split over K into slabs; the last
     chunk is shorter than a slab.  Same numbers as the one-chunk run and as the oracle."""
     pr = make_problem(5000, 40, 64, 3, seed=77)
@@ -390,8 +403,44 @@ def test_onb_step_chunked_and_split_k(P):
         assert relerr(e_many, e_one) < 1e-12, name
 
 
+@pytest.mark.parametrize("mk", [1, 7, 16, 17, 33, 48, 50, 64, 65, 89, 96, 100, 113, 128])
+def test_small_rank_kernels_agree_with_the_two_gemm_path(P, mk):
+    """The fused small-rank kernels (rank <= 128: drift and energy in one pass each) against the GEMM + epilogue path
+    on the same device buffers, for every register-blocking variant (ceil(rank/16) = 1..8), ragged N (not a multiple
+    of the 32-row tile, several row slabs) and ragged J (not a multiple of 64), all five costs.  The projection here
+    is a random matrix (the kernels do not care where A came from); NaN-poisoned padding must not leak."""
+    lib = P.pkg._lib.load()
+    L = P.pkg._lib
+    gen = torch.Generator().manual_seed(1000 + mk)
+    n, j = 2100 + mk, 130 + (mk % 5)
+    a = torch.randn(mk, n, generator=gen, dtype=torch.float64) / mk ** 0.5
+    lam = torch.rand(mk, generator=gen, dtype=torch.float64) + 0.5
+    u = torch.randn(mk, j, generator=gen, dtype=torch.float64)
+    fstar = a.T @ u[:, 0]
+    basis = P.basis.OrthonormalBasis.from_projection(cu(a), cu(lam), poison_padding=True)
+    xi = torch.randn(mk, j, generator=gen, dtype=torch.float64)
+    for name, oc, gc in make_costs(P, fstar + 0.1 * torch.randn(n, generator=gen, dtype=torch.float64), fstar, gen):
+        outs = {}
+        for mode, limit in (("fused", 128), ("gemm", 0)):
+            L.check(lib.pls_set_option(L.OPT_SMALL_RANK_MAX, limit), "pls_set_option")
+            try:
+                step = basis.fused_step(gc, cu(u), 1e-3, noise=P.basis.NoiseSpec(injected=cu(xi)), force_generic=True)
+                en = basis.fused_particle_energy(gc, cu(u), force_generic=True)
+            finally:
+                L.check(lib.pls_set_option(L.OPT_SMALL_RANK_MAX, 128), "pls_set_option")
+            outs[mode] = (step, en)
+        assert torch.isfinite(outs["fused"][0]).all() and torch.isfinite(outs["fused"][1]).all(), name
+        # conditioning floor: the two paths sum F in different orders; 1/f costs amplify that (see step_tolerance)
+        f = a.T @ u
+        tol = 1e-11 if name.startswith(("gaussian", "student")) else 1e-9
+        if name.startswith("poisson"):
+            tol = max(tol, 1e-13 / f.abs().min().item())
+        assert relerr(outs["fused"][0], outs["gemm"][0]) < tol, f"step {name} mk={mk}"
+        assert relerr(outs["fused"][1], outs["gemm"][1]) < tol, f"energy {name} mk={mk}"
+
+
 @pytest.mark.parametrize("n,m,j,d", [(512, 24, 64, 3), (100, 10, 7, 1), (700, 33, 130, 2)])
-def test_ipb_step_all_costs(P, n, m, j, d):
+def test_ipb_step_all_costs(P, rank_path, n, m, j, d):
     pr = make_problem(n, m, j, d, seed=7 * n + m)
     pr["ls"] = pr["ls"] * 0.35  # keeps cond(k(Z,Z)) small enough for 1e-9 parity of the solves
     ob, gb = build_ipb(P, pr)
@@ -571,7 +620,7 @@ def test_noise_is_reproducible_under_set_seed_and_fresh_per_step(P):
 # 5. J-sharding: a rank's shard evolves exactly like the same columns of the full run
 # ------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("cost_name", ["gaussian/identity", "poisson/square"])
-def test_j_shard_invariance(P, cost_name):
+def test_j_shard_invariance(P, rank_path, cost_name):
     pr = make_problem(400, 20, 96, 3, seed=21)
     ob, gb = build_onb(P, pr)
     mk = ob.approximation_dimension
@@ -856,7 +905,7 @@ def test_conformalise_vs_oracle(P):
 # 10. the launch functions neither allocate nor synchronise: a step can be captured into a hipGraph and replayed
 # ------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("force_generic", [False, True])
-def test_step_is_hipgraph_capturable(P, force_generic):
+def test_step_is_hipgraph_capturable(P, rank_path, force_generic):
     pr = make_problem(600, 24, 128, 3, seed=61)
     ob, gb = build_onb(P, pr)
     mk = ob.approximation_dimension
