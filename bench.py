@@ -260,8 +260,10 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = args.steps / dt
     log(f"like-for-like path: {ms_per_step:.2f} ms/step")
-    gemm_ms = sum(tl[k]["total_ms"] for k in ("gemm_cost_deriv", "gemm_store") if k in tl)
-    gemm_launches = sum(tl[k]["launches"] for k in ("gemm_cost_deriv", "gemm_store") if k in tl)
+    # dominant kernels of the step: the two GEMM launches, or (rank <= 128) the one fused small-rank launch
+    dom = ("small_rank_drift",) if "small_rank_drift" in tl else ("gemm_cost_deriv", "gemm_store")
+    gemm_ms = sum(tl[k]["total_ms"] for k in dom if k in tl)
+    gemm_launches = sum(tl[k]["launches"] for k in dom if k in tl)
     flop_per_step_rank = 4.0 * n * m * j_loc
     achieved = flop_per_step_rank * args.steps / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     traffic, traffic_src = None, None
@@ -270,12 +272,15 @@ def main():
         # HBM bytes per launch of the same two kernels on the same workload, from separate rocprofv3 --pmc passes
         # (FETCH_SIZE doubled, WRITE_SIZE as is: MI355X_MICROARCH.md "HBM"); see tools/profile_bench.sh
         pm = json.load(open(prof))
-        ks = [pm.get("gemm_tn_f64<128x128>::EpiCostDeriv", {}), pm.get("gemm_tn_f64<128x128>::EpiStore", {})]
+        ks = [pm.get("gemm_tn_f64<128x128>::EpiGaussDeriv", pm.get("gemm_tn_f64<128x128>::EpiCostDeriv", {})),
+              pm.get("gemm_tn_f64<128x128>::EpiStore", {})]
         if all("hbm_bytes_per_launch" in k for k in ks):
             traffic = sum(k["hbm_bytes_per_launch"] for k in ks) / len(ks)
             traffic_src = "profiles/r01_pmc_summary.json"
     roofline = {
-        "kernel": "gemm_tn_f64_kernel<128,128,64,64,16,*> (cost-derivative + back-projection launches of the step)",
+        "kernel": ("small_rank_kernel<KB,drift> (F, d cost/d f and back-projection fused; N x J intermediates never written)"
+                   if dom[0] == "small_rank_drift" else
+                   "gemm_tn_f64_kernel<128,128,64,64,16,*> (cost-derivative + back-projection launches of the step)"),
         "bound": "mfma",
         "achieved": achieved,
         "peak": FP64_MFMA_PEAK_TFLOPS,
@@ -284,7 +289,8 @@ def main():
         "traffic": traffic,
         "traffic_unit": "bytes per launch (fabric-side L2 misses incl. Infinity-Cache hits)",
         "traffic_source": traffic_src,
-        "algorithmic_bytes_per_launch": 8.0 * (n * m + m * j_loc + 2 * n * j_loc) / 2.0,
+        "algorithmic_bytes_per_launch": (8.0 * (n * m + 2 * m * j_loc) if dom[0] == "small_rank_drift"
+                                         else 8.0 * (n * m + m * j_loc + 2 * n * j_loc) / 2.0),
         "flop_per_launch": flop_per_step_rank / max(gemm_launches / args.steps, 1),
         "avg_launch_ms": gemm_ms / max(gemm_launches, 1),
         "launches_per_step": gemm_launches / args.steps,

@@ -373,6 +373,8 @@ constexpr int64_t kDirectMaxLd = (int64_t)1 << 21;
 template <int BI, int BJ, int WI, int WJ, int BK, int MINW, class Epilogue>
 __global__ __launch_bounds__((BI / WI) * (BJ / WJ) * 64, MINW) void gemm_tn_f64_kernel(GemmShape g, Epilogue epi) {
   constexpr int TI = WI / 16, TJ = WJ / 16;
+  static_assert((BI / WI) * (BJ / WJ) * 2 * 16 * (WJ + 2) <= 2 * BK * ((BI + 16) + (BJ + 16)),
+                "the epilogue slabs reuse the operand tiles' LDS");
   extern __shared__ __attribute__((aligned(16))) double lds[];
 
   int tile_i, tile_j;
@@ -439,24 +441,41 @@ __global__ __launch_bounds__((BI / WI) * (BJ / WJ) * 64, MINW) void gemm_tn_f64_
 constexpr int EPI_PAD = 2;  // doubles; keeps the 4 rows a ds_write_b64 touches on different banks
 
 template <int WJ>
-constexpr int epi_lds_doubles_per_wave() { return 16 * (WJ + EPI_PAD); }
+constexpr int epi_lds_doubles_per_wave() { return 2 * 16 * (WJ + EPI_PAD); }  // accumulator slab + companion slab
 
 struct RowConsts {
   double k0_lo, k0_hi, k1_lo, k1_hi;
+  double x_lo, x_hi;  // companion matrix X at (i_lo, j) and (i_lo + 4, j) (0 when X is not staged)
 };
 
-template <int TI, int TJ, int NCONST = 2, class Fn>
+// X / ldx (optional): a companion matrix addressed like the output (the particles U of the Langevin and energy
+// epilogues).  Its 16 x WJ slab is fetched with 16 row-wise coalesced loads that are ALL in flight together, one slab
+// ahead of its use, and handed to the row loop through LDS -- a load inside the row loop would expose the full memory
+// latency once per iteration (measured: 23 us of the 283 us fast-path step).
+template <int TI, int TJ, int NCONST = 2, int UNROLL = 1, class Fn>
 __device__ __forceinline__ void epilogue_row_pairs(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int wave,
-                                                   int64_t I, int64_t J, double *lds, double k0, double k1, Fn &&fn) {
+                                                   int64_t I, int64_t J, double *lds, double k0, double k1, Fn &&fn,
+                                                   const double *X = nullptr, int64_t ldx = 0) {
   // NCONST: how many of the per-row constant registers (k0, k1) the functor uses (their cross-lane reads are skipped otherwise)
   constexpr int WJ = TJ * 16;
   constexpr int STRIDE = WJ + EPI_PAD;
   constexpr int RPI = 64 / WJ;  // row pairs handled per iteration by the 64 lanes (1 for WJ = 64, 2 for WJ = 32)
+  constexpr int NXL = 16 / RPI;  // companion loads per lane and slab (each covers RPI rows)
   static_assert(WJ == 64 || WJ == 32, "wave tile width");
   double *w = lds + wave * epi_lds_doubles_per_wave<WJ>();
+  double *wx = w + 16 * STRIDE;
   const int q = lane >> 4, c16 = lane & 15;
   const int col = lane % WJ, sub = lane / WJ;
   const int64_t j = jw + col;
+  double xr[NXL];
+  auto load_x = [&](int ta) {
+#pragma unroll
+    for (int k = 0; k < NXL; ++k) {
+      const int64_t i = iw + ta * 16 + k * RPI + sub;
+      xr[k] = (i < I && j < J) ? X[i * ldx + j] : 0.0;
+    }
+  };
+  if (X) load_x(0);
   // One copy of the per-element code: the slab loop and the row loop are run-time loops (`unroll 1`); only the
   // register -> LDS write needs compile-time accumulator indices, so it sits in a wave-uniform switch.  (Fully unrolled,
   // the cost/Box-Muller code was inlined 64 times -- ~0.5 MB of instructions per kernel, every epilogue an I-cache miss
@@ -486,15 +505,24 @@ __device__ __forceinline__ void epilogue_row_pairs(const AccFrag<TI, TJ> &acc, i
     // execute in issue order, so its reads see its own writes.  (A __syncthreads() would also wait vmcnt(0), i.e. for
     // the global stores of the previous slab to COMPLETE: with the write path loaded by the co-resident workgroup that
     // made the epilogue 165k cycles per tile instead of 14k -- measured with tools/stamp_probe.py.)
+    if (X) {
+#pragma unroll
+      for (int k = 0; k < NXL; ++k) wx[(k * RPI + sub) * STRIDE + col] = xr[k];
+      if (ta + 1 < TI) load_x(ta + 1);  // flies during this slab's row loop
+    }
     __builtin_amdgcn_wave_barrier();
-#pragma unroll 1
+#pragma unroll UNROLL
     for (int it = 0; it < 8 / RPI; ++it) {
       const int p = it * RPI + sub;           // pair index 0..7 inside the 16-row slab
       const int rr = (p >> 2) * 8 + (p & 3);  // rows rr and rr + 4
       const int64_t i_lo = iw + ta * 16 + rr;
       const double v_lo = w[rr * STRIDE + col], v_hi = w[(rr + 4) * STRIDE + col];
       const int lr = ta * 16 + rr;
-      RowConsts rc{0.0, 0.0, 0.0, 0.0};
+      RowConsts rc{0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      if (X) {
+        rc.x_lo = wx[rr * STRIDE + col];
+        rc.x_hi = wx[(rr + 4) * STRIDE + col];
+      }
       if constexpr (NCONST >= 1) {
         rc.k0_lo = __shfl(k0, lr);
         rc.k0_hi = __shfl(k0, lr + 4);

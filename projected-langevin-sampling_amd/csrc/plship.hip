@@ -197,14 +197,15 @@ struct EpiGaussianQuad {
     const double laml = load_row_constants(lam, iw, lane, I);
     const double hil = (iw + lane < I) ? 0.5 / laml : 0.0;  // 0.5 / lambda_i
     epilogue_row_pairs<TI, TJ>(acc, iw, jw, lane, wave, I, J, lds, cl, hil,
-                               [&](int64_t i, int64_t j, double v0, bool hi, double v1, const RowConsts &rc) {
-                                 const double u0 = U[i * ldu + j];
+                               [&](int64_t, int64_t, double v0, bool hi, double v1, const RowConsts &rc) {
+                                 const double u0 = rc.x_lo;
                                  s += pscale * u0 * (v0 - 2.0 * rc.k0_lo) + u0 * u0 * rc.k1_lo;
                                  if (hi) {
-                                   const double u1 = U[(i + 4) * ldu + j];
+                                   const double u1 = rc.x_hi;
                                    s += pscale * u1 * (v1 - 2.0 * rc.k0_hi) + u1 * u1 * rc.k1_hi;
                                  }
-                               });
+                               },
+                               U, ldu);
     if (WJ == 32) s += __shfl_xor(s, 32);
     constexpr int NWJ = BJ / WJ, NWI = BI / WI;
     const int wrow = wave / NWJ, wcol = wave % NWJ;
@@ -291,18 +292,19 @@ struct EpiLangevinGaussian {
             if (hi) z1 = nz.xi[(i + 4) * nz.ldxi + j];
           }
           {
-            const double u = U[i * ldu + j], ci = rc.k0_lo, il = rc.k1_lo;
+            const double u = rc.x_lo, ci = rc.k0_lo, il = rc.k1_lo;
             const double d = -eta * inv_noise * (v0 - ci) - eta * u * il + sq2eta * z0;
             out[i * ldo + j] = add_u ? u + d : d;
             es += pscale * u * (v0 - 2.0 * ci) + 0.5 * u * u * il;
           }
           if (hi) {
-            const double u = U[(i + 4) * ldu + j], ci = rc.k0_hi, il = rc.k1_hi;
+            const double u = rc.x_hi, ci = rc.k0_hi, il = rc.k1_hi;
             const double d = -eta * inv_noise * (v1 - ci) - eta * u * il + sq2eta * z1;
             out[(i + 4) * ldo + j] = add_u ? u + d : d;
             es += pscale * u * (v1 - 2.0 * ci) + 0.5 * u * u * il;
           }
-        });
+        },
+        U, ldu);
     if (epart) {  // wave-uniform; fixed-order cross-wave sum like EpiCostValue
       constexpr int WJ = TJ * 16;
       if (WJ == 32) es += __shfl_xor(es, 32);
