@@ -389,6 +389,18 @@ static int64_t plan_split_k(int64_t I, int64_t J, int64_t K, int64_t *kchunk) {
   const int64_t s_local = cdiv(K, 16384);
   if (s_local > s) s = s_local;
   if (s > 16) s = 16;
+  // wave quantisation: tiles * s workgroups run in rounds of 512 (2 per CU); a few more slabs can fill the last round
+  // (J = 2048: 128 tiles x 7 slabs = 1.75 rounds -> 87 % of the MFMA rate; x 8 = 2 rounds)
+  if (s > 1) {
+    auto waste = [&](int64_t sl) {
+      const double rounds = (double)(tiles * sl) / 512.0;
+      return std::ceil(rounds) / rounds;
+    };
+    int64_t best = s;
+    for (int64_t sl = s + 1; sl <= 16 && sl <= s + 4; ++sl)
+      if (waste(sl) < waste(best) - 0.03) best = sl;
+    s = best;
+  }
   while (s > 1 && K / s < 1024) --s;  // keep every slab's k-loop long enough to amortise its prologue / epilogue
   int64_t kc = cdiv(cdiv(K, s), 16) * 16;
   s = cdiv(K, kc);
