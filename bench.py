@@ -36,6 +36,8 @@ CONFIGS = {
                workload="configs[1]: synthetic regression N=1e5 M=1024 J=8192 D=8, RBF/ARD, ONB + Gaussian/identity, fp64"),
     "c3": dict(n=50_000, m=512, j=16384, d=1, cost="poisson", eta=1e-6, obs=None, threshold=1e-7,
                workload="configs[2]: Poisson (f^2 link) regression N=5e4 M=512 J=16384 D=1, ONB, fp64"),
+    "c1": dict(n=100, m=10, j=64, d=1, cost="gaussian", eta=1e-3, obs=0.25,
+               workload="configs[0]: 1D regression N=100 M=10 J=64, ONB + Gaussian/identity, fp64 (launch-bound)"),
     "small": dict(n=4096, m=128, j=512, d=4, cost="gaussian", eta=1e-4, obs=0.01,
                   workload="smoke-sized regression N=4096 M=128 J=512"),
 }
