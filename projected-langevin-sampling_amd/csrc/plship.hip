@@ -1443,7 +1443,8 @@ int pls_onb_step(const pls_onb_desc *basis, const pls_cost_desc *cost, const dou
 size_t pls_onb_energy_workspace_bytes(const pls_onb_desc *basis, int64_t j, int64_t n_chunk) {
   if (!basis || j <= 0) return 0;
   if (n_chunk <= 0 || n_chunk > basis->n) n_chunk = basis->n;
-  return (size_t)cdiv(n_chunk, 64) * j * sizeof(double);
+  const int64_t parts = cdiv(n_chunk, 64) < 2 ? 2 : cdiv(n_chunk, 64);  // (the chunk planner needs two partial rows)
+  return (size_t)parts * j * sizeof(double);
 }
 
 int pls_onb_energy(const pls_onb_desc *basis, const pls_cost_desc *cost, const double *y, const double *U, int64_t ldu,
@@ -1618,7 +1619,8 @@ int pls_ipb_step(const pls_ipb_desc *basis, const pls_cost_desc *cost, const dou
 size_t pls_ipb_energy_workspace_bytes(const pls_ipb_desc *basis, int64_t j, int64_t n_chunk) {
   if (!basis || j <= 0) return 0;
   if (n_chunk <= 0 || n_chunk > basis->n) n_chunk = basis->n;
-  return align_up((size_t)basis->m * j * sizeof(double), 256) + (size_t)cdiv(n_chunk, 64) * j * sizeof(double);
+  const int64_t parts = cdiv(n_chunk, 64) < 2 ? 2 : cdiv(n_chunk, 64);
+  return align_up((size_t)basis->m * j * sizeof(double), 256) + (size_t)parts * j * sizeof(double);
 }
 
 int pls_ipb_energy(const pls_ipb_desc *basis, const pls_cost_desc *cost, const double *y, const double *U, int64_t ldu,

@@ -439,6 +439,38 @@ def test_small_rank_kernels_agree_with_the_two_gemm_path(P, mk):
         assert relerr(outs["fused"][1], outs["gemm"][1]) < tol, f"energy {name} mk={mk}"
 
 
+def test_random_shape_sweep_against_the_oracle(P, rank_path):
+    """Seeded sweep over ragged (N, M, J, D): one Gaussian and one non-Gaussian step + energy per draw against the
+    oracle, through whichever path `rank_path` selects (M <= 128 throughout, so `small_rank` really is the fused
+    kernel and `two_gemm` the 64x64 / 128x128 GEMMs with their edge tiles)."""
+    rng = np.random.default_rng(20260101)
+    for draw in range(12):
+        n = int(rng.integers(1, 1500))
+        m = int(rng.integers(2, min(n, 128) + 1)) if n >= 2 else 1
+        j = int(rng.integers(1, 200))
+        d = int(rng.integers(1, 6))
+        if n < 2:
+            continue
+        pr = make_problem(n, m, j, d, seed=1000 + draw)
+        ob, gb = build_onb(P, pr, threshold=1e-8)
+        mk = ob.approximation_dimension
+        if mk == 0:
+            continue
+        u = pr["u"][:mk].contiguous()
+        xi = torch.randn(mk, j, generator=pr["gen"])
+        costs = make_costs(P, pr["y"], pr["fstar"], pr["gen"])
+        for name, oc, gc in (costs[0], costs[1 + draw % 5]):
+            want = O.PLS(ob, oc).calculate_particle_update(u.clone(), 1e-3, noise=xi)
+            tol = step_tolerance(ob, oc, u, 1e-3, xi, want)
+            if tol >= 1e-8:
+                continue
+            got = gb.fused_step(gc, cu(u), 1e-3, noise=P.basis.NoiseSpec(injected=cu(xi)), force_generic=True)
+            assert relerr(got, want) < tol, f"draw {draw} ({n},{m}->{mk},{j},{d}) {name}"
+            e_want = O.PLS(ob, oc).calculate_energy_potential(u.clone())
+            e_got = gb.fused_particle_energy(gc, cu(u), force_generic=True).mean().item()
+            assert abs(e_got - e_want) <= max(1e-9, tol) * abs(e_want), f"draw {draw} energy {name}"
+
+
 @pytest.mark.parametrize("n,m,j,d", [(512, 24, 64, 3), (100, 10, 7, 1), (700, 33, 130, 2)])
 def test_ipb_step_all_costs(P, rank_path, n, m, j, d):
     pr = make_problem(n, m, j, d, seed=7 * n + m)
