@@ -36,6 +36,10 @@ CONFIGS = {
                workload="configs[1]: synthetic regression N=1e5 M=1024 J=8192 D=8, RBF/ARD, ONB + Gaussian/identity, fp64"),
     "c3": dict(n=50_000, m=512, j=16384, d=1, cost="poisson", eta=1e-6, obs=None, threshold=1e-7,
                workload="configs[2]: Poisson (f^2 link) regression N=5e4 M=512 J=16384 D=1, ONB, fp64"),
+    "c4": dict(n=200_000, m=2048, j=8192, d=8, cost="bernoulli", eta=1e-6, obs=None,
+               workload="configs[3], one GPU's shard (J = 32768 / 4): binary classification N=2e5 M=2048 D=8, ONB + Bernoulli/sigmoid, fp64"),
+    "c5": dict(n=1_000_000, m=4096, j=8192, d=8, cost="gaussian", eta=1e-5, obs=0.01,
+               workload="configs[4], one GPU's shard (J = 65536 / 8): regression N=1e6 M=4096 D=8, ONB + Gaussian/identity, fp64"),
     "c1": dict(n=100, m=10, j=64, d=1, cost="gaussian", eta=1e-3, obs=0.25,
                workload="configs[0]: 1D regression N=100 M=10 J=64, ONB + Gaussian/identity, fp64 (launch-bound)"),
     "small": dict(n=4096, m=128, j=512, d=4, cost="gaussian", eta=1e-4, obs=0.01,
@@ -62,6 +66,8 @@ def make_data(cfg, seed=0):
     fstar = torch.sin(2.0 * (x @ w))
     if cfg["cost"] == "poisson":
         y = torch.poisson((2.0 * fstar) ** 2 + 0.1, generator=g)
+    elif cfg["cost"] == "bernoulli":  # labels ~ Bernoulli(sigmoid(f*)) as curves/curves.py:31-38
+        y = (torch.rand(n, generator=g, dtype=torch.float64) < torch.sigmoid(2.0 * fstar)).double()
     else:
         y = fstar + 0.1 * torch.randn(n, generator=g, dtype=torch.float64)
     ls = 0.5 + torch.rand(d, generator=torch.Generator().manual_seed(1), dtype=torch.float64)
@@ -113,6 +119,8 @@ def cpu_baseline(cfg, x, z, y, ls, lam_all, vec_all):
         ob.scaled_eigenvectors = vec_all / torch.sqrt(lam_all.shape[0] * lam_all)[None, :]
         if cfg["cost"] == "poisson":
             oc = O.PoissonCost(y, O.SquareLink())
+        elif cfg["cost"] == "bernoulli":
+            oc = O.BernoulliCost(y, O.SigmoidLink())
         else:
             oc = O.GaussianCost(cfg["obs"], y, O.IdentityLink())
         pls = O.PLS(ob, oc)
@@ -195,8 +203,14 @@ def main():
     basis = OrthonormalBasis(kernel, z, x, eigenvalue_threshold=cfg.get("threshold", 0.0), verbose=False, keep_gram=False)
     basis.workspace_bytes = int(args.workspace_gb * (1 << 30))
     mk = basis.approximation_dimension
-    cost = (PoissonCost(y, SquareLinkFunction()) if cfg["cost"] == "poisson"
-            else GaussianCost(cfg["obs"], y, IdentityLinkFunction()))
+    if cfg["cost"] == "poisson":
+        cost = PoissonCost(y, SquareLinkFunction())
+    elif cfg["cost"] == "bernoulli":
+        from projected_langevin_sampling_amd.costs import BernoulliCost
+        from projected_langevin_sampling_amd.link_functions import SigmoidLinkFunction
+        cost = BernoulliCost(y, SigmoidLinkFunction())
+    else:
+        cost = GaussianCost(cfg["obs"], y, IdentityLinkFunction())
     j_total = cfg["j"]
     shard_world = args.emulate_world if (args.emulate_world > 1 and world == 1) else world
     j0, j1 = D.attach_shard(basis, j_total, rank, shard_world)
