@@ -188,15 +188,16 @@ class OrthonormalBasis(PLSBasis):
         return True
 
     def supports_input_energy(self, cost) -> bool:
-        """True if fused_step can return the energy of its input particles for free (Gaussian/identity fast path)."""
-        cd = cost.desc()
-        return cd.cost == L.COST_GAUSSIAN and cd.link == L.LINK_IDENTITY
+        """True if fused_step can return the energy of its input particles as a by-product: every native cost.
+        Gaussian/identity: the quadratic form of the same B U product; otherwise the cost VALUE of the same F tile the
+        derivative is taken of (the reference recomputes F for the energy: projected_langevin_sampling.py:125-138)."""
+        return bool(cost.is_native())
 
     def fused_step(self, cost, particles: torch.Tensor, step_size: float, out: torch.Tensor | None = None,
                    new_state: bool = False, noise: NoiseSpec | None = None, force_generic: bool = False,
                    input_energy: torch.Tensor | None = None) -> torch.Tensor:
         """One whole Langevin step in libplship (pls_onb_step): returns dU, or U + dU when new_state.
-        ``input_energy`` (J,) receives the per-particle energy of ``particles`` as a by-product (fast path only)."""
+        ``input_energy`` (J,) receives the per-particle energy of ``particles`` as a by-product."""
         u = _rows_contiguous(L.require_gpu_tensor(particles, "particles"))
         j = u.shape[1]
         if out is None:

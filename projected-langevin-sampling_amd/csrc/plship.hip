@@ -82,6 +82,9 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 // ---------------------------------------------------------------------------------------------------------------
 
 // G = d cost / d f (acc = F tile); rows of this launch are rows [row0, row0 + I) of y.
+// vpart (optional): the cost VALUE of the same F as a by-product -- vpart[wave row][j] = sum over the 16*TI rows of the
+// wave's block of cost(y_i, F_ij) (wave row = iw / (16 TI); fixed order, no cross-wave traffic): the energy of the
+// step's INPUT particles without a third pass over A (projected_langevin_sampling.py:125-138 recomputes F for it).
 struct EpiCostDeriv {
   static constexpr int kTag = PLS_TAG_GEMM_COST_DERIV;
   static constexpr bool kDirect = false;
@@ -89,20 +92,39 @@ struct EpiCostDeriv {
   int64_t ldg;
   const double *y;
   CostP cp;
+  double *vpart;
+  int64_t ldp;
   template <int TI, int TJ>
   __device__ void apply(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int wave, int64_t I, int64_t J,
                         int, int, double *lds) const {
     const double yl = load_row_constants(y, iw, lane, I);
+    if (!vpart) {
+      epilogue_row_pairs<TI, TJ, 1>(acc, iw, jw, lane, wave, I, J, lds, yl, 0.0,
+                                 [&](int64_t i, int64_t j, double v0, bool hi, double v1, const RowConsts &rc) {
+                                   G[i * ldg + j] = cost_deriv(cp, rc.k0_lo, v0);
+                                   if (hi) G[(i + 4) * ldg + j] = cost_deriv(cp, rc.k0_hi, v1);
+                                 });
+      return;
+    }
+    double s = 0.0;
     epilogue_row_pairs<TI, TJ, 1>(acc, iw, jw, lane, wave, I, J, lds, yl, 0.0,
                                [&](int64_t i, int64_t j, double v0, bool hi, double v1, const RowConsts &rc) {
                                  G[i * ldg + j] = cost_deriv(cp, rc.k0_lo, v0);
-                                 if (hi) G[(i + 4) * ldg + j] = cost_deriv(cp, rc.k0_hi, v1);
+                                 s += cost_value(cp, rc.k0_lo, v0);
+                                 if (hi) {
+                                   G[(i + 4) * ldg + j] = cost_deriv(cp, rc.k0_hi, v1);
+                                   s += cost_value(cp, rc.k0_hi, v1);
+                                 }
                                });
+    constexpr int WJ = TJ * 16;
+    if (WJ == 32) s += __shfl_xor(s, 32);  // two lane halves share the 32 columns
+    if (iw < I && lane < WJ && jw + lane < J) vpart[(iw / (16 * TI)) * ldp + jw + lane] = s;
   }
 };
 
 // Gaussian cost with the identity link (gaussian.py:86-88): G = (acc - y_i) / sigma2, evaluated as
-// fma(acc, 1/sigma2, -y_i/sigma2) in every tile shape, so that the result does not depend on the launch geometry.  Interior tiles take the direct path.
+// fma(acc, 1/sigma2, -y_i/sigma2) in every tile shape, so that the result does not depend on the launch geometry.
+// Interior tiles take the direct path.  vpart as in EpiCostDeriv: cost = (acc - y)^2 / (2 sigma2) = G^2 * sigma2 / 2.
 struct EpiGaussDeriv {
   static constexpr int kTag = PLS_TAG_GEMM_COST_DERIV;
   static constexpr bool kDirect = true;
@@ -110,16 +132,30 @@ struct EpiGaussDeriv {
   int64_t ldg;
   const double *y;
   double inv_noise;
+  double *vpart;
+  int64_t ldp;
   __device__ int64_t direct_ld() const { return ldg; }
   template <int TI, int TJ>
   __device__ void apply(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int wave, int64_t I, int64_t J,
                         int, int, double *lds) const {
     const double yl = load_row_constants(y, iw, lane, I);
+    double s = 0.0;
     epilogue_row_pairs<TI, TJ, 1>(acc, iw, jw, lane, wave, I, J, lds, yl, 0.0,
                                [&](int64_t i, int64_t j, double v0, bool hi, double v1, const RowConsts &rc) {
-                                 G[i * ldg + j] = fma(v0, inv_noise, -inv_noise * rc.k0_lo);
-                                 if (hi) G[(i + 4) * ldg + j] = fma(v1, inv_noise, -inv_noise * rc.k0_hi);
+                                 const double g0 = fma(v0, inv_noise, -inv_noise * rc.k0_lo);
+                                 G[i * ldg + j] = g0;
+                                 s = fma(g0, g0, s);
+                                 if (hi) {
+                                   const double g1 = fma(v1, inv_noise, -inv_noise * rc.k0_hi);
+                                   G[(i + 4) * ldg + j] = g1;
+                                   s = fma(g1, g1, s);
+                                 }
                                });
+    if (vpart) {
+      constexpr int WJ = TJ * 16;
+      if (WJ == 32) s += __shfl_xor(s, 32);
+      if (iw < I && lane < WJ && jw + lane < J) vpart[(iw / (16 * TI)) * ldp + jw + lane] = s * (0.5 / inv_noise);
+    }
   }
   template <int TI, int TJ>
   __device__ void apply_direct(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int) const {
@@ -132,8 +168,27 @@ struct EpiGaussDeriv {
 #pragma unroll
     for (int s = 0; s < 4 * TI; ++s)
       yv[s] = -inv_noise * __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(ys, yoff, s * 32, 0));
-    epilogue_direct<TI, TJ>(acc, G + iw * ldg + jw, ldg, lane,
-                            [&](double v, int slot, int, __amdgpu_buffer_rsrc_t, int, int) { return fma(v, inv_noise, yv[slot]); });
+    if (!vpart) {
+      epilogue_direct<TI, TJ>(acc, G + iw * ldg + jw, ldg, lane,
+                              [&](double v, int slot, int, __amdgpu_buffer_rsrc_t, int, int) { return fma(v, inv_noise, yv[slot]); });
+      return;
+    }
+    double sq[TJ];  // per 16-column block: this lane's 4*TI rows of G^2
+#pragma unroll
+    for (int tb = 0; tb < TJ; ++tb) sq[tb] = 0.0;
+    epilogue_direct<TI, TJ>(acc, G + iw * ldg + jw, ldg, lane, [&](double v, int slot, int tb, __amdgpu_buffer_rsrc_t, int, int) {
+      const double g = fma(v, inv_noise, yv[slot]);
+      sq[tb] = fma(g, g, sq[tb]);
+      return g;
+    });
+    const double half_s2 = 0.5 / inv_noise;
+#pragma unroll
+    for (int tb = 0; tb < TJ; ++tb) {
+      double t = sq[tb];
+      t += __shfl_xor(t, 16);
+      t += __shfl_xor(t, 32);  // the four lane groups hold rows (lane >> 4) + 4 r of the same column
+      if (lane < 16) vpart[(iw / (16 * TI)) * ldp + jw + tb * 16 + lane] = t * half_s2;
+    }
 #else
     (void)acc, (void)iw, (void)jw, (void)lane;
 #endif
@@ -962,7 +1017,7 @@ template <int MODE, int COST, int LINK>
 static int launch_small_rank_cl(const SmallRankP &p, int64_t nsplit, hipStream_t st) {
   const int kb = (int)cdiv(p.K, 16);
   dim3 grid((unsigned)cdiv(p.J, 64), (unsigned)nsplit);
-  LaunchScope scope(MODE == SR_MODE_DRIFT ? PLS_TAG_SMALL_RANK_DRIFT : PLS_TAG_SMALL_RANK_VALUE, st);
+  LaunchScope scope(MODE == SR_MODE_VALUE ? PLS_TAG_SMALL_RANK_VALUE : PLS_TAG_SMALL_RANK_DRIFT, st);
 #define PLS_SR_CASE(KB)                                                                                               \
   case KB: {                                                                                                          \
     static bool attr_set = false;                                                                                     \
@@ -1006,17 +1061,38 @@ static int launch_small_rank(const SmallRankP &p, int64_t nsplit, hipStream_t st
 //   Lf (K x N, ldlf): forward operand (A or Kzx), V (K x J) particles in the basis the forward map expects
 //   Lb (N x K, ldlb): back-projection operand (At or Kxz)
 //   D  (K x J): receives the drift  Lb^T cost'(...)
+// Optional by-product of stream_drift: the energy of the particles the drift is evaluated at (cost value of the same F
+// plus the prior term), so that a training loop needs no separate energy pass.
+struct EnergySink {
+  double *partial = nullptr;  // [rows_cap][j] workspace for per-wave-row (or per-slab) cost partial sums
+  int64_t rows_cap = 0;
+  double *e = nullptr;  // (j,) receives cost_j + prior_j
+  int prior_kind = 0;
+  const double *P = nullptr;  // prior operand (U for the ONB, V = K^-1 U for the IPB)
+  int64_t ldp = 0, m = 0;
+  const double *lam = nullptr;
+  double scale = 0.0;
+};
+
 static int stream_drift(const double *Lf, int64_t ldlf, const double *Lb, int64_t ldlb, int64_t kdim, int64_t n,
                         const double *V, int64_t ldv, int64_t j, const CostP &cp, const double *y, double *D,
                         int64_t ldd, int64_t max_slabs, int64_t slab_stride, int64_t *slabs_used, double *Gbuf,
-                        int64_t n_chunk, hipStream_t st) {
+                        int64_t n_chunk, hipStream_t st, const EnergySink *es = nullptr) {
+  auto reduce_partials = [&](int64_t rows, int accumulate, bool last) {
+    hipLaunchKernelGGL(column_reduce_kernel, dim3((unsigned)cdiv(j, 256)), dim3(256), 0, st, es->partial, j, rows, j, es->e,
+                       accumulate, last ? es->prior_kind : 0, es->P, es->ldp, es->m, es->lam, es->scale, 1.0,
+                       (const double *)nullptr);
+    return check_launch("column_reduce");
+  };
   if (small_rank_ok(Lb, ldlb, kdim)) {  // few basis functions: G stays in registers (small_rank.h)
     int64_t rows_per_split = 0;
     const int64_t ns = small_rank_splits(j, n, &rows_per_split);
-    if (ns <= max_slabs) {
-      SmallRankP p{Lb, ldlb, V, ldv, y, n, j, (int)kdim, rows_per_split, D, ldd, slab_stride, cp};
+    if (ns <= max_slabs && (!es || ns <= es->rows_cap)) {
+      SmallRankP p{Lb, ldlb, V, ldv, y, n, j, (int)kdim, rows_per_split, D, ldd, slab_stride, cp, es ? es->partial : nullptr, j};
       *slabs_used = ns;
-      return launch_small_rank<SR_MODE_DRIFT>(p, ns, st);
+      int rc = es ? launch_small_rank<SR_MODE_DRIFT_VALUE>(p, ns, st) : launch_small_rank<SR_MODE_DRIFT>(p, ns, st);
+      if (rc || !es) return rc;
+      return reduce_partials(ns, 0, true);
     }
   }
   // one split-K plan for every chunk (slab s accumulates over the chunks; the update kernel sums the slabs)
@@ -1030,14 +1106,27 @@ static int stream_drift(const double *Lf, int64_t ldlf, const double *Lb, int64_
   for (int64_t r0 = 0, c = 0; r0 < n; r0 += n_chunk, ++c) {
     const int64_t rows = (n - r0 < n_chunk) ? (n - r0) : n_chunk;
     int rc;
+    // wave rows of the forward launch: 64 data rows each with the 128x128 tiles, 32 with the 64x64 ones
+    const int64_t wave_rows = cdiv(rows, use_big_tiles(rows, j, 1) ? 64 : 32);
+    double *vp = nullptr;
+    if (es) {
+      if (wave_rows > es->rows_cap)
+        return fail(PLS_ERR_WORKSPACE_TOO_SMALL, "step energy by-product: %lld partial rows > %lld", (long long)wave_rows,
+                    (long long)es->rows_cap);
+      vp = es->partial;
+    }
     if (cp.cost == PLS_COST_GAUSSIAN && cp.link == PLS_LINK_IDENTITY) {
-      EpiGaussDeriv e1{Gbuf, j, y + r0, 1.0 / cp.p0};
+      EpiGaussDeriv e1{Gbuf, j, y + r0, 1.0 / cp.p0, vp, j};
       rc = launch_gemm(Lf + r0, ldlf, V, ldv, rows, j, kdim, e1, st);
     } else {
-      EpiCostDeriv e1{Gbuf, j, y + r0, cp};
+      EpiCostDeriv e1{Gbuf, j, y + r0, cp, vp, j};
       rc = launch_gemm(Lf + r0, ldlf, V, ldv, rows, j, kdim, e1, st);
     }
     if (rc) return rc;
+    if (es) {
+      rc = reduce_partials(wave_rows, c == 0 ? 0 : 1, r0 + n_chunk >= n);
+      if (rc) return rc;
+    }
     // slab s accumulates rows [s * kchunk, (s + 1) * kchunk) of every chunk; the first chunk has the planned row count,
     // so it writes (beta = 0) every slab; a shorter last chunk simply leaves its missing slabs untouched
     EpiStore e2{D, ldd, 1.0, c == 0 ? 0.0 : 1.0, slab_stride};
@@ -1056,7 +1145,7 @@ static int stream_cost(const double *Lf, int64_t ldlf, const double *Lb, int64_t
     int64_t rows_per_split = 0;
     const int64_t ns = small_rank_splits(j, n, &rows_per_split);
     if (ns <= partial_rows) {
-      SmallRankP p{Lb, ldlb, V, ldv, y, n, j, (int)kdim, rows_per_split, partial, j, j, cp};
+      SmallRankP p{Lb, ldlb, V, ldv, y, n, j, (int)kdim, rows_per_split, partial, j, j, cp, nullptr, 0};
       int rc = launch_small_rank<SR_MODE_VALUE>(p, ns, st);
       if (rc) return rc;
       hipLaunchKernelGGL(column_reduce_kernel, dim3((unsigned)cdiv(j, 256)), dim3(256), 0, st, partial, j, ns, j, e_out, 0,
@@ -1371,12 +1460,32 @@ static int64_t onb_max_slabs(int64_t mk, int64_t j, int64_t n) {
   return s;
 }
 
+// partial rows of the step's energy by-product: one per 32 data rows of a chunk (the 64x64-tile worst case), or one per
+// small-rank row slab (<= 32); sized for the chunk, not for N
+static int64_t energy_partial_rows(int64_t n_chunk) { return cdiv(n_chunk, 32) < 32 ? 32 : cdiv(n_chunk, 32); }
+static size_t onb_energy_partial_bytes(int64_t n_chunk, int64_t j) {
+  return align_up((size_t)energy_partial_rows(n_chunk) * j * sizeof(double), 256);
+}
+
+// largest chunk (all rows, else a multiple of 128) whose G block and partial rows fit into `left` bytes
+static int64_t onb_pick_chunk(int64_t n, size_t left, int64_t j, int64_t min_rows) {
+  auto fits = [&](int64_t c) { return onb_energy_partial_bytes(c, j) + (size_t)c * j * sizeof(double) <= left; };
+  if (fits(n)) return n;
+  const double per_row = (double)j * sizeof(double) * (1.0 + 1.0 / 32.0);
+  int64_t c = (int64_t)(((double)left - 32.0 * j * sizeof(double) - 512.0) / per_row);
+  if (c > n) c = n;
+  c = c / 128 * 128;
+  while (c > min_rows && !fits(c)) c -= 128;
+  while (c + 128 <= n && fits(c + 128)) c += 128;
+  return c < min_rows ? min_rows : c;
+}
+
 size_t pls_onb_step_workspace_bytes(const pls_onb_desc *basis, int64_t j, int64_t n_chunk) {
   if (!basis || j <= 0) return 0;
   if (n_chunk <= 0 || n_chunk > basis->n) n_chunk = basis->n;
-  // D slabs (split-K of the back-projection, each mk x j) + G chunk (n_chunk x j)
+  // D slabs (split-K of the back-projection, each mk x j) + cost partial rows of the energy by-product + G chunk
   return (size_t)onb_max_slabs(basis->mk, j, basis->n) * align_up((size_t)basis->mk * j * sizeof(double), 256) +
-         (size_t)n_chunk * j * sizeof(double);
+         onb_energy_partial_bytes(n_chunk, j) + (size_t)n_chunk * j * sizeof(double);
 }
 
 int pls_onb_step(const pls_onb_desc *basis, const pls_cost_desc *cost, const double *y, double *U, int64_t ldu,
@@ -1416,20 +1525,34 @@ int pls_onb_step(const pls_onb_desc *basis, const pls_cost_desc *cost, const dou
                        energy_in, 0.5 / cost->p[0], basis->c + basis->mk);
     return check_launch("gaussian_energy_finish");
   }
-  if (energy_in)
-    return fail(PLS_ERR_UNSUPPORTED, "onb_step: the input-energy by-product exists on the Gaussian/identity fast path only");
+  // workspace: [D slabs][cost partial rows (energy by-product)][G chunk]; the chunk length follows from what is left
   const size_t d_bytes = align_up((size_t)basis->mk * j * sizeof(double), 256);
   const int64_t max_slabs = onb_max_slabs(basis->mk, j, basis->n);
   const int64_t min_rows = basis->n < 128 ? basis->n : 128;
-  if (!workspace || workspace_bytes < max_slabs * d_bytes + (size_t)min_rows * j * sizeof(double))
+  const size_t need_min = max_slabs * d_bytes + onb_energy_partial_bytes(min_rows, j) + (size_t)min_rows * j * sizeof(double);
+  if (!workspace || workspace_bytes < need_min)
     return fail(PLS_ERR_WORKSPACE_TOO_SMALL, "onb_step: workspace %zu bytes, need at least %zu", workspace_bytes,
                 pls_onb_step_workspace_bytes(basis, j, 128));
   double *D = static_cast<double *>(workspace);
-  double *Gbuf = reinterpret_cast<double *>(static_cast<char *>(workspace) + max_slabs * d_bytes);
-  const int64_t n_chunk = pick_chunk(basis->n, workspace_bytes - max_slabs * d_bytes, j, 0);
+  const size_t left = workspace_bytes - max_slabs * d_bytes;
+  const int64_t n_chunk = onb_pick_chunk(basis->n, left, j, min_rows);
+  double *vpart = reinterpret_cast<double *>(static_cast<char *>(workspace) + max_slabs * d_bytes);
+  double *Gbuf = reinterpret_cast<double *>(static_cast<char *>(workspace) + max_slabs * d_bytes +
+                                            onb_energy_partial_bytes(n_chunk, j));
+  EnergySink sink;
+  if (energy_in) {  // e_j = cost_j(F(U)) + 1/2 sum_m U_mj^2 / lam_m of the INPUT particles (orthonormal.py:120-125)
+    sink.partial = vpart;
+    sink.rows_cap = energy_partial_rows(n_chunk);
+    sink.e = energy_in;
+    sink.prior_kind = 1;
+    sink.P = U;
+    sink.ldp = ldu;
+    sink.m = basis->mk;
+    sink.lam = basis->lam;
+  }
   int64_t nslab = 1;
   rc = stream_drift(basis->A, basis->lda, basis->At, basis->ldat, basis->mk, basis->n, U, ldu, j, cp, y, D, j, max_slabs,
-                    (int64_t)(d_bytes / sizeof(double)), &nslab, Gbuf, n_chunk, st);
+                    (int64_t)(d_bytes / sizeof(double)), &nslab, Gbuf, n_chunk, st, energy_in ? &sink : nullptr);
   if (rc) return rc;
   {
     LaunchScope scope(PLS_TAG_LANGEVIN_UPDATE, st);

@@ -42,9 +42,13 @@ struct SmallRankP {
   double *out;             // MODE_DRIFT: D slabs [split][K][ldo];  MODE_VALUE: partial sums [split][ldo]
   int64_t ldo, slab_stride;
   CostP cp;
+  double *vout;  // SR_MODE_DRIFT_VALUE: cost partial sums [split][ldvo] next to the drift slabs
+  int64_t ldvo;
 };
 
-constexpr int SR_MODE_DRIFT = 0, SR_MODE_VALUE = 1;
+// DRIFT: D = Lb^T cost'(Lb V);  VALUE: sum_rows cost(Lb V);  DRIFT_VALUE: both from the same F (the step that also
+// reports the energy of its input particles)
+constexpr int SR_MODE_DRIFT = 0, SR_MODE_VALUE = 1, SR_MODE_DRIFT_VALUE = 2;
 constexpr int SR_ROWS = 32;  // rows of Lb per LDS tile (two 16-row MFMA blocks)
 
 template <int KB>
@@ -165,18 +169,19 @@ __global__ __launch_bounds__(256, 2) void small_rank_kernel(SmallRankP p) {
         const int row = 16 * b + q + 4 * r;
         const double yv = Y[row];
         const bool valid = !LAST || (n0 + row < nend);
-        if (MODE == SR_MODE_DRIFT) {
-          const double gval = cost_deriv(cp, yv, f[r]);
-          f[r] = valid ? gval : 0.0;
-        } else {
+        if (MODE != SR_MODE_DRIFT) {
           const double cval = cost_value(cp, yv, f[r]);
           vsum += valid ? cval : 0.0;
+        }
+        if (MODE != SR_MODE_VALUE) {
+          const double gval = cost_deriv(cp, yv, f[r]);
+          f[r] = valid ? gval : 0.0;
         }
       }
     }
     // the next tile's global loads fly during the second contraction (their staging registers are not live before)
     if (more) load_tile(n0 + SR_ROWS);
-    if (MODE == SR_MODE_DRIFT) {
+    if (MODE != SR_MODE_VALUE) {
       // second contraction: D[16 ta + c][jcol] += sum_rows Lb[row][16 ta + c] * G[row][jcol]; the A-operands of row
       // group r + 1 are fetched before the MFMAs of group r are issued (and no earlier: registers)
       double an[2][KB];
@@ -214,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void small_rank_kernel(SmallRankP p) {
   for (; n0 + SR_ROWS < nend; n0 += SR_ROWS, buf ^= 1) process_tile(buf, n0, true, std::false_type{});
   if (n0 < nend) process_tile(buf, n0, false, std::true_type{});
 
-  if (MODE == SR_MODE_DRIFT) {
+  if (MODE != SR_MODE_VALUE) {
     double *D = p.out + (int64_t)split * p.slab_stride;
     if (jin) {
 #pragma unroll
@@ -225,10 +230,12 @@ __global__ __launch_bounds__(256, 2) void small_rank_kernel(SmallRankP p) {
           if (m < p.K) D[(int64_t)m * p.ldo + jcol] = dacc[ta][r];
         }
     }
-  } else {
+  }
+  if (MODE != SR_MODE_DRIFT) {
     vsum += __shfl_xor(vsum, 16);
     vsum += __shfl_xor(vsum, 32);
-    if (jin && q == 0) p.out[(int64_t)split * p.slab_stride + jcol] = vsum;
+    double *vo = (MODE == SR_MODE_VALUE) ? p.out + (int64_t)split * p.slab_stride : p.vout + (int64_t)split * p.ldvo;
+    if (jin && q == 0) vo[jcol] = vsum;
   }
 }
 

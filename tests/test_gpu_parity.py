@@ -439,6 +439,70 @@ def test_small_rank_kernels_agree_with_the_two_gemm_path(P, mk):
         assert relerr(outs["fused"][1], outs["gemm"][1]) < tol, f"energy {name} mk={mk}"
 
 
+@pytest.mark.parametrize("n,m,j,d,chunk", [(700, 33, 130, 2, 0), (5000, 40, 64, 3, 2048), (2100, 130, 260, 4, 0), (40, 5, 3, 1, 0)])
+def test_step_energy_by_product_on_the_generic_path(P, rank_path, n, m, j, d, chunk):
+    """pls_onb_step(energy_in=...) on the generic path: the energy of the INPUT particles from the same F the
+    derivative uses, equal to the stand-alone energy call and to the oracle, for every cost, through both kernel
+    paths, with N streamed in chunks, and with the drift itself unchanged by the extra output."""
+    pr = make_problem(n, m, j, d, seed=3 * n + m)
+    ob, gb = build_onb(P, pr)
+    mk = ob.approximation_dimension
+    u = pr["u"][:mk].contiguous()
+    xi = torch.randn(mk, j, generator=pr["gen"])
+    lib = P.pkg._lib.load()
+    if chunk:
+        gb.workspace_bytes = lib.pls_onb_step_workspace_bytes(gb._desc(), j, chunk)
+        gb._ws.clear()
+    for name, oc, gc in make_costs(P, pr["y"], pr["fstar"], pr["gen"]):
+        e_in = torch.full((j,), float("nan"), dtype=torch.float64, device="cuda")
+        noise = P.basis.NoiseSpec(injected=cu(xi))
+        with_e = gb.fused_step(gc, cu(u), 1e-3, noise=noise, force_generic=True, input_energy=e_in)
+        without = gb.fused_step(gc, cu(u), 1e-3, noise=noise, force_generic=True)
+        assert torch.equal(with_e, without), name
+        e_alone = gb.fused_particle_energy(gc, cu(u), force_generic=True)
+        assert relerr(e_in, e_alone) < 1e-11, name
+        e_want = O.PLS(ob, oc).calculate_energy_potential(u.clone())
+        f = ob.calculate_untransformed_train_prediction_samples(u)
+        tol = 1e-9 if not name.startswith("poisson") else max(1e-9, 1e-13 / f.abs().min().item())
+        assert abs(e_in.mean().item() - e_want) <= tol * abs(e_want), name
+
+
+def test_train_pls_is_pipelined_for_every_native_cost(P, rank_path):
+    """The software-pipelined loop (one step launch per iteration, energy as a by-product) against the plain loop
+    (step, then a separate energy pass) for a non-Gaussian cost: same particles, energies and stop index."""
+    pr = make_problem(600, 20, 48, 2, seed=5)
+    ob, gb = build_onb(P, pr)
+    mk = ob.approximation_dimension
+    name, oc, gc = make_costs(P, pr["y"], pr["fstar"], pr["gen"])[2]  # bernoulli/sigmoid (Poisson's 1/f makes a
+    # 12-step trajectory too ill-conditioned to compare two implementations at 1e-8)
+    noises = [torch.randn(mk, 48, generator=pr["gen"]) for _ in range(12)]
+    runs = {}
+    for mode in ("pipelined", "plain"):
+        pls = P.pkg.PLS(gb, gc)
+        particles = cu(pr["u"][:mk].contiguous())
+        if mode == "plain":
+            gb.supports_input_energy = lambda c: False
+        try:
+            out, energies = P.pkg.train_pls(pls, particles, number_of_epochs=12, step_size=2e-6, early_stopper_patience=1e9,
+                                            noises=[cu(z) for z in noises])
+        finally:
+            if mode == "plain":
+                del gb.supports_input_energy
+        runs[mode] = (out.clone(), energies)
+    assert len(runs["pipelined"][1]) == len(runs["plain"][1]) == 12
+    assert relerr(runs["pipelined"][0], runs["plain"][0]) < 1e-12
+    assert np.allclose(runs["pipelined"][1], runs["plain"][1], rtol=1e-11)
+    # and against the oracle's loop
+    u = pr["u"][:mk].contiguous().clone()
+    pls_o = O.PLS(ob, oc)
+    want = []
+    for z in noises:
+        u += pls_o.calculate_particle_update(u, 2e-6, noise=z)
+        want.append(pls_o.calculate_energy_potential(u))
+    assert want[-1] < 10 * want[0], "the test dynamics must not blow up (parity of a chaotic run is meaningless)"
+    assert np.allclose(runs["pipelined"][1], want, rtol=1e-8)
+
+
 def test_random_shape_sweep_against_the_oracle(P, rank_path):
     """Seeded sweep over ragged (N, M, J, D): one Gaussian and one non-Gaussian step + energy per draw against the
     oracle, through whichever path `rank_path` selects (M <= 128 throughout, so `small_rank` really is the fused
