@@ -391,6 +391,36 @@ def main():
             "relaxation_rate_min": rho.min().item(), "stiffness_max": rho.max().item(),
         }
         log(f"train_pls: {len(energies)} steps in {wall:.2f} s, energy {energies[0]:.4g} -> {energies[-1]:.4g}")
+    # ---- train_pls iteration cost for the other costs: step + energy, pipelined (energy as a by-product of the step's
+    # own F) against the plain loop (step, then a separate energy pass as the reference does) ----
+    if cfg["cost"] != "gaussian" and args.converge_steps > 0:
+        from projected_langevin_sampling_amd.trainers import train_pls
+        iters = min(args.converge_steps, 20)
+        res = {}
+        for mode in ("pipelined", "plain"):
+            u0 = torch.normal(0.0, 1.0, size=(mk, j_total), generator=torch.Generator().manual_seed(0), dtype=torch.float64)
+            particles = u0[:, j0:j1].contiguous().cuda()
+            del u0
+            pls = pkg.PLS(basis, cost)
+            if mode == "plain":
+                basis.supports_input_energy = lambda c: False
+            reduce_fn = (lambda e: D.mean_over_particles(e, j_total)) if world > 1 else None
+            try:
+                train_pls(pls, particles.clone(), 2, eta, 1e30, energy_reduce=reduce_fn)  # warm-up
+                barrier()
+                t0 = time.perf_counter()
+                _, energies = train_pls(pls, particles, iters, eta, 1e30, energy_reduce=reduce_fn)
+                barrier()
+                res[mode] = ((time.perf_counter() - t0) / max(len(energies), 1) * 1e3, len(energies))
+            finally:
+                if mode == "plain":
+                    del basis.supports_input_energy
+        out["train_pls_iteration"] = {
+            "ms_pipelined": res["pipelined"][0], "ms_plain": res["plain"][0], "iterations": res["pipelined"][1],
+            "loop": "train_pls (experiments/trainers.py:139-162): step + energy (.item() sync) + EarlyStopper every step",
+            "note": "pipelined: the step launch also emits the energy of its input particles (same F); plain: separate energy pass",
+        }
+        log(f"train_pls iteration: pipelined {res['pipelined'][0]:.3f} ms, plain {res['plain'][0]:.3f} ms")
     # ---- setup extra: greedy conditional-variance inducing-point selection at this N, M ----
     if rank == 0 and args.select_inducing:
         import numpy as np

@@ -145,6 +145,9 @@ int pls_abi_version(void);
  *   kernels (F, d cost / d f and the back-projection in ONE pass: the N x J matrices F and G are never written);
  *   larger ranks, or 0, take the two-GEMM path.  Results agree to rounding, not bit for bit. */
 typedef enum pls_option { PLS_OPT_SMALL_RANK_MAX = 1 } pls_option;
+/* Diagnostic: out[i] = op(x[i]) with the device exp (op 0) / log (op 1) the per-element kernels use (csrc/fmath.h),
+ * so that their accuracy can be pinned against libm.  Not on the step path. */
+int pls_debug_math(int32_t op, const double *x, double *out, int64_t n, void *stream);
 int pls_set_option(int32_t option, int64_t value);
 int64_t pls_get_option(int32_t option); /* -1 for an unknown option */
 

@@ -86,6 +86,7 @@ SIGNATURES = {
     "pls_abi_version": (C.c_int, []),
     "pls_set_option": (C.c_int, [_I32, _I64]),
     "pls_get_option": (C.c_int64, [_I32]),
+    "pls_debug_math": (C.c_int, [_I32, _P, _P, _I64, _P]),
     "pls_timeline_begin": (C.c_int, [_I32]),
     "pls_timeline_end": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_int32), _I32, C.POINTER(C.c_int32)]),
     "pls_kernel_gram": (C.c_int, [_I32, _P, _I64, _P, _I64, _I64, _P, _D, _P, _I64, _P]),

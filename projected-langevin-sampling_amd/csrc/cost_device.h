@@ -3,6 +3,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cmath>
+
+#include "fmath.h"
+
 #include "../../include/plship.h"
 
 namespace plship {
@@ -11,6 +15,7 @@ struct CostP {
   int cost, link, mode;
   double p0, p1, p2, p3, jitter;
   double ip0;  // 1 / p0 (Gaussian: 1 / sigma2), computed on the host
+  double mm_l1, mm_l2, mm_norm, mm_is2;  // multimodal: log p2, log(1 - p2), 0.5 log(2 pi s2), 1 / s2 (host)
 };
 
 __host__ inline CostP make_costp(const pls_cost_desc *d) {
@@ -24,6 +29,14 @@ __host__ inline CostP make_costp(const pls_cost_desc *d) {
   c.p3 = d->p[3];
   c.jitter = d->jitter;
   c.ip0 = (d->p[0] != 0.0) ? 1.0 / d->p[0] : 0.0;
+  c.mm_l1 = c.mm_l2 = c.mm_norm = c.mm_is2 = 0.0;
+  if (d->cost == PLS_COST_MULTIMODAL) {
+    const double s2 = d->p[0] * d->p[0];
+    c.mm_l1 = std::log(d->p[2]);
+    c.mm_l2 = std::log(1.0 - d->p[2]);
+    c.mm_norm = 0.5 * std::log(2.0 * 3.14159265358979323846 * s2);
+    c.mm_is2 = 1.0 / s2;
+  }
   return c;
 }
 
@@ -39,7 +52,7 @@ __device__ inline double link_eval(int link, double f, double jit, double *slope
       *slope = 2.0 * f;
       return f * f;
     case PLS_LINK_SIGMOID: {  // :67-70
-      const double ex = exp(-f);
+      const double ex = fast_exp(-f);
       double raw = 1.0 / (1.0 + ex);
       bool inside = (raw >= jit) && (raw <= 1.0 - jit);
       // d/df 1/(1+e^-f) = e^-f / (1+e^-f)^2, the form autograd differentiates (raw*(1-raw) cancels near raw = 1)
@@ -49,7 +62,7 @@ __device__ inline double link_eval(int link, double f, double jit, double *slope
     default: {  // PLS_LINK_PROBIT :39-45
       double raw = 0.5 * (1.0 + erf(f * 0.70710678118654752440));
       bool inside = (raw >= jit) && (raw <= 1.0 - jit);
-      *slope = inside ? 0.39894228040143267794 * exp(-0.5 * f * f) : 0.0;
+      *slope = inside ? 0.39894228040143267794 * fast_exp(-0.5 * f * f) : 0.0;
       return clipd(raw, jit, 1.0 - jit);
     }
   }
@@ -65,21 +78,19 @@ __device__ inline double cost_value(const CostP &c, double y, double f) {
       return e * e / (2.0 * c.p0);
     }
     case PLS_COST_POISSON:  // poisson.py:59-66
-      return -2.0 * y * log(fabs(f)) + p;
+      return -2.0 * y * fast_log(fabs(f)) + p;
     case PLS_COST_BERNOULLI:  // bernoulli.py:57-62
-      return -log(p) * y - log(1.0 - p) * (1.0 - y);
+      return -fast_log(p) * y - fast_log(1.0 - p) * (1.0 - y);
     case PLS_COST_STUDENT_T: {  // student_t.py:57-72, p0 = dof, p1 = scale
       double e = p - y;
-      return 0.5 * (c.p0 + 1.0) * log(1.0 + e * e / (c.p0 * c.p1 * c.p1));
+      return 0.5 * (c.p0 + 1.0) * fast_log(1.0 + e * e / (c.p0 * c.p1 * c.p1));
     }
     default: {  // PLS_COST_MULTIMODAL multimodal.py:37-77, p0 = sigma (std), p1 = shift, p2 = bernoulli_noise
-      double s2 = c.p0 * c.p0;
       double e1 = y - p + c.p1, e2 = y - p;
-      double norm = 0.5 * log(2.0 * 3.14159265358979323846 * s2);
-      double a1 = log(c.p2) - 0.5 * e1 * e1 / s2 - norm;
-      double a2 = log(1.0 - c.p2) - 0.5 * e2 * e2 / s2 - norm;
+      double a1 = c.mm_l1 - 0.5 * e1 * e1 * c.mm_is2 - c.mm_norm;
+      double a2 = c.mm_l2 - 0.5 * e2 * e2 * c.mm_is2 - c.mm_norm;
       double m = fmax(a1, a2);
-      return -(m + log(exp(a1 - m) + exp(a2 - m)));
+      return -(m + fast_log(fast_exp(a1 - m) + fast_exp(a2 - m)));
     }
   }
 }
@@ -103,13 +114,12 @@ __device__ inline double cost_deriv(const CostP &c, double y, double f) {
       return (c.p0 + 1.0) * e / (c.p0 * c.p1 * c.p1 + e * e) * slope;
     }
     default: {  // multimodal.py:79-91: always the autograd value
-      double s2 = c.p0 * c.p0;
       double e1 = y - p + c.p1, e2 = y - p;
-      double a1 = log(c.p2) - 0.5 * e1 * e1 / s2;
-      double a2 = log(1.0 - c.p2) - 0.5 * e2 * e2 / s2;
+      double a1 = c.mm_l1 - 0.5 * e1 * e1 * c.mm_is2;
+      double a2 = c.mm_l2 - 0.5 * e2 * e2 * c.mm_is2;
       double m = fmax(a1, a2);
-      double w1 = exp(a1 - m), w2 = exp(a2 - m);
-      return -(w1 * e1 + w2 * e2) / ((w1 + w2) * s2) * slope;
+      double w1 = fast_exp(a1 - m), w2 = fast_exp(a2 - m);
+      return -(w1 * e1 + w2 * e2) / (w1 + w2) * c.mm_is2 * slope;
     }
   }
 }

@@ -1,0 +1,75 @@
+// fp64 exp / log for the per-element code of the hot kernels.
+//
+// In these kernels every vector-ALU instruction is paid for in matrix-pipe issue slots (the f64 MFMA and the VALU do
+// not overlap), and the library exp/log spend about half their instructions on special-case
+// ladders, extended-precision tails and constant moves.  These versions keep the classical argument reductions and
+// minimax/Taylor kernels (fdlibm's log, a degree-13 exp) and nothing else: <= 1 ulp on the whole fp64 range including
+// subnormals, with the IEEE limits (log 0 = -inf, log of a negative = NaN, exp overflow = +inf, exp underflow = 0,
+// NaN in = NaN out).  tests/test_gpu_parity.py::test_device_math_matches_libm pins them.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace plship {
+
+// exp(x): n = rint(x log2 e), r = x - n ln 2 (two-piece ln 2), degree-13 Taylor polynomial in Horner form
+// (|r| <= 0.347: truncation 4e-18 relative), scaled by 2^n with v_ldexp (gradual underflow as libm).
+__device__ __forceinline__ double fast_exp(double x) {
+  const double n = rint(x * 1.4426950408889634074);
+  double r = fma(n, -6.93147180369123816490e-01, x);
+  r = fma(n, -1.90821492927058770002e-10, r);
+  double p = 1.6059043836821613e-10;  // 1/13!
+  p = fma(p, r, 2.0876756987868098e-09);
+  p = fma(p, r, 2.5052108385441720e-08);
+  p = fma(p, r, 2.7557319223985893e-07);
+  p = fma(p, r, 2.7557319223985888e-06);
+  p = fma(p, r, 2.4801587301587302e-05);
+  p = fma(p, r, 1.9841269841269841e-04);
+  p = fma(p, r, 1.3888888888888889e-03);
+  p = fma(p, r, 8.3333333333333332e-03);
+  p = fma(p, r, 4.1666666666666664e-02);
+  p = fma(p, r, 1.6666666666666666e-01);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  double v = ldexp(p, (int)n);
+  v = (x < -745.2) ? 0.0 : v;
+  v = (x > 709.8) ? __builtin_huge_val() : v;  // (NaN fails both comparisons and has already propagated through p)
+  return v;
+}
+
+// a / b for b well inside the normal range (no scaling steps): reciprocal seed + two Newton steps + one residual
+// correction of the quotient; <= 1 ulp
+__device__ __forceinline__ double fast_div_normal(double a, double b) {
+  double r = __builtin_amdgcn_rcp(b);
+  r = fma(fma(-b, r, 1.0), r, r);
+  r = fma(fma(-b, r, 1.0), r, r);
+  const double q = a * r;
+  return fma(fma(-b, q, a), r, q);
+}
+
+// log(x) after fdlibm's e_log.c: x = 2^k (1 + f) with 1 + f in [sqrt(1/2), sqrt(2)), s = f / (2 + f),
+// log(1 + f) = f - (f^2/2 - s (f^2/2 + R(s^2))), R the degree-7 minimax polynomial (error < 2^-58.45).
+__device__ __forceinline__ double fast_log(double x) {
+  double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1) (subnormals included)
+  int k = __builtin_amdgcn_frexp_exp(x);
+  const bool low = m < 0.70710678118654752440;
+  m = low ? m + m : m;
+  k = low ? k - 1 : k;
+  const double f = m - 1.0;
+  const double dk = (double)k;
+  const double s = fast_div_normal(f, 2.0 + f);
+  const double z = s * s, w = z * z;
+  const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+  const double t2 =
+      z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01),
+              6.666666666666735130e-01);
+  const double R = t2 + t1;
+  const double hfsq = 0.5 * f * f;
+  double v = dk * 6.93147180369123816490e-01 - ((hfsq - fma(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f);
+  v = (x == 0.0) ? -__builtin_huge_val() : v;
+  v = (x == __builtin_huge_val()) ? x : v;
+  v = (x < 0.0) ? __builtin_nan("") : v;
+  return v;
+}
+
+}  // namespace plship

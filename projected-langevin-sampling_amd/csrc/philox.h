@@ -12,6 +12,8 @@
 // The numpy restatement used by the tests is oracle/philox_ref.py.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include "fmath.h"
 #include <stdint.h>
 
 namespace plship {
@@ -55,7 +57,7 @@ __device__ inline void normal_pair(uint64_t seed, uint64_t step, int64_t ibase, 
   uint64_t b = ((uint64_t)x[2] << 32) | x[3];
   double u1 = ((double)(a >> 11) + 0.5) * two_m53;
   double u2 = ((double)(b >> 11) + 0.5) * two_m53;
-  double rad = sqrt(-2.0 * log(u1));
+  double rad = sqrt(-2.0 * fast_log(u1));
   double s, c;
   sincospi(2.0 * u2, &s, &c);
   z_lo = rad * c;

@@ -589,6 +589,12 @@ static void launch_gram(dim3 grid, hipStream_t st, const double *x1, int64_t row
 #undef PLS_GRAM_CASE
 }
 
+__global__ __launch_bounds__(256) void debug_math_kernel(int op, const double *__restrict__ x, double *__restrict__ out,
+                                                         int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = op == 0 ? fast_exp(x[i]) : fast_log(x[i]);
+}
+
 // elementwise cost derivative (un-fused entry point)
 __global__ __launch_bounds__(256) void cost_deriv_kernel(CostP cp, const double *__restrict__ F, int64_t ldf,
                                                           const double *__restrict__ y, int64_t n, int64_t j,
@@ -1197,6 +1203,14 @@ int pls_set_option(int32_t option, int64_t value) {
       return PLS_OK;
     default: return fail(PLS_ERR_INVALID_ARGUMENT, "set_option: unknown option %d", (int)option);
   }
+}
+
+int pls_debug_math(int32_t op, const double *x, double *out, int64_t n, void *stream) {
+  PLS_REQUIRE(op == 0 || op == 1, "debug_math: op must be 0 (exp) or 1 (log)");
+  PLS_REQUIRE(x && out && n >= 0, "debug_math: bad arguments");
+  if (n == 0) return PLS_OK;
+  hipLaunchKernelGGL(debug_math_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, S(stream), op, x, out, n);
+  return check_launch("debug_math");
 }
 
 int64_t pls_get_option(int32_t option) {

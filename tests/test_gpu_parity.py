@@ -287,6 +287,44 @@ def test_philox_stream_matches_numpy_restatement(P):
     assert abs(torch.corrcoef(torch.stack([z[:-4].flatten(), z[4:].flatten()]))[0, 1].item()) < 3e-3  # pair rows uncorrelated
 
 
+def test_device_math_matches_libm(P):
+    """csrc/fmath.h (the exp / log of every per-element kernel) against numpy's libm over the whole fp64 range:
+    <= 2 ulp everywhere, exact IEEE limits."""
+    L = P.pkg._lib
+    rng = np.random.default_rng(7)
+
+    def run(op, x):
+        xd = torch.from_numpy(x).cuda()
+        out = torch.empty_like(xd)
+        L.check(L.load().pls_debug_math(op, xd.data_ptr(), out.data_ptr(), xd.numel(), L.stream_ptr()), "pls_debug_math")
+        return out.cpu().numpy()
+
+    def ulps(got, want):
+        with np.errstate(invalid="ignore", divide="ignore"):
+            return np.abs(got - want) / np.spacing(np.abs(want))
+
+    # exp: dense near 0, the full finite range, the under/overflow thresholds
+    x = np.concatenate([rng.uniform(-745.0, 709.0, 200000), rng.normal(0, 1, 200000), rng.normal(0, 1e-8, 1000),
+                        np.array([0.0, -0.0, 1.0, -1.0, 709.78, -745.13, -708.4, -720.0, -744.0])])
+    got, want = run(0, x), np.exp(x)
+    ok = np.isfinite(want) & (want > 1e-300)
+    assert ulps(got[ok], want[ok]).max() <= 2.0
+    sub = np.isfinite(want) & (want <= 1e-300)  # gradual underflow: absolute agreement to the last subnormal bits
+    assert np.all(np.abs(got[sub] - want[sub]) <= 2 * np.spacing(np.abs(want[sub])) + 5e-324)
+    sp = run(0, np.array([np.inf, -np.inf, np.nan, 710.0, -746.0, 1e308, -1e308]))
+    assert sp[0] == np.inf and sp[1] == 0.0 and np.isnan(sp[2]) and sp[3] == np.inf and sp[4] == 0.0 and sp[5] == np.inf and sp[6] == 0.0
+    # log: every binade incl. subnormals, dense around 1 (where log -> 0 and relative accuracy is hardest)
+    x = np.concatenate([np.exp(rng.uniform(-744.0, 709.0, 200000)), 1.0 + rng.normal(0, 1e-3, 100000), 1.0 + rng.normal(0, 1e-9, 1000),
+                        rng.uniform(0.5, 2.0, 100000), np.array([1.0, 0.5, 2.0, 5e-324, 2.2250738585072014e-308, 1.7976931348623157e308,
+                                                               0.70710678118654746, 0.70710678118654757, 1e-10, 1 - 1e-10])])
+    x = np.abs(x)
+    got, want = run(1, x), np.log(x)
+    nz = want != 0.0
+    assert ulps(got[nz], want[nz]).max() <= 2.0 and np.all(got[~nz] == 0.0)
+    sp = run(1, np.array([0.0, -0.0, np.inf, np.nan, -1.0]))
+    assert sp[0] == -np.inf and sp[1] == -np.inf and sp[2] == np.inf and np.isnan(sp[3]) and np.isnan(sp[4])
+
+
 def test_costs_vs_oracle_all_pairs(P):
     pr = make_problem(300, 8, 17, 2, seed=3)
     g = pr["gen"]
