@@ -257,9 +257,10 @@ int pls_onb_particle_update(const pls_onb_desc *basis, const double *U, int64_t 
  * out_mode 0: out = dU (the reference's return value);  out_mode 1: out = U + dU (the caller's
  * `particles += update`, trainers.py:157, fused).  out must not alias U: other workgroups still read U as
  * the GEMM operand, so callers ping-pong two particle buffers.
- * energy_in (may be NULL; Gaussian/identity fast path only, else PLS_ERR_UNSUPPORTED): receives e_j(U) of the INPUT
- * particles -- the value pls_onb_energy returns -- as a by-product of the same contraction (B U is what both need), so
- * a train loop (trainers.py:153-159) pays one launch per step; it then needs cdiv(mk, 64) * j workspace doubles.
+ * energy_in (may be NULL): receives e_j(U) of the INPUT particles -- the value pls_onb_energy returns -- as a
+ * by-product: on the fast path from the same B U product (it then needs cdiv(mk, 64) * j workspace doubles), otherwise
+ * from the same F tile the cost derivative is taken of, so a train loop (trainers.py:153-159, which recomputes F for the
+ * energy) pays no separate energy pass.
  * workspace: pls_onb_step_workspace_bytes(...) bytes (any larger size lets it use bigger N chunks). */
 size_t pls_onb_step_workspace_bytes(const pls_onb_desc *basis, int64_t j, int64_t n_chunk);
 int pls_onb_step(const pls_onb_desc *basis, const pls_cost_desc *cost, const double *y, double *U, int64_t ldu,
@@ -298,9 +299,11 @@ int pls_ipb_particle_update(const pls_ipb_desc *basis, const double *U, int64_t 
                             void *workspace, size_t workspace_bytes, void *stream);
 
 size_t pls_ipb_step_workspace_bytes(const pls_ipb_desc *basis, int64_t j, int64_t n_chunk);
+/* energy_in (optional, J doubles): receives the energy of the INPUT particles (cost of the same F the drift uses +
+ * the prior term) as a by-product, like pls_onb_step. */
 int pls_ipb_step(const pls_ipb_desc *basis, const pls_cost_desc *cost, const double *y, double *U, int64_t ldu,
                  int64_t j, double eta, const pls_noise_desc *noise, double *out, int64_t ldo, int32_t out_mode,
-                 void *workspace, size_t workspace_bytes, void *stream);
+                 double *energy_in, void *workspace, size_t workspace_bytes, void *stream);
 
 /* e(J) = cost_j + (M/2) * ||W U_j||^2 (inducing_point.py:95-115). */
 size_t pls_ipb_energy_workspace_bytes(const pls_ipb_desc *basis, int64_t j, int64_t n_chunk);

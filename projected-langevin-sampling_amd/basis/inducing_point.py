@@ -116,7 +116,10 @@ class InducingPointBasis(PLSBasis):
         return True
 
     def fused_step(self, cost, particles: torch.Tensor, step_size: float, out: torch.Tensor | None = None,
-                   new_state: bool = False, noise: NoiseSpec | None = None, force_generic: bool = False) -> torch.Tensor:
+                   new_state: bool = False, noise: NoiseSpec | None = None, force_generic: bool = False,
+                   input_energy: torch.Tensor | None = None) -> torch.Tensor:
+        """One whole Langevin step (pls_ipb_step).  ``input_energy`` (J,) receives the per-particle energy of
+        ``particles`` as a by-product (cost of the same F + (M/2)||K^-1 U||^2)."""
         u = _rows_contiguous(L.require_gpu_tensor(particles, "particles"))
         j = u.shape[1]
         if out is None:
@@ -133,11 +136,14 @@ class InducingPointBasis(PLSBasis):
         nd = (noise if noise is not None else self._draw_noise_spec(None)).desc()
         L.check(
             lib.pls_ipb_step(desc, cost.desc(), cost.y_device().data_ptr(), u.data_ptr(), L.ld(u), j, float(step_size), nd,
-                             out.data_ptr(), L.ld(out), L.OUT_NEW_STATE if new_state else L.OUT_DELTA, ws.data_ptr(), ws_bytes,
-                             L.stream_ptr()),
+                             out.data_ptr(), L.ld(out), L.OUT_NEW_STATE if new_state else L.OUT_DELTA, L.ptr(input_energy),
+                             ws.data_ptr(), ws_bytes, L.stream_ptr()),
             "pls_ipb_step",
         )
         return out
+
+    def supports_input_energy(self, cost) -> bool:
+        return bool(cost.is_native())
 
     def fused_particle_energy(self, cost, particles: torch.Tensor) -> torch.Tensor:
         u = _rows_contiguous(L.require_gpu_tensor(particles, "particles"))

@@ -1711,14 +1711,14 @@ int pls_ipb_particle_update(const pls_ipb_desc *basis, const double *U, int64_t 
 size_t pls_ipb_step_workspace_bytes(const pls_ipb_desc *basis, int64_t j, int64_t n_chunk) {
   if (!basis || j <= 0) return 0;
   if (n_chunk <= 0 || n_chunk > basis->n) n_chunk = basis->n;
-  // V, xi, e (m x j each) + D slabs + G chunk
+  // V, xi, e (m x j each) + D slabs + cost partial rows of the energy by-product + G chunk
   return (size_t)(3 + onb_max_slabs(basis->m, j, basis->n)) * align_up((size_t)basis->m * j * sizeof(double), 256) +
-         (size_t)n_chunk * j * sizeof(double);
+         onb_energy_partial_bytes(n_chunk, j) + (size_t)n_chunk * j * sizeof(double);
 }
 
 int pls_ipb_step(const pls_ipb_desc *basis, const pls_cost_desc *cost, const double *y, double *U, int64_t ldu, int64_t j,
-                 double eta, const pls_noise_desc *noise, double *out, int64_t ldo, int32_t out_mode, void *workspace,
-                 size_t workspace_bytes, void *stream) {
+                 double eta, const pls_noise_desc *noise, double *out, int64_t ldo, int32_t out_mode, double *energy_in,
+                 void *workspace, size_t workspace_bytes, void *stream) {
   int rc = validate_ipb(basis);
   if (rc) return rc;
   rc = validate_cost(cost);
@@ -1734,20 +1734,33 @@ int pls_ipb_step(const pls_ipb_desc *basis, const pls_cost_desc *cost, const dou
   const int64_t max_slabs = onb_max_slabs(basis->m, j, basis->n);
   const size_t fixed = (size_t)(3 + max_slabs) * mj;
   const int64_t min_rows = basis->n < 128 ? basis->n : 128;
-  if (!workspace || workspace_bytes < fixed + (size_t)min_rows * j * sizeof(double))
+  if (!workspace ||
+      workspace_bytes < fixed + onb_energy_partial_bytes(min_rows, j) + (size_t)min_rows * j * sizeof(double))
     return fail(PLS_ERR_WORKSPACE_TOO_SMALL, "ipb_step: workspace %zu bytes, need at least %zu", workspace_bytes,
                 pls_ipb_step_workspace_bytes(basis, j, 128));
   char *w = static_cast<char *>(workspace);
   double *V = reinterpret_cast<double *>(w), *xi = reinterpret_cast<double *>(w + mj);
   double *e = reinterpret_cast<double *>(w + 2 * mj), *D = reinterpret_cast<double *>(w + 3 * mj);
-  double *Gbuf = reinterpret_cast<double *>(w + fixed);
-  const int64_t n_chunk = pick_chunk(basis->n, workspace_bytes - fixed, j, 0);
+  const int64_t n_chunk = onb_pick_chunk(basis->n, workspace_bytes - fixed, j, min_rows);
+  double *vpart = reinterpret_cast<double *>(w + fixed);
+  double *Gbuf = reinterpret_cast<double *>(w + fixed + onb_energy_partial_bytes(n_chunk, j));
   hipStream_t st = S(stream);
   rc = pls_gemm_tn(basis->W, basis->ldw, U, ldu, V, j, basis->m, j, basis->m, 1.0, 0.0, stream);
   if (rc) return rc;
+  EnergySink sink;
+  if (energy_in) {  // e_j = cost_j(F(U)) + (M/2) ||K^-1 U_j||^2 of the INPUT particles (inducing_point.py:95-115)
+    sink.partial = vpart;
+    sink.rows_cap = energy_partial_rows(n_chunk);
+    sink.e = energy_in;
+    sink.prior_kind = 2;
+    sink.P = V;
+    sink.ldp = j;
+    sink.m = basis->m;
+    sink.scale = 0.5 * (double)basis->m;
+  }
   int64_t nslab = 1;
   rc = stream_drift(basis->Kzx, basis->ldkzx, basis->Kxz, basis->ldkxz, basis->m, basis->n, V, j, j, make_costp(cost), y,
-                    D, j, max_slabs, (int64_t)(mj / sizeof(double)), &nslab, Gbuf, n_chunk, st);
+                    D, j, max_slabs, (int64_t)(mj / sizeof(double)), &nslab, Gbuf, n_chunk, st, energy_in ? &sink : nullptr);
   if (rc) return rc;
   return ipb_finish(basis, U, ldu, D, (int)nslab, (int64_t)(mj / sizeof(double)), V, j, eta, noise, out, ldo, out_mode, xi, e,
                     st);

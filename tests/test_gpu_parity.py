@@ -505,6 +505,40 @@ def test_step_energy_by_product_on_the_generic_path(P, rank_path, n, m, j, d, ch
         assert abs(e_in.mean().item() - e_want) <= tol * abs(e_want), name
 
 
+@pytest.mark.parametrize("n,m,j,d", [(512, 24, 64, 3), (700, 33, 130, 2)])
+def test_ipb_step_energy_by_product(P, rank_path, n, m, j, d):
+    """pls_ipb_step(energy_in=...): cost of the same F + (M/2)||K^-1 U||^2 of the input particles, equal to the
+    stand-alone energy call; the update itself is unchanged; and train_pls pipelines on it."""
+    pr = make_problem(n, m, j, d, seed=7 * n + m)
+    pr["ls"] = pr["ls"] * 0.35
+    ob, gb = build_ipb(P, pr)
+    u = pr["u"]
+    e_noise = torch.randn(m, j, generator=pr["gen"])
+    for name, oc, gc in make_costs(P, pr["y"], pr["fstar"], pr["gen"])[:5]:
+        e_in = torch.full((j,), float("nan"), dtype=torch.float64, device="cuda")
+        noise = P.basis.NoiseSpec(injected=cu(e_noise))
+        with_e = gb.fused_step(gc, cu(u), 1e-3, noise=noise, input_energy=e_in)
+        without = gb.fused_step(gc, cu(u), 1e-3, noise=noise)
+        assert torch.equal(with_e, without), name
+        assert relerr(e_in, gb.fused_particle_energy(gc, cu(u))) < 1e-11, name
+    name, oc, gc = make_costs(P, pr["y"], pr["fstar"], pr["gen"])[2]
+    noises = [cu(torch.randn(m, j, generator=pr["gen"])) for _ in range(6)]
+    runs = {}
+    for mode in ("pipelined", "plain"):
+        pls = P.pkg.PLS(gb, gc)
+        if mode == "plain":
+            gb.supports_input_energy = lambda c: False
+        try:
+            out, energies = P.pkg.train_pls(pls, cu(u), number_of_epochs=6, step_size=1e-7, early_stopper_patience=1e9, noises=noises)
+        finally:
+            if mode == "plain":
+                del gb.supports_input_energy
+        runs[mode] = (out.clone(), energies)
+    assert len(runs["pipelined"][1]) == len(runs["plain"][1]) == 6
+    assert relerr(runs["pipelined"][0], runs["plain"][0]) < 1e-12
+    assert np.allclose(runs["pipelined"][1], runs["plain"][1], rtol=1e-10)
+
+
 def test_train_pls_is_pipelined_for_every_native_cost(P, rank_path):
     """The software-pipelined loop (one step launch per iteration, energy as a by-product) against the plain loop
     (step, then a separate energy pass) for a non-Gaussian cost: same particles, energies and stop index."""
