@@ -962,23 +962,43 @@ __global__ __launch_bounds__(CV_BLOCK) void cv_argmax_final_kernel(const double 
 }
 
 // one greedy iteration i (0-based): e = (round20(k(X, x_j)) + jitter [n == j] - c[:i, j] . c[:i, n]) / sqrt(d_j)
+// The dot product over the i previous rows is the whole cost (M^2/2 * N * 8 bytes over the run): a block covers
+// CV_COLS columns with CV_BLOCK / CV_COLS row slices (wave w takes rows w, w + 4, ...; two independent partial sums
+// each), so that 8x more loads are in flight than with one thread per column -- the N = 1e5 columns alone are 1.5
+// waves per SIMD of dependent fma chains; the slices are summed through LDS in a fixed order.
+constexpr int CV_COLS = 64;
 __global__ __launch_bounds__(CV_BLOCK) void cv_update_kernel(int kind, const double *__restrict__ x, int64_t n, int d,
                                                               const double *__restrict__ lengthscale, double outputscale,
                                                               double jitter, int64_t iter, double *__restrict__ ci,
                                                               double *__restrict__ di, const CvState *__restrict__ st) {
+  constexpr int NSL = CV_BLOCK / CV_COLS;
   __shared__ double inv_ls[64];
+  __shared__ double part[NSL][CV_COLS];
   if ((int)threadIdx.x < d) inv_ls[threadIdx.x] = (kind == PLS_KERNEL_RBF_ARD) ? 1.0 / lengthscale[threadIdx.x] : 1.0;
   __syncthreads();
-  if (st->stopped || st->count != iter + 1) return;  // (stopped early, or ran out of candidates)
+  if (st->stopped || st->count != iter + 1) return;  // (stopped early, or ran out of candidates; uniform)
   const int64_t j = st->pivot;
   const double dj = sqrt(st->pivot_d);
-  const int64_t col = (int64_t)blockIdx.x * CV_BLOCK + threadIdx.x;
-  if (col >= n) return;
+  const int c = threadIdx.x % CV_COLS, sl = threadIdx.x / CV_COLS;
+  const int64_t col = (int64_t)blockIdx.x * CV_COLS + c;
+  const bool in = col < n;
+  const int64_t cc = in ? col : 0;
+  double d0 = 0.0, d1 = 0.0;
+  int64_t t = sl;
+  for (; t + NSL < iter; t += 2 * NSL) {
+    d0 = fma(ci[t * n + j], ci[t * n + cc], d0);
+    d1 = fma(ci[(t + NSL) * n + j], ci[(t + NSL) * n + cc], d1);
+  }
+  if (t < iter) d0 = fma(ci[t * n + j], ci[t * n + cc], d0);
+  part[sl][c] = d0 + d1;
+  __syncthreads();
+  if (sl != 0 || !in) return;
+  double dot = part[0][c];
+#pragma unroll
+  for (int k = 1; k < NSL; ++k) dot += part[k][c];
   double g = cv_kernel_eval(kind, x, col, j, d, inv_ls, outputscale);
   g = rint(g * 1e20) / 1e20;  // np.round(., 20) (conditional_variance.py:93)
   if (col == j) g += jitter;
-  double dot = 0.0;
-  for (int64_t t = 0; t < iter; ++t) dot = fma(ci[t * n + j], ci[t * n + col], dot);
   const double e = (g - dot) / dj;
   ci[iter * n + col] = e;
   const double nd = di[col] - e * e;
@@ -1857,7 +1877,7 @@ int pls_select_inducing_conditional_variance(int32_t kernel_kind, const double *
     hipLaunchKernelGGL(cv_argmax_final_kernel, dim3(1), dim3(CV_BLOCK), 0, s, pval, pidx, psum, nparts, di, chosen, indices, m,
                        threshold, it == 0 ? 1 : 0, st);
     if (it + 1 < m)
-      hipLaunchKernelGGL(cv_update_kernel, dim3(gn), dim3(CV_BLOCK), 0, s, kernel_kind, x, n, (int)d, lengthscale, outputscale,
+      hipLaunchKernelGGL(cv_update_kernel, dim3((unsigned)cdiv(n, CV_COLS)), dim3(CV_BLOCK), 0, s, kernel_kind, x, n, (int)d, lengthscale, outputscale,
                          jitter, it, ci, di, st);
     rc = check_launch("cv_iteration");
     if (rc) return rc;
