@@ -65,6 +65,9 @@ def train_pls(
 
     from .basis.base import NoiseSpec
 
+    if energy_reduce is None and particles.is_cuda:
+        return _train_pls_two_in_flight(pls, particles, number_of_epochs, step_size, early_stopper, noises)
+
     cur = particles
     nxt = torch.empty_like(particles, memory_format=torch.contiguous_format)
     e_in = torch.empty(particles.shape[1], dtype=torch.float64, device=particles.device)
@@ -87,4 +90,60 @@ def train_pls(
             energy_potentials.append(energy_potential)
     if cur.data_ptr() != particles.data_ptr():
         particles.copy_(cur)
+    return particles, energy_potentials
+
+
+def _train_pls_two_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs: int, step_size: float,
+                             early_stopper: EarlyStopper, noises) -> Tuple[torch.Tensor, List[float]]:
+    """The pipelined loop with TWO step launches queued: launch k computes U_{k+1} from U_k and, as a by-product, the
+    energy of U_k.  The mean energy travels to pinned host memory by an asynchronous copy followed by an event, and
+    launch k+1 is already queued behind it when the host waits for that event -- so the GPU never idles over the host's
+    round trip (sync + early-stop logic + next launch, ~30 us against a 290 us step at configs[1]).  Three particle
+    buffers rotate, so the (up to two) launches made speculatively past the stop never touch the returned state, and
+    the torch RNG state is rewound to what the plain loop would have consumed.  Same particles, energies and stop
+    index as the plain loop (tests/test_gpu_parity.py)."""
+    from .basis.base import NoiseSpec
+
+    T = number_of_epochs
+    j = particles.shape[1]
+    bufs = [particles, torch.empty_like(particles, memory_format=torch.contiguous_format),
+            torch.empty_like(particles, memory_format=torch.contiguous_format)]
+    e_dev = [torch.empty(j, dtype=torch.float64, device=particles.device) for _ in range(3)]
+    host = torch.empty(3, dtype=torch.float64).pin_memory()
+    events = [torch.cuda.Event() for _ in range(3)]
+    rng_states = {}
+    launched = 0
+
+    def launch():
+        nonlocal launched
+        k = launched
+        rng_states[k] = torch.get_rng_state()  # (a speculative launch may have to be un-drawn)
+        spec = NoiseSpec(injected=noises[k]) if noises is not None else None
+        pls.basis.fused_step(pls.cost, bufs[k % 3], float(step_size), out=bufs[(k + 1) % 3], new_state=True, noise=spec,
+                             input_energy=e_dev[k % 3])
+        host[k % 3: k % 3 + 1].copy_(e_dev[k % 3].mean().reshape(1), non_blocking=True)  # E(U_k)
+        events[k % 3].record()
+        launched += 1
+
+    energy_potentials: List[float] = []
+    final = None
+    for t in range(T):  # iteration t of the plain loop: update t done (U_{t+1}), its energy E(U_{t+1}) wanted
+        while launched < T and launched <= t + 2:  # launches t+1 (carries E(U_{t+1})) and t+2 (keeps the queue non-empty)
+            launch()
+        if t + 1 < T:
+            events[(t + 1) % 3].synchronize()
+            energy_potential = host[(t + 1) % 3].item()
+        else:  # the energy after the last update has no following launch to ride on
+            energy_potential = pls.particle_energy_potential(bufs[T % 3]).mean().item()
+        if early_stopper.should_stop(loss=energy_potential, step_size=step_size):
+            if launched > t + 1:
+                torch.set_rng_state(rng_states[t + 1])
+            final = bufs[(t + 1) % 3]
+            break
+        energy_potentials.append(energy_potential)
+    if final is None:
+        final = bufs[T % 3]
+    torch.cuda.current_stream().synchronize()  # speculative launches still read / write the rotating buffers
+    if final.data_ptr() != particles.data_ptr():
+        particles.copy_(final)
     return particles, energy_potentials
