@@ -391,6 +391,22 @@ def main():
             "relaxation_rate_min": rho.min().item(), "stiffness_max": rho.max().item(),
         }
         log(f"train_pls: {len(energies)} steps in {wall:.2f} s, energy {energies[0]:.4g} -> {energies[-1]:.4g}")
+        if world == 1:
+            # same loop with 32 steps + energies per hipGraph replay (extension; pays off when the step is launch-bound)
+            from projected_langevin_sampling_amd.trainers import train_pls_captured
+            u0 = torch.normal(0.0, 1.0, size=(mk, j_total), generator=torch.Generator().manual_seed(0), dtype=torch.float64)
+            particles = u0[:, j0:j1].contiguous().cuda()
+            del u0
+            barrier()
+            t0 = time.perf_counter()
+            _, energies_c = train_pls_captured(pls, particles, args.converge_steps, eta_c, patience, steps_per_replay=32, seed=1)
+            barrier()
+            wall_c = time.perf_counter() - t0
+            out["converged_energy"]["captured"] = {
+                "wall_s": wall_c, "steps": len(energies_c), "ms_per_step_with_energy": wall_c / max(len(energies_c), 1) * 1e3,
+                "note": "train_pls_captured: 32 steps + energies per hipGraph replay (wall includes the capture itself)",
+            }
+            log(f"train_pls_captured: {len(energies_c)} steps in {wall_c:.3f} s")
     # ---- train_pls iteration cost for the other costs: step + energy, pipelined (energy as a by-product of the step's
     # own F) against the plain loop (step, then a separate energy pass as the reference does) ----
     if cfg["cost"] != "gaussian" and args.converge_steps > 0:

@@ -6,6 +6,6 @@ side: it owns device memory through torch tensors and calls the C ABI (include/p
 from . import _lib
 from .kernel import ARDKernel, LinearKernel, PLSKernel
 from .projected_langevin_sampling import PLS
-from .trainers import EarlyStopper, train_pls
+from .trainers import EarlyStopper, train_pls, train_pls_captured
 
-__all__ = ["PLS", "PLSKernel", "ARDKernel", "LinearKernel", "EarlyStopper", "train_pls", "_lib"]
+__all__ = ["PLS", "PLSKernel", "ARDKernel", "LinearKernel", "EarlyStopper", "train_pls", "train_pls_captured", "_lib"]

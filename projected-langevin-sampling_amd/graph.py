@@ -64,3 +64,83 @@ class CapturedSteps:
     @property
     def steps_done(self) -> int:
         return int(self.counter.item())
+
+
+class CapturedTraining:
+    """The train loop (step + energy + early stop, experiments/trainers.py:139-162) with K steps per hipGraph replay.
+
+    Each captured step launch also emits the energy of its input particles (pls_onb_step / pls_ipb_step ``energy_in``);
+    their means land in a (K,) device vector that is read back once per replay, so a launch-bound problem (the
+    reference's own experiment sizes: N ~ 1e2..1e4, M ~ 1e1..1e2) pays one graph launch and one host sync per K
+    iterations instead of ~5 launches and a sync per iteration.  The early-stop rule is evaluated on the host after
+    every replay; a replay that overshoots the stop is rolled back to its saved starting particles and re-run eagerly
+    up to the stop index with the same (seed, step) noise counters -- the kernels are deterministic, so the returned
+    particles, energy list and stop index are exactly those of the eager loop over the same noise stream
+    (tests/test_gpu_parity.py::test_captured_training_matches_the_eager_loop)."""
+
+    def __init__(self, pls: PLS, particles: torch.Tensor, step_size: float, steps_per_replay: int, seed: int):
+        if not pls._fused() or not getattr(pls.basis, "supports_input_energy", lambda c: False)(pls.cost):
+            raise L.PlsHipError("captured training needs a native basis and cost (fused step with the energy by-product)")
+        assert steps_per_replay >= 1
+        L.require_gpu_tensor(particles, "particles")
+        assert particles.is_contiguous()
+        self.pls, self.particles, self.k, self.seed, self.step_size = pls, particles, steps_per_replay, int(seed), float(step_size)
+        self._pong = torch.empty_like(particles)
+        self._start = torch.empty_like(particles)  # particles at the start of the last replay (roll-back point)
+        self._e = torch.empty(particles.shape[1], dtype=torch.float64, device=particles.device)
+        self.means = torch.zeros(steps_per_replay, dtype=torch.float64, device=particles.device)
+        self.counter = torch.zeros(1, dtype=torch.int64, device=particles.device)
+        basis, cost = pls.basis, pls.cost
+
+        def body():
+            self._start.copy_(self.particles)
+            cur, nxt = self.particles, self._pong
+            for s in range(self.k):
+                spec = NoiseSpec(seed=self.seed, step=s, j_offset=basis.j_offset, step_base=self.counter)
+                basis.fused_step(cost, cur, self.step_size, out=nxt, new_state=True, noise=spec, input_energy=self._e)
+                self.means[s: s + 1].copy_(self._e.mean().reshape(1))  # E(U_{k0 + s}), the INPUT of launch k0 + s
+                cur, nxt = nxt, cur
+            if cur is not self.particles:
+                self.particles.copy_(cur)
+            L.check(L.load().pls_counter_add(self.counter.data_ptr(), self.k, L.stream_ptr()), "pls_counter_add")
+
+        saved = particles.clone()
+        body()  # warm-up outside the capture (workspaces, Gaussian constants, kernel attributes)
+        torch.cuda.synchronize()
+        self.particles.copy_(saved)
+        self.counter.zero_()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(self.graph, stream=side):
+                body()
+        torch.cuda.current_stream().wait_stream(side)
+        self.particles.copy_(saved)
+        self.counter.zero_()
+        self.steps_done = 0
+
+    def eager_steps(self, count: int) -> None:
+        """``count`` steps without the graph, continuing the same noise stream (tail of a run / roll-forward)."""
+        basis, cost = self.pls.basis, self.pls.cost
+        cur, nxt = self.particles, self._pong
+        for _ in range(count):
+            spec = NoiseSpec(seed=self.seed, step=self.steps_done, j_offset=basis.j_offset)
+            basis.fused_step(cost, cur, self.step_size, out=nxt, new_state=True, noise=spec)
+            cur, nxt = nxt, cur
+            self.steps_done += 1
+        if cur is not self.particles:
+            self.particles.copy_(cur)
+        self.counter.fill_(self.steps_done)
+
+    def replay(self) -> torch.Tensor:
+        """K more steps; returns the (K,) host vector [E(U_k0), ..., E(U_{k0+K-1})], k0 = steps done before the call."""
+        self.graph.replay()
+        self.steps_done += self.k
+        return self.means.cpu()
+
+    def roll_back(self) -> None:
+        """Undo the last replay (particles and step counter)."""
+        self.particles.copy_(self._start)
+        self.steps_done -= self.k
+        self.counter.fill_(self.steps_done)

@@ -147,3 +147,61 @@ def _train_pls_two_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs
     if final.data_ptr() != particles.data_ptr():
         particles.copy_(final)
     return particles, energy_potentials
+
+
+def train_pls_captured(pls: PLS, particles: torch.Tensor, number_of_epochs: int, step_size: float,
+                       early_stopper_patience: float, steps_per_replay: int = 16, seed: int | None = None
+                       ) -> Tuple[torch.Tensor, List[float]]:
+    """train_pls for launch-bound problems (extension): K steps and their energies per hipGraph replay
+    (graph.CapturedTraining).  Same loop semantics as experiments/trainers.py:139-162 -- update, energy of the updated
+    particles, early stop, the failing update is kept -- over the library's counter-based noise stream: ``seed`` (one
+    draw from torch's global generator if None) keys it, step t uses counter t.  The result equals the eager loop over
+    that stream exactly (an overshooting replay is rolled back and re-run up to the stop index)."""
+    from .graph import CapturedTraining
+
+    if seed is None:
+        seed = int(torch.randint(0, 2**63 - 1, (1,)).item())
+    early_stopper = EarlyStopper(patience=early_stopper_patience)
+    energies: List[float] = []
+    T, K = number_of_epochs, max(1, min(steps_per_replay, number_of_epochs))
+    if T == 0:
+        return particles, energies
+    cap = CapturedTraining(pls, particles, step_size, K, seed)
+    t = 0  # next plain-loop iteration to judge: needs E(U_{t+1})
+    while t < T:
+        k0 = cap.steps_done
+        if k0 + K <= T:  # a full replay: launches k0 .. k0+K-1 report E(U_k0) .. E(U_{k0+K-1})
+            known = cap.replay().tolist()
+        else:  # fewer than K steps left: finish eagerly, one energy per step
+            known = None
+        if known is not None:
+            stop_at = None
+            for s, e in enumerate(known):
+                it = k0 + s - 1  # E(U_{k0+s}) closes plain-loop iteration k0+s-1
+                if it < 0:
+                    continue  # E(U_0): the plain loop never looks at it
+                if early_stopper.should_stop(loss=e, step_size=step_size):
+                    stop_at = it
+                    break
+                energies.append(e)
+                t = it + 1
+            if stop_at is not None:  # keep U_{stop_at+1}: rewind the replay, roll forward eagerly
+                cap.roll_back()
+                cap.eager_steps(stop_at + 1 - cap.steps_done)
+                return particles, energies
+        else:
+            while t < T:
+                if cap.steps_done < t + 1:
+                    cap.eager_steps(t + 1 - cap.steps_done)
+                e = pls.particle_energy_potential(particles).mean().item()
+                if early_stopper.should_stop(loss=e, step_size=step_size):
+                    return particles, energies
+                energies.append(e)
+                t += 1
+            return particles, energies
+        if cap.steps_done == T:  # all updates done; E(U_T) has no following launch to ride on
+            e = pls.particle_energy_potential(particles).mean().item()
+            if not early_stopper.should_stop(loss=e, step_size=step_size):
+                energies.append(e)
+            return particles, energies
+    return particles, energies

@@ -575,6 +575,39 @@ def test_train_pls_is_pipelined_for_every_native_cost(P, rank_path):
     assert np.allclose(runs["pipelined"][1], want, rtol=1e-8)
 
 
+@pytest.mark.parametrize("cost_idx,epochs,k,patience", [(0, 37, 8, 1e9), (0, 40, 16, 3e-3), (0, 40, 5, 3e-3), (0, 40, 1, 3e-3),
+                                                        (2, 21, 8, 1e9), (2, 30, 4, 1e9), (0, 5, 16, 1e9)])
+def test_captured_training_matches_the_eager_loop(P, cost_idx, epochs, k, patience):
+    """train_pls_captured (K steps + energies per hipGraph replay, roll-back on an overshot stop) against the plain
+    loop over the same counter-based noise stream: identical particles, energies and stop index -- with and without an
+    early stop, epochs not a multiple of K, epochs < K, Gaussian fast path and a generic cost."""
+    pr = make_problem(300, 12, 40, 2, seed=11)
+    ob, gb = build_onb(P, pr)
+    mk = ob.approximation_dimension
+    name, oc, gc = make_costs(P, pr["y"], pr["fstar"], pr["gen"])[cost_idx]
+    eta = 1e-3 if cost_idx == 0 else 1e-6
+    seed = 424242
+    pls = P.pkg.PLS(gb, gc)
+    # plain loop over the same stream
+    u = cu(pr["u"][:mk].contiguous())
+    nxt = torch.empty_like(u)
+    stopper = P.pkg.EarlyStopper(patience=patience)
+    want_e = []
+    for t in range(epochs):
+        gb.fused_step(gc, u, eta, out=nxt, new_state=True, noise=P.basis.NoiseSpec(seed=seed, step=t))
+        u, nxt = nxt, u
+        e = pls.particle_energy_potential(u).mean().item()
+        if stopper.should_stop(loss=e, step_size=eta):
+            break
+        want_e.append(e)
+    got_u, got_e = P.pkg.train_pls_captured(pls, cu(pr["u"][:mk].contiguous()), epochs, eta, patience, steps_per_replay=k, seed=seed)
+    assert len(got_e) == len(want_e), (len(got_e), len(want_e))
+    if patience < 1e8:
+        assert len(want_e) < epochs, "this case is meant to stop early"
+    assert np.allclose(got_e, want_e, rtol=1e-12)
+    assert torch.equal(got_u, u)
+
+
 def test_random_shape_sweep_against_the_oracle(P, rank_path):
     """Seeded sweep over ragged (N, M, J, D): one Gaussian and one non-Gaussian step + energy per draw against the
     oracle, through whichever path `rank_path` selects (M <= 128 throughout, so `small_rank` really is the fused
