@@ -8,7 +8,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libplship.so")
+# the in-tree build; PLSHIP_LIBRARY points at another build of the same ABI (A/B runs, tools/ab_smallrank.py)
+LIB_PATH = os.environ.get("PLSHIP_LIBRARY") or os.path.join(_HERE, "libplship.so")
 
 # enums (include/plship.h)
 KERNEL_RBF_ARD, KERNEL_LINEAR = 0, 1
