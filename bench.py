@@ -167,6 +167,8 @@ def main():
                     help="step cap of the wall-clock-to-converged-energy run (0 = skip it)")
     ap.add_argument("--ipb-steps", type=int, default=3, help="timed steps of the inducing-point-basis extra (0 = skip)")
     ap.add_argument("--select-inducing", action="store_true", help="also time the greedy inducing-point selection (setup)")
+    ap.add_argument("--eigh-device", default="cpu", choices=["cpu", "cuda"],
+                    help="where the one-time eigh of k(Z,Z)/M runs (cpu = the reference's host LAPACK call)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="development aid: run rank 0's particle shard of an N-GPU job on ONE GPU (no collectives); "
                          "the JSON line is marked emulated and is not a scaling result")
@@ -200,7 +202,8 @@ def main():
     log("synthetic data ready")
     t_setup = time.perf_counter()
     kernel = pkg.PLSKernel(pkg.ARDKernel(ls, 1.0), z)
-    basis = OrthonormalBasis(kernel, z, x, eigenvalue_threshold=cfg.get("threshold", 0.0), verbose=False, keep_gram=False)
+    basis = OrthonormalBasis(kernel, z, x, eigenvalue_threshold=cfg.get("threshold", 0.0), verbose=False, keep_gram=False,
+                             eigh_device=args.eigh_device)
     basis.workspace_bytes = int(args.workspace_gb * (1 << 30))
     mk = basis.approximation_dimension
     if cfg["cost"] == "poisson":
