@@ -150,6 +150,19 @@ def test_reference_goldens_bases(P, G):
     assert np.allclose(ipb.calculate_energy_potential(u, ones), G["ipb_energy_potential"]["value"], rtol=1e-4)
 
 
+def test_eigh_on_the_gpu_gives_the_same_basis_up_to_the_gauge(P):
+    """OrthonormalBasis(eigh_device="cuda"): same spectrum, and the gauge-invariant operator A^T diag(lam) A
+    (= k(X,Z) V diag(1/M_k) V^T k(Z,X)) equals the host-LAPACK one."""
+    pr = make_problem(400, 30, 8, 3, seed=21)
+    gk = P.pkg.ARDKernel(pr["ls"], 1.3)
+    bases = [P.basis.OrthonormalBasis(P.pkg.PLSKernel(gk, pr["z"]), pr["z"], pr["x"], 1e-10, verbose=False, eigh_device=dev)
+             for dev in ("cpu", "cuda")]
+    assert bases[0].approximation_dimension == bases[1].approximation_dimension
+    assert relerr(bases[1].eigenvalues, bases[0].eigenvalues) < 1e-10
+    ops = [(b._A.T * b.eigenvalues[None, :]) @ b._A for b in bases]
+    assert relerr(ops[1], ops[0]) < 1e-8
+
+
 def test_reference_goldens_onb_forward_with_oracle_gauge(P, G):
     fx = G["basis_fixture"]
     z, x = torch.tensor(fx["x_induce"]), torch.tensor(fx["x_train"])
