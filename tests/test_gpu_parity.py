@@ -1278,3 +1278,8 @@ def test_train_pls_runner_end_to_end(P):
         _, e = P.pkg.train_pls(pls, u0.clone(), int(2e-3 / s), s, 1.0)
         finals.append(e[-1] if e else float("inf"))
     assert lr_a == steps[int(np.argmin(finals))]
+    # the graph-replay training loop plugs in as train_fn (launch-bound problem sizes); reproducible for the same reason
+    out_d, lr_d, n_d = train_pls_runner(metric_to_optimise="loss", train_fn=P.pkg.train_pls_captured, **kw)
+    out_e, lr_e, n_e = train_pls_runner(metric_to_optimise="loss", train_fn=P.pkg.train_pls_captured, **kw)
+    assert lr_d in steps and n_d == int(2e-3 / lr_d) and torch.isfinite(out_d).all()
+    assert lr_d == lr_e and torch.equal(out_d, out_e)
