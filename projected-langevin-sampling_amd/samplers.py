@@ -14,16 +14,26 @@ from . import _lib as L
 from .kernel import _dev
 
 
+#: where the covariance eigendecompositions of prediction run: "cpu" = the reference's host LAPACK call; "cuda" = the same
+#: factorisation through torch on the GPU (an (M_k + N*)-sized eigh: seconds on the host for a few thousand test points).
+#: Both give a valid factor Q sqrt(Lambda) of the same covariance; the SAMPLE differs (another eigenvector gauge).
+DEFAULT_EIGH_DEVICE = "cpu"
+
+
 def sample_multivariate_normal(
     mean: torch.Tensor,
     cov: torch.Tensor,
     size: Tuple[int] | None = None,
     seed: int | None = None,
+    eigh_device: str | None = None,
 ) -> torch.Tensor:
     """samplers.py:6-44.  Returns a (size..., n) float64 device tensor."""
     generator = torch.Generator().manual_seed(seed) if seed is not None else None
     size = (1,) if not size else size
-    eigenvalues, eigenvectors = torch.linalg.eigh(cov.detach().cpu().to(torch.float64))  # samplers.py:27
+    where = eigh_device or DEFAULT_EIGH_DEVICE
+    assert where in ("cpu", "cuda"), "eigh_device must be 'cpu' or 'cuda'"
+    c64 = cov.detach().to(torch.float64)
+    eigenvalues, eigenvectors = torch.linalg.eigh(c64.cpu() if where == "cpu" else _dev(c64))  # samplers.py:27
     eigenvalues = torch.clip(eigenvalues, 0, None)
     n = eigenvalues.shape[0]
     normal_sample = torch.normal(mean=0.0, std=1.0, size=(n, *size), generator=generator)  # samplers.py:30-35

@@ -251,6 +251,23 @@ def test_reference_vectors_costs_and_links(P, V):
     assert np.allclose(c.calculate_cost_derivative(f).cpu().numpy(), V["multimodal_identity_dcost"], rtol=1e-10)
 
 
+def test_sampler_eigh_on_either_device_colours_the_noise_correctly(P):
+    """sample_multivariate_normal(eigh_device=...): both factorisations are factors of the SAME covariance (the draws
+    themselves differ: the eigenvector gauge is the library's)."""
+    from projected_langevin_sampling_amd.samplers import sample_multivariate_normal
+
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(12, 12, generator=g, dtype=torch.float64)
+    cov = a @ a.T / 12 + 0.1 * torch.eye(12, dtype=torch.float64)
+    mean = torch.randn(12, generator=g, dtype=torch.float64)
+    for dev in ("cpu", "cuda"):
+        x = sample_multivariate_normal(mean, cov, size=(40000,), seed=1, eigh_device=dev).cpu()  # (40000, 12)
+        assert x.shape == (40000, 12)
+        emp = torch.cov(x.T)
+        assert (emp - cov).abs().max().item() < 0.05 * cov.abs().max().item(), dev
+        assert (x.mean(0) - mean).abs().max().item() < 0.03, dev
+
+
 def test_reference_vectors_sampler(P, V):
     s = P.samplers.sample_multivariate_normal(torch.zeros(6), torch.tensor(V["mvn_cov"]), (9,), seed=7)
     assert np.allclose(s.cpu().numpy(), V["mvn_sample_seed7"], rtol=1e-10, atol=1e-12)
