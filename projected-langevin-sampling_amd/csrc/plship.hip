@@ -1194,14 +1194,6 @@ static int stream_cost(const double *Lf, int64_t ldlf, const double *Lb, int64_t
   return PLS_OK;
 }
 
-static int64_t pick_chunk(int64_t n, size_t avail_bytes, int64_t j, size_t per_row_extra_bytes) {
-  // rows of G (j doubles each) that fit; at least 128-row granularity
-  const size_t per_row = (size_t)j * sizeof(double) + per_row_extra_bytes;
-  int64_t rows = (int64_t)(avail_bytes / per_row);
-  if (rows >= n) return n;
-  rows = rows / 128 * 128;
-  return rows;
-}
 
 }  // namespace plship
 
