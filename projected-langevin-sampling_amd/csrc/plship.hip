@@ -11,71 +11,17 @@
 #include <vector>
 
 #include "../../include/plship.h"
+#include "common.h"
 #include "cost_device.h"
 #include "gemm_tn_f64.h"
 #include "philox.h"
 #include "small_rank.h"
+#include "small_rank_launch.h"
 
 namespace plship {
 
-// ---------------------------------------------------------------------------------------------------------------
-// error plumbing
-// ---------------------------------------------------------------------------------------------------------------
-static thread_local std::string g_last_error;
-
-static int fail(int code, const char *fmt, ...) {
-  char buf[512];
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(buf, sizeof(buf), fmt, ap);
-  va_end(ap);
-  g_last_error = buf;
-  return code;
-}
-
-#define PLS_REQUIRE(cond, ...) \
-  do {                         \
-    if (!(cond)) return fail(PLS_ERR_INVALID_ARGUMENT, __VA_ARGS__); \
-  } while (0)
-
-static int check_launch(const char *what) {
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail(PLS_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
-  return PLS_OK;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// per-launch timeline (pls_timeline_begin / _end): events live outside the step path's no-allocation rule because
-// they are created in begin(), never inside a launch function
-// ---------------------------------------------------------------------------------------------------------------
-struct Timeline {
-  bool on = false;
-  int capacity = 0, count = 0;
-  std::vector<hipEvent_t> ev;  // 2 per launch
-  std::vector<int> tag;
-};
-static thread_local Timeline g_tl;
-
-struct LaunchScope {  // records the bracketing events of one launch when the timeline is on
-  hipStream_t st;
-  int slot;
-  LaunchScope(int tag, hipStream_t s) : st(s), slot(-1) {
-    if (!g_tl.on) return;
-    if (g_tl.count < g_tl.capacity) {
-      slot = g_tl.count;
-      g_tl.tag[slot] = tag;
-      (void)hipEventRecord(g_tl.ev[2 * slot], st);
-    }
-    ++g_tl.count;
-  }
-  ~LaunchScope() {
-    if (slot >= 0) (void)hipEventRecord(g_tl.ev[2 * slot + 1], st);
-  }
-};
-
-static inline hipStream_t S(void *stream) { return reinterpret_cast<hipStream_t>(stream); }
-__host__ __device__ static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
-static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+thread_local std::string g_last_error;
+thread_local Timeline g_tl;
 
 // ---------------------------------------------------------------------------------------------------------------
 // GEMM epilogues that need the cost functions / the noise generator
@@ -1039,49 +985,7 @@ static bool small_rank_ok(const double *Lb, int64_t ldlb, int64_t kdim) {
   return kdim >= 1 && kdim <= g_small_rank_max.load() && (ldlb & 1) == 0 && (reinterpret_cast<uintptr_t>(Lb) & 15) == 0;
 }
 
-template <int MODE, int COST, int LINK>
-static int launch_small_rank_cl(const SmallRankP &p, int64_t nsplit, hipStream_t st) {
-  const int kb = (int)cdiv(p.K, 16);
-  dim3 grid((unsigned)cdiv(p.J, 64), (unsigned)nsplit);
-  LaunchScope scope(MODE == SR_MODE_VALUE ? PLS_TAG_SMALL_RANK_VALUE : PLS_TAG_SMALL_RANK_DRIFT, st);
-#define PLS_SR_CASE(KB)                                                                                               \
-  case KB: {                                                                                                          \
-    static bool attr_set = false;                                                                                     \
-    if (!attr_set) {                                                                                                  \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&small_rank_kernel<KB, MODE, COST, LINK>),    \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sr_lds_bytes<KB>());       \
-      if (e != hipSuccess) return fail(PLS_ERR_HIP, "small_rank: hipFuncSetAttribute: %s", hipGetErrorString(e));    \
-      attr_set = true;                                                                                                \
-    }                                                                                                                 \
-    hipLaunchKernelGGL((small_rank_kernel<KB, MODE, COST, LINK>), grid, dim3(256), sr_lds_bytes<KB>(), st, p);       \
-  } break;
-  switch (kb) {
-    PLS_SR_CASE(1)
-    PLS_SR_CASE(2)
-    PLS_SR_CASE(3)
-    PLS_SR_CASE(4)
-    PLS_SR_CASE(5)
-    PLS_SR_CASE(6)
-    PLS_SR_CASE(7)
-    PLS_SR_CASE(8)
-    default: return fail(PLS_ERR_INVALID_ARGUMENT, "small_rank: rank %d > 128", p.K);
-  }
-#undef PLS_SR_CASE
-  return check_launch("small_rank");
-}
-
-// the cost/link pairs the reference's experiments use get their own instantiation; anything else the run-time switch
-template <int MODE>
-static int launch_small_rank(const SmallRankP &p, int64_t nsplit, hipStream_t st) {
-  const int c = p.cp.cost, l = p.cp.link;
-  if (c == PLS_COST_GAUSSIAN && l == PLS_LINK_IDENTITY) return launch_small_rank_cl<MODE, PLS_COST_GAUSSIAN, PLS_LINK_IDENTITY>(p, nsplit, st);
-  if (c == PLS_COST_POISSON && l == PLS_LINK_SQUARE) return launch_small_rank_cl<MODE, PLS_COST_POISSON, PLS_LINK_SQUARE>(p, nsplit, st);
-  if (c == PLS_COST_BERNOULLI && l == PLS_LINK_SIGMOID) return launch_small_rank_cl<MODE, PLS_COST_BERNOULLI, PLS_LINK_SIGMOID>(p, nsplit, st);
-  if (c == PLS_COST_BERNOULLI && l == PLS_LINK_PROBIT) return launch_small_rank_cl<MODE, PLS_COST_BERNOULLI, PLS_LINK_PROBIT>(p, nsplit, st);
-  if (c == PLS_COST_STUDENT_T && l == PLS_LINK_IDENTITY) return launch_small_rank_cl<MODE, PLS_COST_STUDENT_T, PLS_LINK_IDENTITY>(p, nsplit, st);
-  if (c == PLS_COST_MULTIMODAL && l == PLS_LINK_IDENTITY) return launch_small_rank_cl<MODE, PLS_COST_MULTIMODAL, PLS_LINK_IDENTITY>(p, nsplit, st);
-  return launch_small_rank_cl<MODE, -1, -1>(p, nsplit, st);
-}
+// (the launchers of the fused small-rank kernels live in their own translation units: small_rank_launch.h)
 
 // Streams N in chunks:  G_c = cost'(Lf[:, chunk]^T V)  ->  D (+)= Lb[chunk, :]^T G_c.
 //   Lf (K x N, ldlf): forward operand (A or Kzx), V (K x J) particles in the basis the forward map expects
@@ -1116,7 +1020,7 @@ static int stream_drift(const double *Lf, int64_t ldlf, const double *Lb, int64_
     if (ns <= max_slabs && (!es || ns <= es->rows_cap)) {
       SmallRankP p{Lb, ldlb, V, ldv, y, n, j, (int)kdim, rows_per_split, D, ldd, slab_stride, cp, es ? es->partial : nullptr, j};
       *slabs_used = ns;
-      int rc = es ? launch_small_rank<SR_MODE_DRIFT_VALUE>(p, ns, st) : launch_small_rank<SR_MODE_DRIFT>(p, ns, st);
+      int rc = es ? launch_small_rank_drift_value(p, ns, st) : launch_small_rank_drift(p, ns, st);
       if (rc || !es) return rc;
       return reduce_partials(ns, 0, true);
     }
@@ -1172,7 +1076,7 @@ static int stream_cost(const double *Lf, int64_t ldlf, const double *Lb, int64_t
     const int64_t ns = small_rank_splits(j, n, &rows_per_split);
     if (ns <= partial_rows) {
       SmallRankP p{Lb, ldlb, V, ldv, y, n, j, (int)kdim, rows_per_split, partial, j, j, cp, nullptr, 0};
-      int rc = launch_small_rank<SR_MODE_VALUE>(p, ns, st);
+      int rc = launch_small_rank_value(p, ns, st);
       if (rc) return rc;
       hipLaunchKernelGGL(column_reduce_kernel, dim3((unsigned)cdiv(j, 256)), dim3(256), 0, st, partial, j, ns, j, e_out, 0,
                          prior_kind, P, ldp, m, lam, scale, 1.0, (const double *)nullptr);

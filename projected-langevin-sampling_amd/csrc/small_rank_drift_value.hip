@@ -1,0 +1,6 @@
+// libplship.so: the SR_MODE_DRIFT_VALUE instantiations of the fused small-rank kernel.
+#include "small_rank_launch.inc"
+
+namespace plship {
+int launch_small_rank_drift_value(const SmallRankP &p, int64_t nsplit, hipStream_t st) { return launch_small_rank<SR_MODE_DRIFT_VALUE>(p, nsplit, st); }
+}  // namespace plship
