@@ -135,6 +135,9 @@ typedef struct {
   int64_t ldw;
   const double *LcT; /* may be NULL when noise is injected already coloured */
   int64_t ldlct;
+  const double *B; /* optional Gaussian fast path: Kzx Kxz (M x M), see pls_ipb_build_gaussian */
+  int64_t ldb;
+  const double *c; /* optional: Kzx y (M), then y^T y */
 } pls_ipb_desc;
 
 const char *pls_last_error(void);
@@ -300,15 +303,21 @@ int pls_ipb_particle_update(const pls_ipb_desc *basis, const double *U, int64_t 
 
 size_t pls_ipb_step_workspace_bytes(const pls_ipb_desc *basis, int64_t j, int64_t n_chunk);
 /* energy_in (optional, J doubles): receives the energy of the INPUT particles (cost of the same F the drift uses +
- * the prior term) as a by-product, like pls_onb_step. */
+ * the prior term) as a by-product, like pls_onb_step.  If basis->B/c are set and the cost is Gaussian/identity the
+ * M x M x J fast path is taken unless force_generic != 0. */
 int pls_ipb_step(const pls_ipb_desc *basis, const pls_cost_desc *cost, const double *y, double *U, int64_t ldu,
                  int64_t j, double eta, const pls_noise_desc *noise, double *out, int64_t ldo, int32_t out_mode,
-                 double *energy_in, void *workspace, size_t workspace_bytes, void *stream);
+                 int32_t force_generic, double *energy_in, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Gaussian/identity fast path constants of the inducing-point basis: B = Kzx Kxz (M x M), c[0..M) = Kzx y, c[M] = y^T y.
+ * With V = K^-1 U the data drift Kzx (Kxz V - y) / sigma2 (inducing_point.py:117-150 with gaussian.py:86-88) is
+ * (B V - c) / sigma2 and the cost (gaussian.py:63-73) the quadratic form (v^T B v - 2 c^T v + y^T y) / (2 sigma2). */
+int pls_ipb_build_gaussian(const pls_ipb_desc *basis, const double *y, double *B, int64_t ldb, double *c, void *stream);
 
 /* e(J) = cost_j + (M/2) * ||W U_j||^2 (inducing_point.py:95-115). */
 size_t pls_ipb_energy_workspace_bytes(const pls_ipb_desc *basis, int64_t j, int64_t n_chunk);
 int pls_ipb_energy(const pls_ipb_desc *basis, const pls_cost_desc *cost, const double *y, const double *U,
-                   int64_t ldu, int64_t j, double *e, void *workspace, size_t workspace_bytes, void *stream);
+                   int64_t ldu, int64_t j, double *e, int32_t force_generic, void *workspace, size_t workspace_bytes, void *stream);
 
 /* e(J) = cost_j + (M/2) * ||W U_j||^2 with the cost vector handed in (inducing_point.py:95-115).
  * workspace: m*j doubles. */

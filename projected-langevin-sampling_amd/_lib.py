@@ -75,6 +75,9 @@ class IpbDesc(C.Structure):
         ("ldw", C.c_int64),
         ("LcT", C.c_void_p),
         ("ldlct", C.c_int64),
+        ("B", C.c_void_p),
+        ("ldb", C.c_int64),
+        ("c", C.c_void_p),
     ]
 
 
@@ -115,9 +118,10 @@ SIGNATURES = {
     "pls_ipb_forward": (C.c_int, [_ID, _P, _I64, _I64, _P, _I64, _P, _SZ, _P]),
     "pls_ipb_particle_update": (C.c_int, [_ID, _P, _I64, _P, _I64, _I64, _D, _ND, _P, _I64, _P, _SZ, _P]),
     "pls_ipb_step_workspace_bytes": (_SZ, [_ID, _I64, _I64]),
-    "pls_ipb_step": (C.c_int, [_ID, _CD, _P, _P, _I64, _I64, _D, _ND, _P, _I64, _I32, _P, _P, _SZ, _P]),
+    "pls_ipb_step": (C.c_int, [_ID, _CD, _P, _P, _I64, _I64, _D, _ND, _P, _I64, _I32, _I32, _P, _P, _SZ, _P]),
+    "pls_ipb_build_gaussian": (C.c_int, [_ID, _P, _P, _I64, _P, _P]),
     "pls_ipb_energy_workspace_bytes": (_SZ, [_ID, _I64, _I64]),
-    "pls_ipb_energy": (C.c_int, [_ID, _CD, _P, _P, _I64, _I64, _P, _P, _SZ, _P]),
+    "pls_ipb_energy": (C.c_int, [_ID, _CD, _P, _P, _I64, _I64, _P, _I32, _P, _SZ, _P]),
 }
 
 _lib = None

@@ -44,19 +44,44 @@ class InducingPointBasis(PLSBasis):
         # k(X,Z) as its own k-major operand for the back-projection k(Z,X) G
         self._Kxz = alloc_matrix(n, m, dev)
         self._Kxz.copy_(self.base_gram_induce_train.T)
+        self._B = None  # Gaussian fast path constants, keyed by the y they were built from
+        self._c = None
+        self._gauss_key = None
 
     @property
     def approximation_dimension(self) -> int:
         return self.x_induce.shape[0]  # :52-58
 
-    def _desc(self) -> L.IpbDesc:
+    def _desc(self, with_gaussian: bool = False) -> L.IpbDesc:
         d = L.IpbDesc()
         d.m, d.n = self.approximation_dimension, self._n
         d.Kzx, d.ldkzx = self.base_gram_induce_train.data_ptr(), L.ld(self.base_gram_induce_train)
         d.Kxz, d.ldkxz = self._Kxz.data_ptr(), L.ld(self._Kxz)
         d.W, d.ldw = self._W.data_ptr(), L.ld(self._W)
         d.LcT, d.ldlct = self._LcT.data_ptr(), L.ld(self._LcT)
+        if with_gaussian and self._B is not None:
+            d.B, d.ldb, d.c = self._B.data_ptr(), L.ld(self._B), self._c.data_ptr()
         return d
+
+    def prepare_gaussian(self, y_dev: torch.Tensor) -> None:
+        """B = k(Z,X) k(X,Z), c = k(Z,X) y: the Gaussian/identity step becomes two M x M x J products (pls_ipb_build_gaussian)."""
+        key = (y_dev.data_ptr(), y_dev._version)
+        if self._gauss_key == key:
+            return
+        m = self.approximation_dimension
+        self._B = alloc_matrix(m, m, y_dev.device)
+        self._c = torch.empty(m + 1, dtype=torch.float64, device=y_dev.device)
+        L.check(
+            L.load().pls_ipb_build_gaussian(self._desc(), y_dev.data_ptr(), self._B.data_ptr(), L.ld(self._B), self._c.data_ptr(),
+                                            L.stream_ptr()),
+            "pls_ipb_build_gaussian",
+        )
+        self._gauss_key = key
+
+    @staticmethod
+    def _is_gaussian(cost, force_generic: bool) -> bool:
+        cd = cost.desc()
+        return cd.cost == L.COST_GAUSSIAN and cd.link == L.LINK_IDENTITY and not force_generic
 
     def _initialise_particles(self, number_of_particles: int, noise_only: bool = True, seed: int | None = None) -> torch.Tensor:
         particle_noise = self._initialise_particles_noise(number_of_particles=number_of_particles, seed=seed)
@@ -128,7 +153,10 @@ class InducingPointBasis(PLSBasis):
             return out
         assert out.data_ptr() != u.data_ptr(), "fused_step: out must not alias particles"
         lib = L.load()
-        desc = self._desc()
+        gaussian = self._is_gaussian(cost, force_generic)
+        if gaussian:
+            self.prepare_gaussian(cost.y_device())
+        desc = self._desc(with_gaussian=gaussian)
         need_min = lib.pls_ipb_step_workspace_bytes(desc, j, 128)
         need_full = lib.pls_ipb_step_workspace_bytes(desc, j, self._n)
         ws_bytes = max(need_min, min(need_full, self.workspace_bytes))
@@ -136,8 +164,8 @@ class InducingPointBasis(PLSBasis):
         nd = (noise if noise is not None else self._draw_noise_spec(None)).desc()
         L.check(
             lib.pls_ipb_step(desc, cost.desc(), cost.y_device().data_ptr(), u.data_ptr(), L.ld(u), j, float(step_size), nd,
-                             out.data_ptr(), L.ld(out), L.OUT_NEW_STATE if new_state else L.OUT_DELTA, L.ptr(input_energy),
-                             ws.data_ptr(), ws_bytes, L.stream_ptr()),
+                             out.data_ptr(), L.ld(out), L.OUT_NEW_STATE if new_state else L.OUT_DELTA, 1 if force_generic else 0,
+                             L.ptr(input_energy), ws.data_ptr(), ws_bytes, L.stream_ptr()),
             "pls_ipb_step",
         )
         return out
@@ -145,17 +173,20 @@ class InducingPointBasis(PLSBasis):
     def supports_input_energy(self, cost) -> bool:
         return bool(cost.is_native())
 
-    def fused_particle_energy(self, cost, particles: torch.Tensor) -> torch.Tensor:
+    def fused_particle_energy(self, cost, particles: torch.Tensor, force_generic: bool = False) -> torch.Tensor:
         u = _rows_contiguous(L.require_gpu_tensor(particles, "particles"))
         j = u.shape[1]
         lib = L.load()
-        desc = self._desc()
+        gaussian = self._is_gaussian(cost, force_generic)
+        if gaussian:
+            self.prepare_gaussian(cost.y_device())
+        desc = self._desc(with_gaussian=gaussian)
         ws_bytes = lib.pls_ipb_energy_workspace_bytes(desc, j, self._n)
         ws = self._workspace(ws_bytes, u.device)
         e = torch.empty(j, dtype=torch.float64, device=u.device)
         L.check(
             lib.pls_ipb_energy(desc, cost.desc(), cost.y_device().data_ptr(), u.data_ptr(), L.ld(u), j, e.data_ptr(),
-                               ws.data_ptr(), ws_bytes, L.stream_ptr()),
+                               1 if force_generic else 0, ws.data_ptr(), ws_bytes, L.stream_ptr()),
             "pls_ipb_energy",
         )
         return e

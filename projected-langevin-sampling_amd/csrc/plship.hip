@@ -616,7 +616,9 @@ __global__ __launch_bounds__(256) void langevin_update_kernel(double *out, int64
                                                                const double *__restrict__ P, int64_t ldp,
                                                                const double *__restrict__ lam, double pconst,
                                                                int64_t rows, int64_t j, double eta, double sq2eta,
-                                                               int add_u, NoiseP nz) {
+                                                               int add_u, NoiseP nz,
+                                                               const double *__restrict__ dsub = nullptr,
+                                                               double dsub_scale = 0.0) {
   const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (col >= j) return;
   const int64_t npairs = cdiv(rows, 8) * 4;
@@ -637,11 +639,33 @@ __global__ __launch_bounds__(256) void langevin_update_kernel(double *out, int64
         const double ps = lam ? 1.0 / lam[i] : pconst;
         double drift = D[i * ldd + col];
         for (int sl = 1; sl < nslab; ++sl) drift += D[sl * slab_stride + i * ldd + col];  // split-K slabs, fixed order
+        if (dsub) drift -= dsub_scale * dsub[i];  // (IPB Gaussian fast path: drift = (B V - c) / sigma2)
         const double d = -eta * drift - eta * ps * P[i * ldp + col] + sq2eta * (h ? z1 : z0);
         out[i * ldo + col] = add_u ? U[i * ldu + col] + d : d;
       }
     }
   }
+}
+
+// IPB Gaussian fast path: e[col] = sum_i v (0.5 d - c_i / sigma2) + (M/2) v^2  + y^T y / (2 sigma2),
+//   v = V[i][col] = (K^-1 U)_i,  d = D[i][col] = (Kzx Kxz V)_i / sigma2  (the quadratic form of the Gaussian cost in V).
+// 64 columns x 4 row slices per block, slices summed through LDS in a fixed order.
+__global__ __launch_bounds__(256) void ipb_gaussian_energy_kernel(const double *__restrict__ V, int64_t ldv,
+                                                                   const double *__restrict__ D, int64_t ldd,
+                                                                   const double *__restrict__ c, int64_t m, int64_t j,
+                                                                   double inv_noise, double mhalf, double *__restrict__ e) {
+  __shared__ double part[4][64];
+  const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int64_t col = (int64_t)blockIdx.x * 64 + cl;
+  double s = 0.0;
+  if (col < j)
+    for (int64_t i = sl; i < m; i += 4) {
+      const double v = V[i * ldv + col];
+      s += v * (0.5 * D[i * ldd + col] - inv_noise * c[i]) + mhalf * v * v;
+    }
+  part[sl][cl] = s;
+  __syncthreads();
+  if (sl == 0 && col < j) e[col] = ((part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl])) + 0.5 * inv_noise * c[m];
 }
 
 // e[col] = sum_p partial[p][col] + yscale * (*yty)
@@ -1559,6 +1583,7 @@ static int validate_ipb(const pls_ipb_desc *b) {
   PLS_REQUIRE(b->Kzx && b->Kxz && b->W, "ipb: Kzx, Kxz and W must be set");
   PLS_REQUIRE(b->ldkzx >= b->n && b->ldkxz >= b->m && b->ldw >= b->m, "ipb: leading dimension too small");
   if (b->LcT) PLS_REQUIRE(b->ldlct >= b->m, "ipb: ldlct < m");
+  if (b->B) PLS_REQUIRE(b->ldb >= b->m && b->c, "ipb: fast-path constants need ldb >= m and c");
   return PLS_OK;
 }
 
@@ -1580,7 +1605,7 @@ int pls_ipb_forward(const pls_ipb_desc *basis, const double *U, int64_t ldu, int
 // shared tail of the IPB update: out = [U +] -eta*D - eta*M*V + sqrt(2 eta) e
 static int ipb_finish(const pls_ipb_desc *basis, const double *U, int64_t ldu, const double *D, int nslab,
                       int64_t slab_stride, const double *V, int64_t j, double eta, const pls_noise_desc *noise, double *out, int64_t ldo, int add_u,
-                      double *xi_buf, double *e_buf, hipStream_t st) {
+                      double *xi_buf, double *e_buf, hipStream_t st, const double *dsub = nullptr, double dsub_scale = 0.0) {
   NoiseP nz = make_noisep(noise);
   if (nz.kind == PLS_NOISE_PHILOX) {
     if (!basis->LcT) return fail(PLS_ERR_INVALID_ARGUMENT, "ipb: Philox noise needs the Cholesky factor LcT");
@@ -1597,8 +1622,29 @@ static int ipb_finish(const pls_ipb_desc *basis, const double *U, int64_t ldu, c
   }
   hipLaunchKernelGGL(langevin_update_kernel, dim3((unsigned)cdiv(j, 256), rows_grid(cdiv(basis->m, 8) * 4)), dim3(256), 0, st,
                      out, ldo, U, ldu, D, j, nslab, slab_stride, V, j, (const double *)nullptr, (double)basis->m, basis->m, j,
-                     eta, sqrt(2.0 * eta), add_u, nz);
+                     eta, sqrt(2.0 * eta), add_u, nz, dsub, dsub_scale);
   return check_launch("langevin_update");
+}
+
+static bool ipb_fast_path(const pls_ipb_desc *b, const pls_cost_desc *c, int force_generic) {
+  return !force_generic && b->B && b->c && c->cost == PLS_COST_GAUSSIAN && c->link == PLS_LINK_IDENTITY;
+}
+
+// Gaussian/identity constants of the inducing-point basis: B = Kzx Kxz (M x M), c[0..M) = Kzx y, c[M] = y^T y.
+// With V = K^-1 U the data drift is Kzx (Kxz V - y) / sigma2 = (B V - c) / sigma2: two M x M x J products per step
+// instead of two N x M x J ones (the same algebra as pls_onb_build_gaussian).
+int pls_ipb_build_gaussian(const pls_ipb_desc *basis, const double *y, double *B, int64_t ldb, double *c, void *stream) {
+  int rc = validate_ipb(basis);
+  if (rc) return rc;
+  PLS_REQUIRE(y && B && c && ldb >= basis->m, "ipb_build_gaussian: bad arguments");
+  rc = pls_gemm_tn(basis->Kxz, basis->ldkxz, basis->Kxz, basis->ldkxz, B, ldb, basis->m, basis->m, basis->n, 1.0, 0.0, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(matvec_rows_kernel, dim3((unsigned)basis->m), dim3(256), 0, S(stream), basis->Kzx, basis->ldkzx,
+                     basis->n, y, c);
+  rc = check_launch("matvec_rows");
+  if (rc) return rc;
+  hipLaunchKernelGGL(matvec_rows_kernel, dim3(1), dim3(256), 0, S(stream), y, basis->n, basis->n, y, c + basis->m);  // y^T y
+  return check_launch("matvec_rows");
 }
 
 int pls_ipb_particle_update(const pls_ipb_desc *basis, const double *U, int64_t ldu, const double *G, int64_t ldg,
@@ -1633,8 +1679,8 @@ size_t pls_ipb_step_workspace_bytes(const pls_ipb_desc *basis, int64_t j, int64_
 }
 
 int pls_ipb_step(const pls_ipb_desc *basis, const pls_cost_desc *cost, const double *y, double *U, int64_t ldu, int64_t j,
-                 double eta, const pls_noise_desc *noise, double *out, int64_t ldo, int32_t out_mode, double *energy_in,
-                 void *workspace, size_t workspace_bytes, void *stream) {
+                 double eta, const pls_noise_desc *noise, double *out, int64_t ldo, int32_t out_mode, int32_t force_generic,
+                 double *energy_in, void *workspace, size_t workspace_bytes, void *stream) {
   int rc = validate_ipb(basis);
   if (rc) return rc;
   rc = validate_cost(cost);
@@ -1663,6 +1709,18 @@ int pls_ipb_step(const pls_ipb_desc *basis, const pls_cost_desc *cost, const dou
   hipStream_t st = S(stream);
   rc = pls_gemm_tn(basis->W, basis->ldw, U, ldu, V, j, basis->m, j, basis->m, 1.0, 0.0, stream);
   if (rc) return rc;
+  if (ipb_fast_path(basis, cost, force_generic)) {
+    const double inv_noise = 1.0 / cost->p[0];
+    rc = pls_gemm_tn(basis->B, basis->ldb, V, j, D, j, basis->m, j, basis->m, inv_noise, 0.0, stream);  // B symmetric
+    if (rc) return rc;
+    if (energy_in) {
+      hipLaunchKernelGGL(ipb_gaussian_energy_kernel, dim3((unsigned)cdiv(j, 64)), dim3(256), 0, st, V, j, D, j, basis->c,
+                         basis->m, j, inv_noise, 0.5 * (double)basis->m, energy_in);
+      rc = check_launch("ipb_gaussian_energy");
+      if (rc) return rc;
+    }
+    return ipb_finish(basis, U, ldu, D, 1, (int64_t)0, V, j, eta, noise, out, ldo, out_mode, xi, e, st, basis->c, inv_noise);
+  }
   EnergySink sink;
   if (energy_in) {  // e_j = cost_j(F(U)) + (M/2) ||K^-1 U_j||^2 of the INPUT particles (inducing_point.py:95-115)
     sink.partial = vpart;
@@ -1686,11 +1744,13 @@ size_t pls_ipb_energy_workspace_bytes(const pls_ipb_desc *basis, int64_t j, int6
   if (!basis || j <= 0) return 0;
   if (n_chunk <= 0 || n_chunk > basis->n) n_chunk = basis->n;
   const int64_t parts = cdiv(n_chunk, 64) < 2 ? 2 : cdiv(n_chunk, 64);
-  return align_up((size_t)basis->m * j * sizeof(double), 256) + (size_t)parts * j * sizeof(double);
+  const size_t mj = align_up((size_t)basis->m * j * sizeof(double), 256);
+  const size_t generic = mj + (size_t)parts * j * sizeof(double);
+  return generic > 2 * mj ? generic : 2 * mj;  // (the Gaussian fast path keeps V and B V)
 }
 
 int pls_ipb_energy(const pls_ipb_desc *basis, const pls_cost_desc *cost, const double *y, const double *U, int64_t ldu,
-                   int64_t j, double *e, void *workspace, size_t workspace_bytes, void *stream) {
+                   int64_t j, double *e, int32_t force_generic, void *workspace, size_t workspace_bytes, void *stream) {
   int rc = validate_ipb(basis);
   if (rc) return rc;
   rc = validate_cost(cost);
@@ -1701,6 +1761,18 @@ int pls_ipb_energy(const pls_ipb_desc *basis, const pls_cost_desc *cost, const d
   if (!workspace || workspace_bytes < mj + 2 * (size_t)j * sizeof(double))
     return fail(PLS_ERR_WORKSPACE_TOO_SMALL, "ipb_energy: workspace %zu bytes too small", workspace_bytes);
   double *V = static_cast<double *>(workspace);
+  if (ipb_fast_path(basis, cost, force_generic)) {
+    if (workspace_bytes < 2 * mj) return fail(PLS_ERR_WORKSPACE_TOO_SMALL, "ipb_energy: workspace %zu < %zu bytes", workspace_bytes, 2 * mj);
+    double *D = reinterpret_cast<double *>(static_cast<char *>(workspace) + mj);
+    const double inv_noise = 1.0 / cost->p[0];
+    rc = pls_gemm_tn(basis->W, basis->ldw, U, ldu, V, j, basis->m, j, basis->m, 1.0, 0.0, stream);
+    if (rc) return rc;
+    rc = pls_gemm_tn(basis->B, basis->ldb, V, j, D, j, basis->m, j, basis->m, inv_noise, 0.0, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(ipb_gaussian_energy_kernel, dim3((unsigned)cdiv(j, 64)), dim3(256), 0, S(stream), V, j, D, j, basis->c,
+                       basis->m, j, inv_noise, 0.5 * (double)basis->m, e);
+    return check_launch("ipb_gaussian_energy");
+  }
   double *partial = reinterpret_cast<double *>(static_cast<char *>(workspace) + mj);
   const int64_t max_parts = (int64_t)((workspace_bytes - mj) / ((size_t)j * sizeof(double)));
   int64_t n_chunk = max_parts * 64;

@@ -41,7 +41,7 @@ def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(L.CostDesc) == 4 * 4 + 4 * 8 + 8
     assert ctypes.sizeof(L.NoiseDesc) == 8 + 8 + 8 + 8 + 8 + 8 + 8
     assert ctypes.sizeof(L.OnbDesc) == 10 * 8
-    assert ctypes.sizeof(L.IpbDesc) == 10 * 8
+    assert ctypes.sizeof(L.IpbDesc) == 13 * 8
     assert L.CostDesc.p.offset == 16 and L.CostDesc.jitter.offset == 48
 
 

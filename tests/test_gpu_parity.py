@@ -535,6 +535,32 @@ def test_step_energy_by_product_on_the_generic_path(P, rank_path, n, m, j, d, ch
         assert abs(e_in.mean().item() - e_want) <= tol * abs(e_want), name
 
 
+@pytest.mark.parametrize("n,m,j,d", [(512, 24, 64, 3), (700, 33, 130, 2), (3000, 150, 40, 4)])
+def test_ipb_gaussian_fast_path_equals_the_generic_path(P, n, m, j, d):
+    """Inducing-point basis, Gaussian/identity: the M x M x J algebraic path (B = k(Z,X) k(X,Z), c = k(Z,X) y) against
+    the N x M x J path -- step, stand-alone energy and the energy by-product -- and against the oracle."""
+    pr = make_problem(n, m, j, d, seed=9 * n + m)
+    pr["ls"] = pr["ls"] * 0.35
+    ob, gb = build_ipb(P, pr)
+    cond = torch.linalg.cond(ob.base_gram_induce).item()
+    name, oc, gc = make_costs(P, pr["y"], pr["fstar"], pr["gen"])[0]
+    u = pr["u"]
+    e_noise = torch.randn(m, j, generator=pr["gen"])
+    noise = P.basis.NoiseSpec(injected=cu(e_noise))
+    e_fast_in = torch.empty(j, dtype=torch.float64, device="cuda")
+    fast = gb.fused_step(gc, cu(u), 1e-3, noise=noise, input_energy=e_fast_in)
+    assert gb._B is not None
+    gen = gb.fused_step(gc, cu(u), 1e-3, noise=noise, force_generic=True)
+    tol = max(1e-9, cond * 1e-13)
+    assert relerr(fast, gen) < tol
+    want = O.PLS(ob, oc).calculate_particle_update(u.clone(), 1e-3, noise=e_noise)
+    assert relerr(fast, want) < max(tol, cond * 1e-14)
+    e_fast, e_gen = gb.fused_particle_energy(gc, cu(u)), gb.fused_particle_energy(gc, cu(u), force_generic=True)
+    assert relerr(e_fast, e_gen) < tol and relerr(e_fast_in, e_gen) < tol
+    e_want = O.PLS(ob, oc).calculate_energy_potential(u.clone())
+    assert abs(e_fast.mean().item() - e_want) <= max(1e-9, tol) * abs(e_want)
+
+
 @pytest.mark.parametrize("n,m,j,d", [(512, 24, 64, 3), (700, 33, 130, 2)])
 def test_ipb_step_energy_by_product(P, rank_path, n, m, j, d):
     """pls_ipb_step(energy_in=...): cost of the same F + (M/2)||K^-1 U||^2 of the input particles, equal to the
@@ -547,10 +573,10 @@ def test_ipb_step_energy_by_product(P, rank_path, n, m, j, d):
     for name, oc, gc in make_costs(P, pr["y"], pr["fstar"], pr["gen"])[:5]:
         e_in = torch.full((j,), float("nan"), dtype=torch.float64, device="cuda")
         noise = P.basis.NoiseSpec(injected=cu(e_noise))
-        with_e = gb.fused_step(gc, cu(u), 1e-3, noise=noise, input_energy=e_in)
-        without = gb.fused_step(gc, cu(u), 1e-3, noise=noise)
+        with_e = gb.fused_step(gc, cu(u), 1e-3, noise=noise, input_energy=e_in, force_generic=True)
+        without = gb.fused_step(gc, cu(u), 1e-3, noise=noise, force_generic=True)
         assert torch.equal(with_e, without), name
-        assert relerr(e_in, gb.fused_particle_energy(gc, cu(u))) < 1e-11, name
+        assert relerr(e_in, gb.fused_particle_energy(gc, cu(u), force_generic=True)) < 1e-11, name
     name, oc, gc = make_costs(P, pr["y"], pr["fstar"], pr["gen"])[2]
     noises = [cu(torch.randn(m, j, generator=pr["gen"])) for _ in range(6)]
     runs = {}
