@@ -27,12 +27,12 @@ for f in sorted(glob.glob(os.path.join(src, "pmc*", "bench_counter_collection.cs
         rows[k][r["Counter_Name"]].append((float(r["Counter_Value"]), dur))
 summary = {}
 for k, d in rows.items():
-    # keep the step-sized launches only (setup GEMMs of the same kernel are much shorter / longer)
-    durs = sorted(x[1] for v in d.values() for x in v)
-    med = durs[len(durs) // 2]
+    # keep the step-sized launches only: the longest ones of that kernel (setup GEMMs and the M x M x J products of
+    # the extras run the same kernel on much smaller shapes)
+    big = max(x[1] for v in d.values() for x in v)
     ent = {}
     for c, v in d.items():
-        sel = [x for x in v if 0.5 * med <= x[1] <= 2 * med] or v
+        sel = [x for x in v if x[1] >= 0.5 * big] or v
         ent[c] = sum(x[0] for x in sel) / len(sel)
         ent["_dur_ms"] = sum(x[1] for x in sel) / len(sel) / 1e6
         ent["_launches"] = len(sel)
