@@ -1190,6 +1190,33 @@ def test_step_is_hipgraph_capturable(P, rank_path, force_generic):
     assert torch.equal(out_graph, out_eager)
 
 
+@pytest.mark.parametrize("force_generic", [False, True])
+def test_ipb_step_is_hipgraph_capturable(P, force_generic):
+    """The inducing-point step (W U, drift, Philox fill + L_c xi, update; Gaussian fast path or the N x M x J path) is
+    capturable and replays bit for bit, energy by-product included."""
+    pr = make_problem(600, 24, 96, 3, seed=63)
+    pr["ls"] = pr["ls"] * 0.35
+    ob, gb = build_ipb(P, pr)
+    gc = P.costs.GaussianCost(0.3, pr["y"], P.links.IdentityLinkFunction())
+    u = cu(pr["u"])
+    out_eager, out_graph = torch.empty_like(u), torch.empty_like(u)
+    e_eager = torch.empty(96, dtype=torch.float64, device="cuda")
+    e_graph = torch.empty_like(e_eager)
+    spec = P.basis.NoiseSpec(seed=19, step=2)
+    gb.fused_step(gc, u, 1e-4, out=out_eager, noise=spec, force_generic=force_generic, input_energy=e_eager)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            gb.fused_step(gc, u, 1e-4, out=out_graph, noise=spec, force_generic=force_generic, input_energy=e_graph)
+    out_graph.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out_graph, out_eager) and torch.equal(e_graph, e_eager)
+
+
 def test_captured_multi_step_graph_draws_fresh_noise_and_matches_eager(P):
     from projected_langevin_sampling_amd.graph import CapturedSteps
 
