@@ -80,6 +80,11 @@ __device__ inline double cost_value(const CostP &c, double y, double f) {
     case PLS_COST_POISSON:  // poisson.py:59-66
       return -2.0 * y * fast_log(fabs(f)) + p;
     case PLS_COST_BERNOULLI:  // bernoulli.py:57-62
+      // binary labels (the usual case) need ONE logarithm; the other term of the general formula is +-0 * finite
+      // (p is clipped away from 0 and 1), so these returns are bit-identical to it.  In the row-walking epilogues y
+      // is uniform across the wave, so the branch really skips the second log.
+      if (y == 1.0) return -fast_log(p);
+      if (y == 0.0) return -fast_log(1.0 - p);
       return -fast_log(p) * y - fast_log(1.0 - p) * (1.0 - y);
     case PLS_COST_STUDENT_T: {  // student_t.py:57-72, p0 = dof, p1 = scale
       double e = p - y;
