@@ -6,7 +6,7 @@ TAG=${1:-r01}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python3 $PWD/bench.py --steps 5 --warmup 1 --no-cpu-baseline"
+BENCH="python3 $PWD/bench.py --steps 5 --warmup 1 --no-cpu-baseline $BENCH_ARGS"   # e.g. BENCH_ARGS="--config c3 --ipb-steps 0"
 cd /tmp
 echo "== kernel trace + stats" | tee "$OUT/log.txt"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- $BENCH >> "$OUT/log.txt" 2>&1

@@ -13,6 +13,10 @@ def short(n):
     m = re.search(r"gemm_tn_f64_kernel<(\d+), (\d+).*?plship::(\w+)", n)
     if m:
         return f"gemm_tn_f64<{m.group(1)}x{m.group(2)}>::{m.group(3)}"
+    m = re.search(r"small_rank_kernel<(\d+), (\d+), (-?\d+), (-?\d+)>", n)
+    if m:
+        mode = {"0": "drift", "1": "value", "2": "drift+value"}[m.group(2)]
+        return f"small_rank_kernel<KB={m.group(1)},{mode},cost={m.group(3)},link={m.group(4)}>"
     m = re.search(r"plship::(\w+)", n)
     return m.group(1) if m else None
 
