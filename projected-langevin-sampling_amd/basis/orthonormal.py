@@ -120,6 +120,15 @@ class OrthonormalBasis(PLSBasis):
 
     # ---- descriptors ---------------------------------------------------------------------------------------------
     def _desc(self, with_gaussian: bool = False) -> L.OnbDesc:
+        key = (bool(with_gaussian and self._B is not None), self._A.data_ptr(), None if self._B is None else self._B.data_ptr())
+        cached = self.__dict__.get("_desc_cache")
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        d = self._build_desc(with_gaussian)
+        self._desc_cache = (key, d)
+        return d
+
+    def _build_desc(self, with_gaussian: bool) -> L.OnbDesc:
         d = L.OnbDesc()
         d.mk, d.n = self.approximation_dimension, self._n
         d.A, d.lda = self._A.data_ptr(), L.ld(self._A)
@@ -227,9 +236,13 @@ class OrthonormalBasis(PLSBasis):
                 ws_bytes = ((self.approximation_dimension + 63) // 64) * j * 8
                 ws = self._workspace(ws_bytes, u.device)
         else:
-            need_min = lib.pls_onb_step_workspace_bytes(desc, j, 128)
-            need_full = lib.pls_onb_step_workspace_bytes(desc, j, self._n)
-            ws_bytes = max(need_min, min(need_full, self.workspace_bytes))
+            wkey = (j, self.workspace_bytes)
+            ws_bytes = self.__dict__.setdefault("_ws_bytes_cache", {}).get(wkey)
+            if ws_bytes is None:
+                need_min = lib.pls_onb_step_workspace_bytes(desc, j, 128)
+                need_full = lib.pls_onb_step_workspace_bytes(desc, j, self._n)
+                ws_bytes = max(need_min, min(need_full, self.workspace_bytes))
+                self._ws_bytes_cache[wkey] = ws_bytes
             ws = self._workspace(ws_bytes, u.device)
         nd = (noise if noise is not None else self._draw_noise_spec(None)).desc()
         L.check(

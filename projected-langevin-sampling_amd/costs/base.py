@@ -34,6 +34,15 @@ class PLSCost(ABC):
 
     def is_native(self) -> bool:
         """True if both the cost and its link are evaluated by libplship (fused-step eligible)."""
+        key = (type(self), id(self.link_function))  # (the answer only depends on the classes involved: cached)
+        cached = getattr(self, "_native_cache", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        value = self._is_native_uncached()
+        self._native_cache = (key, value)
+        return value
+
+    def _is_native_uncached(self) -> bool:
         overridden = any(
             getattr(type(self), name) is not getattr(_native_base_of(type(self)), name)
             for name in ("calculate_cost", "calculate_cost_derivative")
