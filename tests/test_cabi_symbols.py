@@ -33,6 +33,21 @@ def test_library_exports_every_declared_symbol():
     assert lib.pls_last_error() is not None
 
 
+def test_options_validate_without_touching_the_gpu():
+    """pls_set_option / pls_get_option are host-only: range checks and unknown options behave as documented."""
+    import projected_langevin_sampling_amd as pkg
+
+    L = pkg._lib
+    lib = L.load()
+    assert lib.pls_get_option(L.OPT_SMALL_RANK_MAX) == 128
+    assert lib.pls_set_option(L.OPT_SMALL_RANK_MAX, 129) != 0 and b"outside 0..128" in lib.pls_last_error()
+    assert lib.pls_set_option(L.OPT_SMALL_RANK_MAX, -1) != 0
+    assert lib.pls_set_option(99, 1) != 0 and b"unknown option" in lib.pls_last_error()
+    assert lib.pls_get_option(99) == -1
+    assert lib.pls_set_option(L.OPT_SMALL_RANK_MAX, 64) == 0 and lib.pls_get_option(L.OPT_SMALL_RANK_MAX) == 64
+    assert lib.pls_set_option(L.OPT_SMALL_RANK_MAX, 128) == 0
+
+
 def test_struct_layouts_match_the_header():
     """sizeof / field order of the descriptor structs (plain C layout on x86-64)."""
     import projected_langevin_sampling_amd as pkg
