@@ -450,8 +450,10 @@ struct RowConsts {
 
 // X / ldx (optional): a companion matrix addressed like the output (the particles U of the Langevin and energy
 // epilogues).  Its 16 x WJ slab is fetched with 16 row-wise coalesced loads that are ALL in flight together, one slab
-// ahead of its use, and handed to the row loop through LDS -- a load inside the row loop would expose the full memory
-// latency once per iteration (measured: 23 us of the 283 us fast-path step).
+// ahead of its use, and handed to the row loop through LDS -- a load inside the row loop exposes the memory latency
+// once per iteration.  (Measured gain: 2-3 us of the 283 us fast-path step; the rest of that epilogue is instruction
+// count)
+// UNROLL: unroll factor of the row loop (2 interleaves two independent row pairs; measured neutral, left at 1).
 template <int TI, int TJ, int NCONST = 2, int UNROLL = 1, class Fn>
 __device__ __forceinline__ void epilogue_row_pairs(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int wave,
                                                    int64_t I, int64_t J, double *lds, double k0, double k1, Fn &&fn,
