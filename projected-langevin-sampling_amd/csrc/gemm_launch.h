@@ -1,0 +1,57 @@
+// GEMM launch helpers shared by the translation units that instantiate gemm_tn_f64_kernel.
+#pragma once
+#include "common.h"
+#include "gemm_tn_f64.h"
+
+namespace plship {
+
+#ifdef PLS_STAMP
+extern unsigned long long *g_stamp_buffer;  // diagnostic build only (tools/stamp_probe.py); defined in plship.hip
+#endif
+
+// ---------------------------------------------------------------------------------------------------------------
+// GEMM launcher
+// ---------------------------------------------------------------------------------------------------------------
+template <int BI, int BJ, int WI, int WJ, class Epi, int MINW = ((BI >= 128) ? 2 : 4)>
+static int launch_gemm_cfg(GemmShape g, const Epi &epi, hipStream_t st) {
+  constexpr int BK = 16;  // MINW: waves per SIMD the register allocation must leave room for
+  constexpr int NT = (BI / WI) * (BJ / WJ) * 64;
+  constexpr size_t lds_bytes = (size_t)2 * BK * ((BI + 16) + (BJ + 16)) * sizeof(double);
+  auto kern = gemm_tn_f64_kernel<BI, BJ, WI, WJ, BK, MINW, Epi>;
+  static bool attr_set = false;  // benign race: idempotent
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return fail(PLS_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+#ifdef PLS_STAMP
+  g.stamps = g_stamp_buffer;
+#endif
+  g.nti = (int)cdiv(g.I, BI);
+  g.ntj = (int)cdiv(g.J, BJ);
+  const int64_t nwg = (int64_t)g.nti * g.ntj;
+  if (nwg <= 0) return PLS_OK;
+  if (nwg > 0x7fffffff) return fail(PLS_ERR_INVALID_ARGUMENT, "gemm: too many tiles");
+  unsigned nsplit = 1;
+  if (g.kchunk > 0 && g.kchunk < g.K) nsplit = (unsigned)cdiv(g.K, g.kchunk);
+  {
+    LaunchScope scope(Epi::kTag, st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg, nsplit), dim3(NT), lds_bytes, st, g, epi);
+  }
+  return check_launch("gemm_tn_f64");
+}
+
+static inline bool use_big_tiles(int64_t I, int64_t J, int64_t nsplit = 1) { return cdiv(I, 128) * cdiv(J, 128) * nsplit >= 256; }
+
+// kchunk > 0 (EpiStore only): split-K into cdiv(K, kchunk) slabs, one grid.y plane each
+template <class Epi>
+static int launch_gemm(const double *L, int64_t ldl, const double *R, int64_t ldr, int64_t I, int64_t J, int64_t K,
+                       const Epi &epi, hipStream_t st, int64_t kchunk = 0) {
+  GemmShape g{L, ldl, R, ldr, I, J, K, 0, 0, kchunk};
+  const int64_t nsplit = (kchunk > 0 && kchunk < K) ? cdiv(K, kchunk) : 1;
+  if (use_big_tiles(I, J, nsplit)) return launch_gemm_cfg<128, 128, 64, 64>(g, epi, st);
+  return launch_gemm_cfg<64, 64, 32, 32>(g, epi, st);
+}
+
+}  // namespace plship

@@ -14,11 +14,18 @@
 #include "common.h"
 #include "cost_device.h"
 #include "gemm_tn_f64.h"
+#include "gemm_launch.h"
+#include "cost_epilogues.h"
 #include "philox.h"
 #include "small_rank.h"
 #include "small_rank_launch.h"
 
 namespace plship {
+
+#ifdef PLS_STAMP
+unsigned long long *g_stamp_buffer = nullptr;  // diagnostic build only (tools/stamp_probe.py)
+extern "C" void pls_debug_set_stamp_buffer(unsigned long long *p) { g_stamp_buffer = p; }
+#endif
 
 thread_local std::string g_last_error;
 thread_local Timeline g_tl;
@@ -26,120 +33,6 @@ thread_local Timeline g_tl;
 // ---------------------------------------------------------------------------------------------------------------
 // GEMM epilogues that need the cost functions / the noise generator
 // ---------------------------------------------------------------------------------------------------------------
-
-// G = d cost / d f (acc = F tile); rows of this launch are rows [row0, row0 + I) of y.
-// vpart (optional): the cost VALUE of the same F as a by-product -- vpart[wave row][j] = sum over the 16*TI rows of the
-// wave's block of cost(y_i, F_ij) (wave row = iw / (16 TI); fixed order, no cross-wave traffic): the energy of the
-// step's INPUT particles without a third pass over A (projected_langevin_sampling.py:125-138 recomputes F for it).
-struct EpiCostDeriv {
-  static constexpr int kTag = PLS_TAG_GEMM_COST_DERIV;
-  static constexpr bool kDirect = false;
-  double *G;
-  int64_t ldg;
-  const double *y;
-  CostP cp;
-  double *vpart;
-  int64_t ldp;
-  template <int TI, int TJ>
-  __device__ void apply(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int wave, int64_t I, int64_t J,
-                        int, int, double *lds) const {
-    const double yl = load_row_constants(y, iw, lane, I);
-    if (!vpart) {
-      epilogue_row_pairs<TI, TJ, 1>(acc, iw, jw, lane, wave, I, J, lds, yl, 0.0,
-                                 [&](int64_t i, int64_t j, double v0, bool hi, double v1, const RowConsts &rc) {
-                                   G[i * ldg + j] = cost_deriv(cp, rc.k0_lo, v0);
-                                   if (hi) G[(i + 4) * ldg + j] = cost_deriv(cp, rc.k0_hi, v1);
-                                 });
-      return;
-    }
-    double s = 0.0;
-    epilogue_row_pairs<TI, TJ, 1>(acc, iw, jw, lane, wave, I, J, lds, yl, 0.0,
-                               [&](int64_t i, int64_t j, double v0, bool hi, double v1, const RowConsts &rc) {
-                                 G[i * ldg + j] = cost_deriv(cp, rc.k0_lo, v0);
-                                 s += cost_value(cp, rc.k0_lo, v0);
-                                 if (hi) {
-                                   G[(i + 4) * ldg + j] = cost_deriv(cp, rc.k0_hi, v1);
-                                   s += cost_value(cp, rc.k0_hi, v1);
-                                 }
-                               });
-    constexpr int WJ = TJ * 16;
-    if (WJ == 32) s += __shfl_xor(s, 32);  // two lane halves share the 32 columns
-    if (iw < I && lane < WJ && jw + lane < J) vpart[(iw / (16 * TI)) * ldp + jw + lane] = s;
-  }
-};
-
-// Gaussian cost with the identity link (gaussian.py:86-88): G = (acc - y_i) / sigma2, evaluated as
-// fma(acc, 1/sigma2, -y_i/sigma2) in every tile shape, so that the result does not depend on the launch geometry.
-// Interior tiles take the direct path.  vpart as in EpiCostDeriv: cost = (acc - y)^2 / (2 sigma2) = G^2 * sigma2 / 2.
-struct EpiGaussDeriv {
-  static constexpr int kTag = PLS_TAG_GEMM_COST_DERIV;
-  static constexpr bool kDirect = true;
-  double *G;
-  int64_t ldg;
-  const double *y;
-  double inv_noise;
-  double *vpart;
-  int64_t ldp;
-  __device__ int64_t direct_ld() const { return ldg; }
-  template <int TI, int TJ>
-  __device__ void apply(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int wave, int64_t I, int64_t J,
-                        int, int, double *lds) const {
-    const double yl = load_row_constants(y, iw, lane, I);
-    double s = 0.0;
-    epilogue_row_pairs<TI, TJ, 1>(acc, iw, jw, lane, wave, I, J, lds, yl, 0.0,
-                               [&](int64_t i, int64_t j, double v0, bool hi, double v1, const RowConsts &rc) {
-                                 const double g0 = fma(v0, inv_noise, -inv_noise * rc.k0_lo);
-                                 G[i * ldg + j] = g0;
-                                 s = fma(g0, g0, s);
-                                 if (hi) {
-                                   const double g1 = fma(v1, inv_noise, -inv_noise * rc.k0_hi);
-                                   G[(i + 4) * ldg + j] = g1;
-                                   s = fma(g1, g1, s);
-                                 }
-                               });
-    if (vpart) {
-      constexpr int WJ = TJ * 16;
-      if (WJ == 32) s += __shfl_xor(s, 32);
-      if (iw < I && lane < WJ && jw + lane < J) vpart[(iw / (16 * TI)) * ldp + jw + lane] = s * (0.5 / inv_noise);
-    }
-  }
-  template <int TI, int TJ>
-  __device__ void apply_direct(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int) const {
-#if defined(__HIP_DEVICE_COMPILE__)
-    // y of the 16 row groups this lane's registers belong to: rows iw + 4 s + (lane >> 4), s = 0..4 TI - 1
-    const __amdgpu_buffer_rsrc_t ys =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(y + iw), 0, 0x7FFFFFF0, 0x00020000);
-    const int yoff = (lane >> 4) * 8;
-    double yv[4 * TI];  // -y_i / sigma2: one fma per element, v / sigma2 - y_i / sigma2 (abs. error <= ulp(y / sigma2))
-#pragma unroll
-    for (int s = 0; s < 4 * TI; ++s)
-      yv[s] = -inv_noise * __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(ys, yoff, s * 32, 0));
-    if (!vpart) {
-      epilogue_direct<TI, TJ>(acc, G + iw * ldg + jw, ldg, lane,
-                              [&](double v, int slot, int, __amdgpu_buffer_rsrc_t, int, int) { return fma(v, inv_noise, yv[slot]); });
-      return;
-    }
-    double sq[TJ];  // per 16-column block: this lane's 4*TI rows of G^2
-#pragma unroll
-    for (int tb = 0; tb < TJ; ++tb) sq[tb] = 0.0;
-    epilogue_direct<TI, TJ>(acc, G + iw * ldg + jw, ldg, lane, [&](double v, int slot, int tb, __amdgpu_buffer_rsrc_t, int, int) {
-      const double g = fma(v, inv_noise, yv[slot]);
-      sq[tb] = fma(g, g, sq[tb]);
-      return g;
-    });
-    const double half_s2 = 0.5 / inv_noise;
-#pragma unroll
-    for (int tb = 0; tb < TJ; ++tb) {
-      double t = sq[tb];
-      t += __shfl_xor(t, 16);
-      t += __shfl_xor(t, 32);  // the four lane groups hold rows (lane >> 4) + 4 r of the same column
-      if (lane < 16) vpart[(iw / (16 * TI)) * ldp + jw + tb * 16 + lane] = t * half_s2;
-    }
-#else
-    (void)acc, (void)iw, (void)jw, (void)lane;
-#endif
-  }
-};
 
 // partial[tile_i][j] = sum over the tile's rows of cost(y_i, acc_ij); deterministic order.
 template <int BI, int BJ, int WI, int WJ>
@@ -326,55 +219,6 @@ struct EpiLangevinGaussian {
   }
 };
 
-#ifdef PLS_STAMP
-static unsigned long long *g_stamp_buffer = nullptr;  // diagnostic build only (tools/stamp_probe.py)
-extern "C" void pls_debug_set_stamp_buffer(unsigned long long *p) { g_stamp_buffer = p; }
-#endif
-
-// ---------------------------------------------------------------------------------------------------------------
-// GEMM launcher
-// ---------------------------------------------------------------------------------------------------------------
-template <int BI, int BJ, int WI, int WJ, class Epi, int MINW = ((BI >= 128) ? 2 : 4)>
-static int launch_gemm_cfg(GemmShape g, const Epi &epi, hipStream_t st) {
-  constexpr int BK = 16;  // MINW: waves per SIMD the register allocation must leave room for
-  constexpr int NT = (BI / WI) * (BJ / WJ) * 64;
-  constexpr size_t lds_bytes = (size_t)2 * BK * ((BI + 16) + (BJ + 16)) * sizeof(double);
-  auto kern = gemm_tn_f64_kernel<BI, BJ, WI, WJ, BK, MINW, Epi>;
-  static bool attr_set = false;  // benign race: idempotent
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return fail(PLS_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_set = true;
-  }
-#ifdef PLS_STAMP
-  g.stamps = g_stamp_buffer;
-#endif
-  g.nti = (int)cdiv(g.I, BI);
-  g.ntj = (int)cdiv(g.J, BJ);
-  const int64_t nwg = (int64_t)g.nti * g.ntj;
-  if (nwg <= 0) return PLS_OK;
-  if (nwg > 0x7fffffff) return fail(PLS_ERR_INVALID_ARGUMENT, "gemm: too many tiles");
-  unsigned nsplit = 1;
-  if (g.kchunk > 0 && g.kchunk < g.K) nsplit = (unsigned)cdiv(g.K, g.kchunk);
-  {
-    LaunchScope scope(Epi::kTag, st);
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg, nsplit), dim3(NT), lds_bytes, st, g, epi);
-  }
-  return check_launch("gemm_tn_f64");
-}
-
-static bool use_big_tiles(int64_t I, int64_t J, int64_t nsplit = 1) { return cdiv(I, 128) * cdiv(J, 128) * nsplit >= 256; }
-
-// kchunk > 0 (EpiStore only): split-K into cdiv(K, kchunk) slabs, one grid.y plane each
-template <class Epi>
-static int launch_gemm(const double *L, int64_t ldl, const double *R, int64_t ldr, int64_t I, int64_t J, int64_t K,
-                       const Epi &epi, hipStream_t st, int64_t kchunk = 0) {
-  GemmShape g{L, ldl, R, ldr, I, J, K, 0, 0, kchunk};
-  const int64_t nsplit = (kchunk > 0 && kchunk < K) ? cdiv(K, kchunk) : 1;
-  if (use_big_tiles(I, J, nsplit)) return launch_gemm_cfg<128, 128, 64, 64>(g, epi, st);
-  return launch_gemm_cfg<64, 64, 32, 32>(g, epi, st);
-}
 
 // Split-K plan for the back-projection D (I x J) = L^T R with a long contraction (K = rows of the N chunk).  Two reasons
 // to cut the contraction into slabs (summed in a fixed order by the update kernel: deterministic, no atomics):
@@ -1069,13 +913,7 @@ static int stream_drift(const double *Lf, int64_t ldlf, const double *Lb, int64_
                     (long long)es->rows_cap);
       vp = es->partial;
     }
-    if (cp.cost == PLS_COST_GAUSSIAN && cp.link == PLS_LINK_IDENTITY) {
-      EpiGaussDeriv e1{Gbuf, j, y + r0, 1.0 / cp.p0, vp, j};
-      rc = launch_gemm(Lf + r0, ldlf, V, ldv, rows, j, kdim, e1, st);
-    } else {
-      EpiCostDeriv e1{Gbuf, j, y + r0, cp, vp, j};
-      rc = launch_gemm(Lf + r0, ldlf, V, ldv, rows, j, kdim, e1, st);
-    }
+    rc = launch_cost_deriv_gemm(Lf + r0, ldlf, V, ldv, rows, j, kdim, Gbuf, j, y + r0, cp, vp, j, st);
     if (rc) return rc;
     if (es) {
       rc = reduce_partials(wave_rows, c == 0 ? 0 : 1, r0 + n_chunk >= n);
