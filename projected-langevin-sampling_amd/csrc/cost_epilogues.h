@@ -128,6 +128,54 @@ struct EpiGaussDeriv {
   }
 };
 
+// partial[tile_i][j] = sum over the tile's rows of cost(y_i, acc_ij); deterministic order.
+template <int BI, int BJ, int WI, int WJ, int COST = -1, int LINK = -1>
+struct EpiCostValue {
+  static constexpr int kTag = PLS_TAG_GEMM_COST_VALUE;
+  static constexpr bool kDirect = false;
+  double *partial;
+  int64_t ldp;
+  const double *y;
+  CostP cp;
+  template <int TI, int TJ>
+  __device__ void apply(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int wave, int64_t I, int64_t J,
+                        int tile_i, int, double *lds) const {
+    double s = 0.0;  // this lane's column, summed over the rows it is handed (fixed order)
+    CostP cp = this->cp;
+    if constexpr (COST >= 0) {
+      cp.cost = COST;
+      cp.link = LINK;
+    }
+    const double yl = load_row_constants(y, iw, lane, I);
+    epilogue_row_pairs<TI, TJ, 1>(acc, iw, jw, lane, wave, I, J, lds, yl, 0.0,
+                               [&](int64_t, int64_t, double v0, bool hi, double v1, const RowConsts &rc) {
+                                 s += cost_value(cp, rc.k0_lo, v0);
+                                 if (hi) s += cost_value(cp, rc.k0_hi, v1);
+                               });
+    if (WJ == 32) s += __shfl_xor(s, 32);  // two lane halves share the 32 columns
+    constexpr int NWJ = BJ / WJ, NWI = BI / WI;
+    const int wrow = wave / NWJ, wcol = wave % NWJ;
+    double *red = lds;  // [NWI][BJ]; overlaps the waves' slabs: wait until every wave has left its row loops
+    __syncthreads();
+    if (lane < WJ) red[wrow * BJ + wcol * WJ + lane] = s;
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < BJ) {
+      double tot = 0.0;
+#pragma unroll
+      for (int w = 0; w < NWI; ++w) tot += red[w * BJ + t];
+      const int64_t j = (jw - wcol * WJ) + t;
+      if (j < J) partial[(int64_t)tile_i * ldp + j] = tot;
+    }
+  }
+};
+
+// Forward GEMM + cost-VALUE epilogue: partial[tile row][j] = sum over the tile's rows of cost(y_i, F_ij); the number of
+// partial rows written is cdiv(rows, 128) with the big tiles, cdiv(rows, 64) otherwise (cost_value_partial_rows in
+// plship.hip).  Dispatches on (cost, link); defined in gemm_cost_value.hip.
+int launch_cost_value_gemm(const double *Lf, int64_t ldlf, const double *V, int64_t ldv, int64_t rows, int64_t j, int64_t kdim,
+                           double *partial, int64_t ldp, const double *y, const CostP &cp, hipStream_t st);
+
 // Forward GEMM + cost-derivative epilogue for rows [0, rows) of Lf / y:  G = cost'(Lf^T V); vpart (optional) receives the
 // per-wave-row cost partial sums.  Dispatches on (cost, link); defined in gemm_cost.hip.
 int launch_cost_deriv_gemm(const double *Lf, int64_t ldlf, const double *V, int64_t ldv, int64_t rows, int64_t j, int64_t kdim,

@@ -34,43 +34,6 @@ thread_local Timeline g_tl;
 // GEMM epilogues that need the cost functions / the noise generator
 // ---------------------------------------------------------------------------------------------------------------
 
-// partial[tile_i][j] = sum over the tile's rows of cost(y_i, acc_ij); deterministic order.
-template <int BI, int BJ, int WI, int WJ>
-struct EpiCostValue {
-  static constexpr int kTag = PLS_TAG_GEMM_COST_VALUE;
-  static constexpr bool kDirect = false;
-  double *partial;
-  int64_t ldp;
-  const double *y;
-  CostP cp;
-  template <int TI, int TJ>
-  __device__ void apply(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int wave, int64_t I, int64_t J,
-                        int tile_i, int, double *lds) const {
-    double s = 0.0;  // this lane's column, summed over the rows it is handed (fixed order)
-    const double yl = load_row_constants(y, iw, lane, I);
-    epilogue_row_pairs<TI, TJ, 1>(acc, iw, jw, lane, wave, I, J, lds, yl, 0.0,
-                               [&](int64_t, int64_t, double v0, bool hi, double v1, const RowConsts &rc) {
-                                 s += cost_value(cp, rc.k0_lo, v0);
-                                 if (hi) s += cost_value(cp, rc.k0_hi, v1);
-                               });
-    if (WJ == 32) s += __shfl_xor(s, 32);  // two lane halves share the 32 columns
-    constexpr int NWJ = BJ / WJ, NWI = BI / WI;
-    const int wrow = wave / NWJ, wcol = wave % NWJ;
-    double *red = lds;  // [NWI][BJ]; overlaps the waves' slabs: wait until every wave has left its row loops
-    __syncthreads();
-    if (lane < WJ) red[wrow * BJ + wcol * WJ + lane] = s;
-    __syncthreads();
-    const int t = threadIdx.x;
-    if (t < BJ) {
-      double tot = 0.0;
-#pragma unroll
-      for (int w = 0; w < NWI; ++w) tot += red[w * BJ + t];
-      const int64_t j = (jw - wcol * WJ) + t;
-      if (j < J) partial[(int64_t)tile_i * ldp + j] = tot;
-    }
-  }
-};
-
 // Gaussian fast energy: acc = (B U)_ij;  partial[tile_i][j] = sum over the tile's rows of
 //   pscale * u_ij * (acc_ij - 2 c_i) + 0.5 * u_ij^2 / lam_i       (cost quadratic form + prior energy of those rows)
 template <int BI, int BJ, int WI, int WJ>
@@ -256,17 +219,6 @@ static int64_t plan_split_k(int64_t I, int64_t J, int64_t K, int64_t *kchunk) {
 // cost-value GEMM (tile geometry is part of the epilogue type); returns the number of partial rows written
 static int64_t cost_value_partial_rows(int64_t I, int64_t J) { return use_big_tiles(I, J) ? cdiv(I, 128) : cdiv(I, 64); }
 
-static int launch_gemm_cost_value(const double *L, int64_t ldl, const double *R, int64_t ldr, int64_t I, int64_t J,
-                                  int64_t K, double *partial, int64_t ldp, const double *y, const CostP &cp,
-                                  hipStream_t st) {
-  GemmShape g{L, ldl, R, ldr, I, J, K, 0, 0, 0};
-  if (use_big_tiles(I, J)) {
-    EpiCostValue<128, 128, 64, 64> e{partial, ldp, y, cp};
-    return launch_gemm_cfg<128, 128, 64, 64>(g, e, st);
-  }
-  EpiCostValue<64, 64, 32, 32> e{partial, ldp, y, cp};
-  return launch_gemm_cfg<64, 64, 32, 32>(g, e, st);
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // HBM-bound kernels
@@ -948,7 +900,7 @@ static int stream_cost(const double *Lf, int64_t ldlf, const double *Lb, int64_t
   int64_t nchunks = cdiv(n, n_chunk);
   for (int64_t r0 = 0, c = 0; r0 < n; r0 += n_chunk, ++c) {
     const int64_t rows = (n - r0 < n_chunk) ? (n - r0) : n_chunk;
-    int rc = launch_gemm_cost_value(Lf + r0, ldlf, V, ldv, rows, j, kdim, partial, j, y + r0, cp, st);
+    int rc = launch_cost_value_gemm(Lf + r0, ldlf, V, ldv, rows, j, kdim, partial, j, y + r0, cp, st);
     if (rc) return rc;
     const bool last = (c == nchunks - 1);
     hipLaunchKernelGGL(column_reduce_kernel, dim3((unsigned)cdiv(j, 256)), dim3(256), 0, st, partial, j,
