@@ -874,7 +874,19 @@ static int stream_drift(const double *Lf, int64_t ldlf, const double *Lb, int64_
     // slab s accumulates rows [s * kchunk, (s + 1) * kchunk) of every chunk; the first chunk has the planned row count,
     // so it writes (beta = 0) every slab; a shorter last chunk simply leaves its missing slabs untouched
     EpiStore e2{D, ldd, 1.0, c == 0 ? 0.0 : 1.0, slab_stride};
-    rc = launch_gemm(Lb + r0 * ldlb, ldlb, Gbuf, j, kdim, j, rows, e2, st, nslab > 1 ? kchunk : 0);
+    const int64_t kc2 = nslab > 1 ? kchunk : 0;
+    const int64_t main_rows = kdim / 128 * 128, rem_rows = kdim - main_rows;
+    if (main_rows > 0 && rem_rows > 0 && rem_rows <= 64 && use_big_tiles(kdim, j, nslab)) {
+      // a rank just above a multiple of 128 (129: the back-projection would compute 256 rows): the full 128-row tiles
+      // with the big configuration, the remainder with 64-row tiles
+      rc = launch_gemm(Lb + r0 * ldlb, ldlb, Gbuf, j, main_rows, j, rows, e2, st, kc2);
+      if (rc) return rc;
+      EpiStore e3{D + main_rows * ldd, ldd, 1.0, c == 0 ? 0.0 : 1.0, slab_stride};
+      GemmShape g3{Lb + r0 * ldlb + main_rows, ldlb, Gbuf, j, rem_rows, j, rows, 0, 0, kc2};
+      rc = launch_gemm_cfg<64, 64, 32, 32>(g3, e3, st);
+    } else {
+      rc = launch_gemm(Lb + r0 * ldlb, ldlb, Gbuf, j, kdim, j, rows, e2, st, kc2);
+    }
     if (rc) return rc;
   }
   return PLS_OK;

@@ -664,6 +664,29 @@ def test_captured_training_matches_the_eager_loop(P, cost_idx, epochs, k, patien
     assert torch.equal(got_u, u)
 
 
+@pytest.mark.parametrize("mk", [129, 150, 192, 200, 257])
+def test_ranks_just_above_a_tile_multiple(P, mk):
+    """Ranks a little above a multiple of 128 take the back-projection as full 128-row tiles plus a 64-row-tile
+    remainder launch (129 rows would otherwise compute as 256).  Step and energy by-product against plain torch fp64
+    on the host, with the row slabs of the split-K plan in play (N = 40000)."""
+    gen = torch.Generator().manual_seed(500 + mk)
+    n, j, eta, s2 = 40000, 2200, 1e-3, 0.4
+    a = torch.randn(mk, n, generator=gen, dtype=torch.float64) / mk ** 0.5
+    lam = torch.rand(mk, generator=gen, dtype=torch.float64) + 0.5
+    u = torch.randn(mk, j, generator=gen, dtype=torch.float64)
+    xi = torch.randn(mk, j, generator=gen, dtype=torch.float64)
+    y = torch.randn(n, generator=gen, dtype=torch.float64)
+    basis = P.basis.OrthonormalBasis.from_projection(cu(a), cu(lam), poison_padding=True)
+    gc = P.costs.GaussianCost(s2, y, P.links.IdentityLinkFunction())
+    e_in = torch.empty(j, dtype=torch.float64, device="cuda")
+    got = basis.fused_step(gc, cu(u), eta, noise=P.basis.NoiseSpec(injected=cu(xi)), force_generic=True, input_energy=e_in)
+    f = a.T @ u
+    want = -eta * (a @ ((f - y[:, None]) / s2)) - eta * u / lam[:, None] + math.sqrt(2 * eta) * xi
+    assert relerr(got, want) < 1e-11
+    e_want = ((f - y[:, None]) ** 2).sum(0) / (2 * s2) + 0.5 * (u * u / lam[:, None]).sum(0)
+    assert relerr(e_in, e_want) < 1e-11
+
+
 def test_random_shape_sweep_against_the_oracle(P, rank_path):
     """Seeded sweep over ragged (N, M, J, D): one Gaussian and one non-Gaussian step + energy per draw against the
     oracle, through whichever path `rank_path` selects (M <= 128 throughout, so `small_rank` really is the fused
