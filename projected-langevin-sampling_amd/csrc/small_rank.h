@@ -239,13 +239,16 @@ __global__ __launch_bounds__(256, 2) void small_rank_kernel(SmallRankP p) {
   }
 }
 
-// number of row slabs: enough workgroups for two per CU twice over, slabs of >= 128 rows (4 tiles), at most 32
+// number of row slabs: enough workgroups for two per CU twice over; up to 32 slabs of >= 128 rows, up to 128 slabs of
+// >= 512 rows (every slab costs a K x J block of workspace, its write and one more read by the update kernel:
+// N = 2e4, K = 32, J = 256 is 0.046 ms with 32 slabs and 0.080 ms with 128, N = 1e5, K = 128, J = 256 0.43 and 0.27 ms)
 // (narrow particle sets, J of a few hundred, otherwise leave most CUs idle: N = 4096, K = 128, J = 512 ran on 64
 // workgroups, 75 us; the slabs cost S*K*J*8 bytes of workspace and one extra read by the update kernel)
 static inline int64_t small_rank_splits(int64_t J, int64_t N, int64_t *rows_per_split) {
   const int64_t jt = (J + 63) / 64;
   int64_t s = (1024 + jt - 1) / jt;
-  if (s > 32) s = 32;
+  if (s > 128) s = 128;
+  if (s > 32 && N / s < 512) s = (N / 512 > 32) ? N / 512 : 32;  // beyond 32 slabs only while each keeps >= 512 rows
   while (s > 1 && N / s < 128) --s;
   if (s < 1) s = 1;
   int64_t rows = ((N + s - 1) / s + SR_ROWS - 1) / SR_ROWS * SR_ROWS;
