@@ -209,7 +209,11 @@ static int64_t plan_split_k(int64_t I, int64_t J, int64_t K, int64_t *kchunk) {
       if (waste(sl) < waste(best) - 0.03) best = sl;
     s = best;
   }
-  while (s > 1 && K / s < 1024) --s;  // keep every slab's k-loop long enough to amortise its prologue / epilogue
+  // keep every slab's k-loop long enough to amortise its prologue / epilogue; a handful of tiles (small ranks AND few
+  // particles) is latency-bound on its serial k-loop instead, so shorter slabs pay (M_k = 129, J = 256, N = 2000:
+  // 12 workgroups walked 125 k-steps each)
+  const int64_t min_chunk = tiles < 64 ? 256 : 1024;
+  while (s > 1 && K / s < min_chunk) --s;
   int64_t kc = cdiv(cdiv(K, s), 16) * 16;
   s = cdiv(K, kc);
   *kchunk = (s > 1) ? kc : 0;
