@@ -1326,7 +1326,8 @@ int pls_onb_step(const pls_onb_desc *basis, const pls_cost_desc *cost, const dou
 size_t pls_onb_energy_workspace_bytes(const pls_onb_desc *basis, int64_t j, int64_t n_chunk) {
   if (!basis || j <= 0) return 0;
   if (n_chunk <= 0 || n_chunk > basis->n) n_chunk = basis->n;
-  const int64_t parts = cdiv(n_chunk, 64) < 2 ? 2 : cdiv(n_chunk, 64);  // (the chunk planner needs two partial rows)
+  int64_t parts = cdiv(n_chunk, 64) < 2 ? 2 : cdiv(n_chunk, 64);  // (the chunk planner needs two partial rows)
+  if (cdiv(basis->mk, 64) > parts) parts = cdiv(basis->mk, 64);  // the Gaussian quadratic form reduces over M_k instead
   return (size_t)parts * j * sizeof(double);
 }
 

@@ -687,6 +687,23 @@ def test_ranks_just_above_a_tile_multiple(P, mk):
     assert relerr(e_in, e_want) < 1e-11
 
 
+def test_fast_path_energy_when_the_rank_exceeds_the_data(P):
+    """M_k > N (more basis functions than data rows): the Gaussian quadratic-form energy reduces over M_k, and the
+    workspace query must size for it (found by tools/fastpath_sweep.py)."""
+    gen = torch.Generator().manual_seed(5)
+    mk, n, j = 300, 100, 40
+    a = torch.randn(mk, n, generator=gen, dtype=torch.float64) / mk ** 0.5
+    lam = torch.rand(mk, generator=gen, dtype=torch.float64) + 0.5
+    u = torch.randn(mk, j, generator=gen, dtype=torch.float64)
+    y = torch.randn(n, generator=gen, dtype=torch.float64)
+    basis = P.basis.OrthonormalBasis.from_projection(cu(a), cu(lam))
+    gc = P.costs.GaussianCost(0.4, y, P.links.IdentityLinkFunction())
+    e_fast = basis.fused_particle_energy(gc, cu(u))
+    e_gen = basis.fused_particle_energy(gc, cu(u), force_generic=True)
+    want = ((a.T @ u - y[:, None]) ** 2).sum(0) / 0.8 + 0.5 * (u * u / lam[:, None]).sum(0)
+    assert relerr(e_fast, want) < 1e-11 and relerr(e_gen, want) < 1e-11
+
+
 def test_random_shape_sweep_against_the_oracle(P, rank_path):
     """Seeded sweep over ragged (N, M, J, D): one Gaussian and one non-Gaussian step + energy per draw against the
     oracle, through whichever path `rank_path` selects (M <= 128 throughout, so `small_rank` really is the fused
