@@ -704,6 +704,44 @@ def test_fast_path_energy_when_the_rank_exceeds_the_data(P):
     assert relerr(e_fast, want) < 1e-11 and relerr(e_gen, want) < 1e-11
 
 
+def test_fuzz_fused_against_unfused_composition(P):
+    """120 seeded random draws of (N, M_k, J, cost, workspace): the fused step and its energy by-product against the
+    un-fused composition of the SAME library (pls_onb_forward -> cost kernels -> pls_onb_particle_update: plain GEMMs
+    and element-wise kernels, no epilogue fusion, no small-rank kernel) -- two independent code paths on the device,
+    so odd shapes, chunked workspaces and every kernel family get cross-checked without a CPU in the loop."""
+    rng = np.random.default_rng(99)
+    for draw in range(120):
+        n = int(rng.integers(1, 6000))
+        mk = int(rng.choice([1, 3, 16, 17, 64, 100, 128, 129, 130, 200, 260]))
+        j = int(rng.choice([1, 5, 63, 64, 65, 257, 1000, 2500]))
+        gen = torch.Generator().manual_seed(7000 + draw)
+        a = torch.randn(mk, n, generator=gen, dtype=torch.float64) / mk ** 0.5
+        lam = torch.rand(mk, generator=gen, dtype=torch.float64) + 0.5
+        u = torch.randn(mk, j, generator=gen, dtype=torch.float64)
+        xi = torch.randn(mk, j, generator=gen, dtype=torch.float64)
+        basis = P.basis.OrthonormalBasis.from_projection(cu(a), cu(lam), poison_padding=True)
+        f_host = a.T @ u
+        fstar = f_host[:, 0].clone()
+        costs = make_costs(P, fstar + 0.1 * torch.randn(n, generator=gen, dtype=torch.float64), fstar, gen)
+        name, _, gc = costs[draw % 6]
+        if name.startswith("poisson") and f_host.abs().min().item() < 1e-3:
+            name, _, gc = costs[2]  # 1/f too ill-conditioned for a tight two-path comparison
+        if draw % 3 == 0:  # small workspace: N streamed in chunks (two-GEMM path) / slab limits
+            lib = P.pkg._lib.load()
+            basis.workspace_bytes = lib.pls_onb_step_workspace_bytes(basis._desc(), j, max(128, n // 3))
+        e_in = torch.empty(j, dtype=torch.float64, device="cuda")
+        noise = P.basis.NoiseSpec(injected=cu(xi))
+        fused = basis.fused_step(gc, cu(u), 1e-3, noise=noise, force_generic=True, input_energy=e_in)
+        fdev = basis.calculate_untransformed_train_prediction_samples(cu(u))
+        unfused = basis.calculate_particle_update(cu(u), gc.calculate_cost_derivative(fdev), 1e-3, noise=cu(xi))
+        tag = f"draw {draw}: N={n} M_k={mk} J={j} {name}"
+        assert torch.isfinite(fused).all(), tag
+        assert relerr(fused, unfused) < 1e-9, tag
+        e_unfused = basis.particle_energy_potential(cu(u), gc.calculate_cost(fdev))
+        assert relerr(e_in, e_unfused) < 1e-9, tag
+        assert relerr(basis.fused_particle_energy(gc, cu(u), force_generic=True), e_unfused) < 1e-9, tag
+
+
 def test_random_shape_sweep_against_the_oracle(P, rank_path):
     """Seeded sweep over ragged (N, M, J, D): one Gaussian and one non-Gaussian step + energy per draw against the
     oracle, through whichever path `rank_path` selects (M <= 128 throughout, so `small_rank` really is the fused
