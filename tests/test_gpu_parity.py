@@ -742,6 +742,48 @@ def test_fuzz_fused_against_unfused_composition(P):
         assert relerr(basis.fused_particle_energy(gc, cu(u), force_generic=True), e_unfused) < 1e-9, tag
 
 
+def test_fuzz_inducing_point_basis_paths(P):
+    """30 seeded random draws on the inducing-point basis: fused step (N x M x J path) and its energy by-product against
+    the un-fused composition, and for the Gaussian cost the M x M x J algebraic path against both."""
+    rng = np.random.default_rng(123)
+    for draw in range(30):
+        n = int(rng.integers(20, 3000))
+        m = int(rng.integers(2, min(n, 150)))
+        j = int(rng.choice([1, 7, 64, 130, 700]))
+        d = int(rng.integers(1, 5))
+        pr = make_problem(n, m, j, d, seed=9000 + draw)
+        pr["ls"] = pr["ls"] * 0.2
+        try:
+            ob, gb = build_ipb(P, pr)
+        except torch.linalg.LinAlgError:
+            continue  # this draw's k(Z,Z) is numerically singular (the reference could not factorise it either)
+        cond = torch.linalg.cond(ob.base_gram_induce).item()
+        if cond > 1e8:
+            continue
+        tested = locals().get("tested", 0) + 1
+        costs = make_costs(P, pr["y"], pr["fstar"], pr["gen"])
+        name, _, gc = costs[draw % 5]
+        u = pr["u"]
+        e_noise = torch.randn(m, j, generator=pr["gen"])
+        noise = P.basis.NoiseSpec(injected=cu(e_noise))
+        fdev = gb.calculate_untransformed_train_prediction_samples(cu(u))
+        if name.startswith("poisson") and fdev.abs().min().item() < 1e-3:
+            name, _, gc = costs[2]
+        tol = max(1e-9, cond * 1e-13)
+        e_in = torch.empty(j, dtype=torch.float64, device="cuda")
+        fused = gb.fused_step(gc, cu(u), 1e-3, noise=noise, force_generic=True, input_energy=e_in)
+        unfused = gb.calculate_particle_update(cu(u), gc.calculate_cost_derivative(fdev), 1e-3, noise=cu(e_noise))
+        tag = f"draw {draw}: N={n} M={m} J={j} {name} cond={cond:.1e}"
+        assert relerr(fused, unfused) < tol, tag
+        e_unfused = gb.particle_energy_potential(cu(u), gc.calculate_cost(fdev))
+        assert relerr(e_in, e_unfused) < tol, tag
+        if name.startswith("gaussian/identity"):
+            e_fast_in = torch.empty(j, dtype=torch.float64, device="cuda")
+            fast = gb.fused_step(gc, cu(u), 1e-3, noise=noise, input_energy=e_fast_in)
+            assert relerr(fast, unfused) < tol and relerr(e_fast_in, e_unfused) < tol, tag
+    assert tested >= 15, f"only {tested} of 30 draws were well conditioned"
+
+
 def test_random_shape_sweep_against_the_oracle(P, rank_path):
     """Seeded sweep over ragged (N, M, J, D): one Gaussian and one non-Gaussian step + energy per draw against the
     oracle, through whichever path `rank_path` selects (M <= 128 throughout, so `small_rank` really is the fused
