@@ -298,6 +298,41 @@ def test_gemm_tn(P, i, j, k):
     assert relerr(c, 0.75 * (a.T @ b) - 0.5 * c0) < 1e-13
 
 
+def test_gemm_tn_fuzz_against_device_matmul(P):
+    """80 seeded random (I, J, K, alpha, beta, leading dimensions, odd / unaligned views) through pls_gemm_tn against
+    torch's fp64 matmul on the same device: both tile configurations, the direct and the LDS epilogue (interior and
+    edge tiles), accumulate (beta != 0) and the unaligned register path, padding poisoned with NaN."""
+    L = P.pkg._lib
+    rng = np.random.default_rng(4242)
+    for draw in range(80):
+        i = int(rng.choice([1, 2, 63, 64, 65, 127, 128, 129, 300, 1000, 2048, 5000]))
+        j = int(rng.choice([1, 3, 64, 100, 128, 257, 1024, 3000]))
+        k = int(rng.choice([1, 4, 15, 16, 17, 31, 33, 100, 1000, 4097]))
+        if i * j * k > 4e9:
+            continue
+        pad_l, pad_r, pad_c = (int(v) for v in rng.integers(0, 3, 3))  # odd paddings break the 16-byte vector path
+        off = int(rng.integers(0, 2))  # start one double into the buffer: unaligned base
+        g = torch.Generator().manual_seed(100 + draw)
+        lbuf = torch.full((k, i + pad_l + off), float("nan"), dtype=torch.float64, device="cuda")
+        rbuf = torch.full((k, j + pad_r + off), float("nan"), dtype=torch.float64, device="cuda")
+        cbuf = torch.full((i, j + pad_c), float("nan"), dtype=torch.float64, device="cuda")
+        lm, rm, cm = lbuf[:, off:off + i], rbuf[:, off:off + j], cbuf[:, :j]
+        lm.copy_(torch.randn(k, i, generator=g, dtype=torch.float64))
+        rm.copy_(torch.randn(k, j, generator=g, dtype=torch.float64))
+        c0 = torch.randn(i, j, generator=g, dtype=torch.float64).cuda()
+        cm.copy_(c0)
+        alpha = float(rng.choice([1.0, -0.5, 2.25]))
+        beta = float(rng.choice([0.0, 0.0, 1.0, -0.75]))
+        L.check(L.load().pls_gemm_tn(lm.data_ptr(), lm.stride(0), rm.data_ptr(), rm.stride(0), cm.data_ptr(), cm.stride(0), i, j, k,
+                                     alpha, beta, L.stream_ptr()), "pls_gemm_tn")
+        want = alpha * (lm.T.contiguous() @ rm.contiguous()) + beta * c0
+        tag = f"draw {draw}: I={i} J={j} K={k} alpha={alpha} beta={beta} pads={pad_l},{pad_r},{pad_c} off={off}"
+        assert torch.isfinite(cm).all(), tag
+        assert relerr(cm, want) < 1e-12, tag
+        if pad_c:
+            assert torch.isnan(cbuf[:, j:]).all(), tag + " (padding of C overwritten)"
+
+
 def test_philox_stream_matches_numpy_restatement(P):
     L = P.pkg._lib
     for rows, cols, seed, step, joff in [(8, 16, 1, 0, 0), (13, 37, 0xDEADBEEFCAFE, 5, 1000), (1030, 70, 2**63 + 11, 2**33 + 3, 123456)]:
