@@ -98,7 +98,11 @@ def host_cores() -> int:
 
 def cpu_baseline(cfg, x, z, y, ls, lam_all, vec_all):
     """The oracle ("port": faithful torch-CPU restatement of the reference's step, oracle/pls_oracle.py) timed on this
-    box's host cores on a bounded sample: two particle-subset sizes, linear in J, extrapolated to the full J."""
+    box's host cores.  The step is MEASURED at the configuration's full (N, J) whenever 1 warm-up + 2 timed steps fit the
+    ~30 s budget (configs[1], configs[2]); a larger configuration is timed on a stated (N, J) sub-sample and scaled by
+    the flop ratio of the step, and the sample string says so."""
+    import resource
+
     from oracle import pls_oracle as O
 
     cores = host_cores()
@@ -106,53 +110,83 @@ def cpu_baseline(cfg, x, z, y, ls, lam_all, vec_all):
     prev = torch.get_default_dtype()
     torch.set_default_dtype(torch.float64)
     try:
+        m, mk = z.shape[0], lam_all.shape[0]
+        n_full, j_full = x.shape[0], cfg["j"]
+
+        def step_flop(n, j):  # reference association: (K_XZ V~) U, V~^T K_ZX then @ G, + the dense diag(1/lam) @ U
+            return 4.0 * n * m * mk + 4.0 * n * mk * j + 2.0 * mk * mk * j
+
+        budget = 1.3e13  # ~25 s at the ~0.5 TFLOP/s these 16 host cores sustain in fp64
+        n_s, j_s = n_full, j_full
+        while 3 * step_flop(n_s, j_s) > budget and j_s > max(256, j_full // 8):
+            j_s //= 2
+        while 3 * step_flop(n_s, j_s) > budget and n_s > 20_000:
+            n_s //= 2
+        xs, ys = x[:n_s], y[:n_s]
         ob = O.OrthonormalBasis.__new__(O.OrthonormalBasis)  # reuse the spectrum already computed for the GPU basis
         kern = O.RBFARDKernel(ls, 1.0)
         ob.base_kernel, ob.x_induce = kern, z
         ob.base_gram_induce = None
-        ob.base_gram_induce_train = torch.empty(z.shape[0], x.shape[0])
-        for r0 in range(0, x.shape[0], 8192):  # chunked k(Z,X): the broadcasted build would need N*M*D doubles
-            ob.base_gram_induce_train[:, r0:r0 + 8192] = kern(z, x[r0:r0 + 8192])
-            if (r0 // 8192) % 4 == 0:
-                log(f"cpu baseline: host k(Z,X) rows {r0}/{x.shape[0]}")
+        ob.base_gram_induce_train = torch.empty(m, n_s)
+        for r0 in range(0, n_s, 8192):  # chunked k(Z,X): the broadcasted build would need N*M*D doubles
+            ob.base_gram_induce_train[:, r0:r0 + 8192] = kern(z, xs[r0:r0 + 8192])
+            if (r0 // 8192) % 8 == 0:
+                log(f"cpu baseline: host k(Z,X) rows {r0}/{n_s}")
         ob.eigenvalues, ob.eigenvectors = lam_all, vec_all
-        ob.scaled_eigenvectors = vec_all / torch.sqrt(lam_all.shape[0] * lam_all)[None, :]
+        ob.scaled_eigenvectors = vec_all / torch.sqrt(mk * lam_all)[None, :]
         if cfg["cost"] == "poisson":
-            oc = O.PoissonCost(y, O.SquareLink())
+            oc = O.PoissonCost(ys, O.SquareLink())
         elif cfg["cost"] == "bernoulli":
-            oc = O.BernoulliCost(y, O.SigmoidLink())
+            oc = O.BernoulliCost(ys, O.SigmoidLink())
         else:
-            oc = O.GaussianCost(cfg["obs"], y, O.IdentityLink())
+            oc = O.GaussianCost(cfg["obs"], ys, O.IdentityLink())
         pls = O.PLS(ob, oc)
-        mk = lam_all.shape[0]
-        times = {}
-        j_full = cfg["j"]
-        j_samples = sorted({max(64, j_full // 16), max(128, j_full // 8)})
-        log(f"cpu baseline: k(Z,X) built on the host, {cores} threads")
-        for js in j_samples:
-            log(f"cpu baseline: timing oracle steps at J={js}")
-            u = torch.randn(mk, js, generator=torch.Generator().manual_seed(3))
-            u += pls.calculate_particle_update(u, 1e-12)  # warm-up
-            t0 = time.perf_counter()
-            reps = 2
-            for _ in range(reps):
-                u += pls.calculate_particle_update(u, 1e-12)  # faithful: eigh(I) noise, dense diag @ U, full F and G
-                log(f"cpu baseline: step done ({time.perf_counter() - t0:.1f} s since start of timing)")
-            times[js] = (time.perf_counter() - t0) / reps
-        (j1, t1), (j2, t2) = sorted(times.items())
-        slope = (t2 - t1) / (j2 - j1)
-        t_full = t1 + slope * (j_full - j1)
+        log(f"cpu baseline: k(Z,X) built on the host, {cores} threads; timing the oracle step at N={n_s}, J={j_s}")
+        u = torch.randn(mk, j_s, generator=torch.Generator().manual_seed(3))
+        t0 = time.perf_counter()
+        u += pls.calculate_particle_update(u, 1e-12)  # warm-up (thread pool, page faults of the N x J temporaries)
+        log(f"cpu baseline: warm-up step {time.perf_counter() - t0:.1f} s")
+        reps = 2
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            u += pls.calculate_particle_update(u, 1e-12)  # faithful: eigh(I) noise, dense diag @ U, full F and G
+            log(f"cpu baseline: step done ({time.perf_counter() - t0:.1f} s since start of timing)")
+        t_s = (time.perf_counter() - t0) / reps
+        scale = step_flop(n_full, j_full) / step_flop(n_s, j_s)
+        t_full = t_s * scale
+        rss_gb = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1048576.0
+        full = (n_s, j_s) == (n_full, j_full)
+        how = ("measured at the full configuration, no extrapolation" if full else
+               f"sub-sample N={n_s} of {n_full}, J={j_s} of {j_full}; scaled by the step's flop ratio x{scale:.2f} to "
+               f"{t_full:.1f} s/step (the full step would take minutes of host time)")
         return {
             "value": 1.0 / t_full,
             "unit": "steps/s",
             "cores": cores,
             "kind": "port",
-            "sample": f"oracle step (reference op order incl. per-step eigh(I) noise) at J={j1} ({t1:.2f} s/step) and J={j2} "
-                      f"({t2:.2f} s/step) of {j_full}, 1 warm-up + 2 timed steps each, linear-in-J extrapolation to J={j_full} "
-                      f"({t_full:.2f} s/step)",
+            "extrapolated": not full,
+            "sample": f"oracle step (reference op order incl. per-step eigh(I) noise, full N x J F and G) at N={n_s}, J={j_s}: "
+                      f"1 warm-up + {reps} timed steps, {t_s:.2f} s/step, peak RSS {rss_gb:.1f} GB; {how}",
         }
     finally:
         torch.set_default_dtype(prev)
+
+
+def self_launch(n_ranks: int) -> int:
+    """Run this script as ``n_ranks`` ranks under torch.distributed.run (one rank per GPU, rendezvous on 127.0.0.1) in a
+    child process and return its exit code.  stdout/stderr are inherited, so rank 0's JSON line is this process's too."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
+    log(f"--gpus {n_ranks} without a launcher: starting {n_ranks} ranks under torch.distributed.run (port {port})")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -175,21 +209,26 @@ def main():
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, as a CHILD process, before this
+        # process has touched the GPU (nothing above initialises HIP), and relay rank 0's JSON line and the exit code
+        sys.exit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     # one rank per GPU; (the modulo only matters for the development rehearsal of several ranks on a one-GPU box)
-    torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    device_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
     import torch.distributed as dist
 
     if world > 1 or "RANK" in os.environ:
         # RCCL ("nccl") in production; PLS_BENCH_BACKEND=gloo lets a one-GPU box rehearse the multi-rank control flow
-        dist.init_process_group(os.environ.get("PLS_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
+        backend = os.environ.get("PLS_BENCH_BACKEND", "nccl")
+        extra = {"device_id": torch.device("cuda", device_index)} if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **extra)
 
     import projected_langevin_sampling_amd as pkg
     from projected_langevin_sampling_amd import distributed as D
@@ -285,17 +324,28 @@ def main():
     gemm_launches = sum(tl[k]["launches"] for k in dom if k in tl)
     flop_per_step_rank = 4.0 * n * m * j_loc
     achieved = flop_per_step_rank * args.steps / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    # HBM bytes per launch of the same two kernels on the same workload come from separate rocprofv3 --pmc passes
+    # (FETCH_SIZE doubled, WRITE_SIZE as is: MI355X_MICROARCH.md "HBM"; tools/profile_bench.sh + tools/summarize_prof.py).
+    # A counter pass cannot run inside this process, so the committed summary is used ONLY when it was collected from
+    # exactly the kernel sources of this tree (tools/source_hash.py stamp); otherwise traffic stays null.
     traffic, traffic_src = None, None
-    prof = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-    if args.config == "c2" and world == 1 and shard_world == 1 and os.path.exists(prof):
-        # HBM bytes per launch of the same two kernels on the same workload, from separate rocprofv3 --pmc passes
-        # (FETCH_SIZE doubled, WRITE_SIZE as is: MI355X_MICROARCH.md "HBM"); see tools/profile_bench.sh
-        pm = json.load(open(prof))
-        ks = [pm.get("gemm_tn_f64<128x128>::EpiGaussDeriv", pm.get("gemm_tn_f64<128x128>::EpiCostDeriv", {})),
-              pm.get("gemm_tn_f64<128x128>::EpiStore", {})]
-        if all("hbm_bytes_per_launch" in k for k in ks):
-            traffic = sum(k["hbm_bytes_per_launch"] for k in ks) / len(ks)
-            traffic_src = "profiles/r01_pmc_summary.json"
+    if args.config == "c2" and world == 1 and shard_world == 1:
+        import glob
+
+        from tools.source_hash import kernel_source_hash
+
+        here = kernel_source_hash()
+        traffic_src = "no PMC summary under profiles/ was collected from the current kernel sources"
+        for prof in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), reverse=True):
+            pm = json.load(open(prof))
+            if pm.get("_kernel_source_hash") != here:
+                continue
+            ks = [pm.get("gemm_tn_f64<128x128>::EpiGaussDeriv", pm.get("gemm_tn_f64<128x128>::EpiCostDeriv", {})),
+                  pm.get("gemm_tn_f64<128x128>::EpiStore", {})]
+            if all("hbm_bytes_per_launch" in k for k in ks):
+                traffic = sum(k["hbm_bytes_per_launch"] for k in ks) / len(ks)
+                traffic_src = f"profiles/{os.path.basename(prof)} (kernel sources {here[:12]})"
+                break
     roofline = {
         "kernel": ("small_rank_kernel<KB,drift> (F, d cost/d f and back-projection fused; N x J intermediates never written)"
                    if dom[0] == "small_rank_drift" else

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
-from .kernel import _dev, as_base_kernel
+from .kernel import PLSKernel, _dev, as_base_kernel
 
 
 class InducingPointSelector(ABC):
@@ -38,7 +38,12 @@ class ConditionalVarianceInducingPointSelector(InducingPointSelector):
 
     def compute_induce_data(self, x: torch.Tensor, m: int, kernel, jitter: float = 1e-12) -> Tuple[torch.Tensor, torch.Tensor]:
         assert m > 1, "Must have at least 2 inducing points"  # conditional_variance.py:57
-        base = as_base_kernel(getattr(kernel, "base_kernel", kernel) if not hasattr(kernel, "kind") else kernel)
+        if isinstance(kernel, PLSKernel):
+            # the reference would select on r = k(., S) k(S, .)^T / |S| (an N x N Gram of the PLS kernel); its experiments
+            # always pass the base ScaleKernel(RBFKernel) (experiments/uci/regression/main.py:203), and so must callers here
+            raise TypeError("ConditionalVarianceInducingPointSelector selects on a base kernel (ARDKernel / LinearKernel / a "
+                            "gpytorch ScaleKernel(RBFKernel)); pass pls_kernel.base_kernel, not the PLSKernel")
+        base = as_base_kernel(kernel)  # ARDKernel / LinearKernel as is; ScaleKernel(RBFKernel): lengthscale AND outputscale
         n = x.shape[0]
         perm = np.random.permutation(n)  # permute entries so tie-breaking is random (:58-61)
         xp = x[torch.as_tensor(perm)] if isinstance(x, torch.Tensor) else torch.as_tensor(x)[perm]

@@ -293,3 +293,24 @@ def test_conformalise_goldens(G):
     assert torch.allclose(torch.quantile(samples_fn(xc), q=0.5, dim=1), t32(c["median"]))
     lo, up = O.conformal_predict_coverage(samples_fn, xc, yc, xc, 0.95)
     assert np.allclose(torch.mean(up - lo).item(), c["average_interval_width_095"])
+
+
+# Random123 known-answer vectors of Philox4x32-10 (Salmon et al., SC'11; kat_vectors of the Random123 distribution):
+# (counter words, key words) -> output words.  They pin oracle/philox_ref.py, which in turn pins csrc/philox.h through
+# tests/test_gpu_parity.py::test_philox_stream_matches_numpy_restatement.
+PHILOX4X32_10_KAT = [
+    ((0x00000000, 0x00000000, 0x00000000, 0x00000000), (0x00000000, 0x00000000),
+     (0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8)),
+    ((0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF), (0xFFFFFFFF, 0xFFFFFFFF),
+     (0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD)),
+    ((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0),
+     (0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1)),
+]
+
+
+@pytest.mark.parametrize("ctr,key,want", PHILOX4X32_10_KAT)
+def test_philox4x32_10_known_answer_vectors(ctr, key, want):
+    from oracle import philox_ref
+
+    got = philox_ref.philox4x32_10(*[np.array([c], dtype=np.uint64) for c in ctr], key[0], key[1])
+    assert tuple(int(g[0]) for g in got) == want

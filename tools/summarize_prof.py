@@ -54,6 +54,12 @@ for k, d in rows.items():
     if "TCC_HIT_sum" in ent:
         ent["l2_hit_rate"] = ent["TCC_HIT_sum"] / (ent["TCC_HIT_sum"] + ent["TCC_MISS_sum"])
     summary[k] = ent
+sys.path.insert(0, ROOT)
+from tools.source_hash import kernel_source_hash  # noqa: E402
+
+summary["_kernel_source_hash"] = kernel_source_hash()  # bench.py quotes roofline.traffic only from a matching summary
 json.dump(summary, open(os.path.join(out_dir, f"{tag}_pmc_summary.json"), "w"), indent=1, sort_keys=True)
 for k, e in summary.items():
+    if not isinstance(e, dict):
+        continue
     print(k, {kk: (round(v, 4) if isinstance(v, float) else v) for kk, v in e.items() if kk.startswith(("_", "hbm", "mfma", "clock", "l2"))})
