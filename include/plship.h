@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PLSHIP_ABI_VERSION 1
+#define PLSHIP_ABI_VERSION 2
 
 typedef enum {
   PLS_OK = 0,
@@ -122,23 +122,60 @@ typedef struct {
   const double *c; /* may be NULL */
 } pls_onb_desc;
 
+/* Cholesky factor of an SPD matrix K = Lc Lc^T as pls_chol_factor leaves it on the device:
+ *   Lc  (M x M, lower, row-major) and LcT = Lc^T (upper): the same factor stored both ways, so that either is a k-major
+ *       operand of the MFMA contraction;
+ *   Sf, Sb (M x M): the block forward / backward substitution operators.  With D_b the inverse of the b-th 128 x 128
+ *       DIAGONAL block of Lc:  Sf[k][i] = -(D_b Lc[b, k-block])^T for k-blocks left of block b (i in block b), D_b^T on the
+ *       diagonal block;  Sb[k][i] = -(Lc[k-block, b] D_b) for k-blocks below, D_b on the diagonal.  One block row of a
+ *       solve is then a single MFMA k-loop; K^-1 itself is never formed.  NULL if the factor is only used for L xi. */
+typedef struct {
+  int64_t m;
+  const double *Lc;
+  int64_t ldlc;
+  const double *LcT;
+  int64_t ldlct;
+  const double *Sf;
+  int64_t ldsf;
+  const double *Sb;
+  int64_t ldsb;
+} pls_chol_desc;
+
 /* Inducing-point basis state (reference: basis/inducing_point.py:23-50).
- *   Kzx = k(Z,X) (M x N), Kxz = its transpose (N x M), W = k(Z,Z)^{-1} (M x M, symmetric),
- *   Lc = lower Cholesky factor of k(Z,Z) stored TRANSPOSED (Lc^T, upper, M x M) for noise colouring. */
+ *   Kzx = k(Z,X) (M x N), Kxz = its transpose (N x M);
+ *   k(Z,Z) enters through its Cholesky factor (pls_chol_factor): LcT = Lc^T for the noise colouring e = Lc xi, and the
+ *   substitution operators Sf / Sb for the two solves per step, V = k(Z,Z)^-1 U = Lc^-T Lc^-1 U (the reference's
+ *   gpytorch.solve, inducing_point.py:89-93, :130-132).
+ *   W = k(Z,Z)^-1 (M x M, symmetric) is OPTIONAL and only used for A/B runs: with Sf/Sb == NULL, or after
+ *   pls_set_option(PLS_OPT_IPB_EXPLICIT_INVERSE, 1), the solves are replaced by the contraction W U. */
 typedef struct {
   int64_t m, n;
   const double *Kzx;
   int64_t ldkzx;
   const double *Kxz;
   int64_t ldkxz;
-  const double *W;
+  const double *W; /* may be NULL when Sf / Sb are set */
   int64_t ldw;
   const double *LcT; /* may be NULL when noise is injected already coloured */
   int64_t ldlct;
   const double *B; /* optional Gaussian fast path: Kzx Kxz (M x M), see pls_ipb_build_gaussian */
   int64_t ldb;
   const double *c; /* optional: Kzx y (M), then y^T y */
+  const double *Sf; /* substitution operators of pls_chol_factor (see pls_chol_desc) */
+  int64_t ldsf;
+  const double *Sb;
+  int64_t ldsb;
 } pls_ipb_desc;
+
+/* Step-size search (experiments/runners.py:331-446): the S candidate step sizes run as S column blocks of ONE particle
+ * matrix, block b = columns [b * block_cols, (b + 1) * block_cols).  Every block is an independent copy of the same
+ * sampler: its step size is eta[b], and its noise stream is the one a stand-alone run of block_cols particles would
+ * draw (Philox column = j_offset + column inside the block), so a batched search reproduces the sequential one.
+ * eta is a DEVICE array: a block whose search has ended is frozen by writing 0 (update and noise both vanish). */
+typedef struct {
+  int64_t block_cols;
+  const double *eta; /* device, cdiv(j, block_cols) entries */
+} pls_block_desc;
 
 const char *pls_last_error(void);
 int pls_abi_version(void);
@@ -147,7 +184,12 @@ int pls_abi_version(void);
  *   PLS_OPT_SMALL_RANK_MAX: bases with at most this many functions (0..128, default 128) take the fused small-rank
  *   kernels (F, d cost / d f and the back-projection in ONE pass: the N x J matrices F and G are never written);
  *   larger ranks, or 0, take the two-GEMM path.  Results agree to rounding, not bit for bit. */
-typedef enum pls_option { PLS_OPT_SMALL_RANK_MAX = 1 } pls_option;
+typedef enum pls_option {
+  PLS_OPT_SMALL_RANK_MAX = 1,
+  /* 1: V = k(Z,Z)^-1 U of the inducing-point basis as the contraction W U with the explicit inverse (needs
+   * pls_ipb_desc.W); 0 (default): two blocked triangular solves with the Cholesky factor (pls_chol_solve). */
+  PLS_OPT_IPB_EXPLICIT_INVERSE = 2
+} pls_option;
 /* Diagnostic: out[i] = op(x[i]) with the device exp (op 0) / log (op 1) the per-element kernels use (csrc/fmath.h),
  * so that their accuracy can be pinned against libm.  Not on the step path. */
 int pls_debug_math(int32_t op, const double *x, double *out, int64_t n, void *stream);
@@ -167,7 +209,8 @@ typedef enum {
   PLS_TAG_KERNEL_GRAM = 6,
   PLS_TAG_OTHER = 7,
   PLS_TAG_SMALL_RANK_DRIFT = 8,      /* small_rank_kernel: F, d cost / d f and the back-projection in one pass (rank <= 128) */
-  PLS_TAG_SMALL_RANK_VALUE = 9       /* small_rank_kernel: F and the per-column cost sums in one pass */
+  PLS_TAG_SMALL_RANK_VALUE = 9,      /* small_rank_kernel: F and the per-column cost sums in one pass */
+  PLS_TAG_TRI_SOLVE = 10             /* tri_solve_strip_kernel: V = Lc^-T Lc^-1 U, forward + backward substitution in one launch */
 } pls_kernel_tag;
 int pls_timeline_begin(int32_t capacity);
 int pls_timeline_end(float *ms, int32_t *tags, int32_t capacity, int32_t *count);
@@ -227,6 +270,41 @@ int pls_counter_add(uint64_t *counter, uint64_t increment, void *stream);
 int pls_normal_fill(double *out, int64_t ldout, int64_t rows, int64_t j, uint64_t seed, uint64_t step,
                     int64_t j_offset, void *stream);
 
+/* out[b] = mean of e[b * block_cols .. (b + 1) * block_cols) (the last block may be shorter), b < nblocks; fixed
+ * summation order.  Replaces `.mean()` of the per-particle energies (orthonormal.py:126, inducing_point.py:115), per
+ * step-size candidate when the particle matrix holds several (pls_block_desc).  `out` may be device memory or pinned
+ * host memory mapped into the device (the training loop reads it after an event, without a copy kernel). */
+int pls_block_means(const double *e, int64_t j, int64_t block_cols, double *out, void *stream);
+
+/* Cholesky factorisation on the device: K (M x M, SPD, row-major; only read) + jitter * I = Lc Lc^T.
+ * Replaces the factorisation inside gpytorch.solve(lhs = k(Z,Z), ...) (inducing_point.py:89-93, :104-106, :130-132,
+ * :235-239) and the per-step eigh(k(Z,Z)) of the noise sampler (samplers.py:27 via inducing_point.py:133-137).
+ * Right-looking blocked algorithm, 64-column panels; the trailing updates run on the fp64 MFMA contraction.
+ * Outputs (caller-allocated, M x M each, 16-byte aligned, even leading dimensions): Lc, LcT and -- unless NULL -- the
+ * substitution operators Sf, Sb (see pls_chol_desc).  info (DEVICE int32): 0, or the 1-based index of the first
+ * pivot that was not positive (K + jitter I is not numerically positive definite; the outputs are then garbage and the
+ * caller retries with a larger jitter, as gpytorch's psd_safe_cholesky does).  Nothing synchronises. */
+int pls_chol_factor(const double *K, int64_t ldk, int64_t m, double jitter, double *Lc, int64_t ldlc, double *LcT,
+                    int64_t ldlct, double *Sf, int64_t ldsf, double *Sb, int64_t ldsb, int32_t *info, void *stream);
+
+/* The substitution operators Sf, Sb (see pls_chol_desc) of a factor that is already on the device -- pls_chol_factor
+ * ends with this call; parity runs upload the oracle's own LAPACK factor (Lc and its transpose, zeros in the other
+ * triangle) and build the operators from it, so that both sides solve with the SAME factor.  Sf and Sb must be zero
+ * outside the blocks this call writes (block upper / lower triangle). */
+int pls_chol_build_operators(const double *Lc, int64_t ldlc, const double *LcT, int64_t ldlct, int64_t m, double *Sf,
+                             int64_t ldsf, double *Sb, int64_t ldsb, void *stream);
+
+/* V (M x J) = K^-1 U = Lc^-T Lc^-1 U: block forward then backward substitution in ONE launch (a workgroup owns 32
+ * columns for the whole solve).  Replaces gpytorch.solve(lhs = k(Z,Z), input = k(Z,Z), rhs = U).  V must not alias U. */
+int pls_chol_solve(const pls_chol_desc *factor, const double *U, int64_t ldu, int64_t j, double *V, int64_t ldv,
+                   void *stream);
+
+/* out (M x J) = Lc X with the TRANSPOSED factor LcT (upper) as the k-major operand; only k <= row is contracted.
+ * Colours standard normals: e = Lc xi ~ N(0, k(Z,Z)) (replaces sample_multivariate_normal's Q sqrt(Lambda) xi,
+ * samplers.py:37-44, same law). */
+int pls_tri_multiply(const double *LcT, int64_t ldlct, int64_t m, const double *X, int64_t ldx, int64_t j, double *out,
+                     int64_t ldo, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Orthonormal basis: setup + step
  * ------------------------------------------------------------------------------------------- */
@@ -270,6 +348,12 @@ int pls_onb_step(const pls_onb_desc *basis, const pls_cost_desc *cost, const dou
                  int64_t j, double eta, const pls_noise_desc *noise, double *out, int64_t ldo, int32_t out_mode,
                  int32_t force_generic, double *energy_in, void *workspace, size_t workspace_bytes, void *stream);
 
+/* pls_onb_step with one step size PER COLUMN BLOCK (pls_block_desc): the batched step-size search. */
+int pls_onb_step_blocks(const pls_onb_desc *basis, const pls_cost_desc *cost, const double *y, double *U, int64_t ldu,
+                        int64_t j, const pls_block_desc *blocks, const pls_noise_desc *noise, double *out, int64_t ldo,
+                        int32_t out_mode, int32_t force_generic, double *energy_in, void *workspace,
+                        size_t workspace_bytes, void *stream);
+
 /* e(J) = cost_j + 0.5 * sum_m U_mj^2 / lam_m  (per-particle energy; the caller takes the mean over all
  * particles of all ranks).  Replaces PLS.calculate_energy_potential -> OrthonormalBasis.calculate_energy_potential
  * (projected_langevin_sampling.py:125-138, orthonormal.py:110-126).
@@ -287,14 +371,14 @@ int pls_onb_prior_energy(const pls_onb_desc *basis, const double *U, int64_t ldu
                          double *e, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Inducing-point basis: step (setup = pls_kernel_gram + a host Cholesky)
+ * Inducing-point basis: step (setup = pls_kernel_gram + pls_chol_factor)
  * ------------------------------------------------------------------------------------------- */
 
-/* F = Kxz W U (inducing_point.py:81-93). workspace: m*j doubles. */
+/* F = Kxz k(Z,Z)^-1 U (inducing_point.py:81-93). workspace: m*j doubles. */
 int pls_ipb_forward(const pls_ipb_desc *basis, const double *U, int64_t ldu, int64_t j, double *F, int64_t ldf,
                     void *workspace, size_t workspace_bytes, void *stream);
 
-/* dU = -eta Kzx G - eta M W U + sqrt(2 eta) e, e = Lc xi (inducing_point.py:117-150).
+/* dU = -eta Kzx G - eta M k(Z,Z)^-1 U + sqrt(2 eta) e, e = Lc xi (inducing_point.py:117-150).
  * PLS_NOISE_INJECTED: noise->xi is used AS e (already coloured).
  * workspace: 4 * align256(m*j*8) bytes. */
 int pls_ipb_particle_update(const pls_ipb_desc *basis, const double *U, int64_t ldu, const double *G, int64_t ldg,
@@ -309,17 +393,23 @@ int pls_ipb_step(const pls_ipb_desc *basis, const pls_cost_desc *cost, const dou
                  int64_t j, double eta, const pls_noise_desc *noise, double *out, int64_t ldo, int32_t out_mode,
                  int32_t force_generic, double *energy_in, void *workspace, size_t workspace_bytes, void *stream);
 
+/* pls_ipb_step with one step size PER COLUMN BLOCK (pls_block_desc): the batched step-size search. */
+int pls_ipb_step_blocks(const pls_ipb_desc *basis, const pls_cost_desc *cost, const double *y, double *U, int64_t ldu,
+                        int64_t j, const pls_block_desc *blocks, const pls_noise_desc *noise, double *out, int64_t ldo,
+                        int32_t out_mode, int32_t force_generic, double *energy_in, void *workspace,
+                        size_t workspace_bytes, void *stream);
+
 /* Gaussian/identity fast path constants of the inducing-point basis: B = Kzx Kxz (M x M), c[0..M) = Kzx y, c[M] = y^T y.
  * With V = K^-1 U the data drift Kzx (Kxz V - y) / sigma2 (inducing_point.py:117-150 with gaussian.py:86-88) is
  * (B V - c) / sigma2 and the cost (gaussian.py:63-73) the quadratic form (v^T B v - 2 c^T v + y^T y) / (2 sigma2). */
 int pls_ipb_build_gaussian(const pls_ipb_desc *basis, const double *y, double *B, int64_t ldb, double *c, void *stream);
 
-/* e(J) = cost_j + (M/2) * ||W U_j||^2 (inducing_point.py:95-115). */
+/* e(J) = cost_j + (M/2) * ||k(Z,Z)^-1 U_j||^2 (inducing_point.py:95-115). */
 size_t pls_ipb_energy_workspace_bytes(const pls_ipb_desc *basis, int64_t j, int64_t n_chunk);
 int pls_ipb_energy(const pls_ipb_desc *basis, const pls_cost_desc *cost, const double *y, const double *U,
                    int64_t ldu, int64_t j, double *e, int32_t force_generic, void *workspace, size_t workspace_bytes, void *stream);
 
-/* e(J) = cost_j + (M/2) * ||W U_j||^2 with the cost vector handed in (inducing_point.py:95-115).
+/* e(J) = cost_j + (M/2) * ||k(Z,Z)^-1 U_j||^2 with the cost vector handed in (inducing_point.py:95-115).
  * workspace: m*j doubles. */
 int pls_ipb_prior_energy(const pls_ipb_desc *basis, const double *U, int64_t ldu, int64_t j, const double *cost,
                          double *e, void *workspace, size_t workspace_bytes, void *stream);

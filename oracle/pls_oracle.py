@@ -578,13 +578,15 @@ def train_pls(
     step_size: float,
     early_stopper_patience: float,
     noises: Optional[List[torch.Tensor]] = None,
+    noise_fn=None,
 ) -> Tuple[torch.Tensor, List[float]]:
-    """experiments/trainers.py:139-162 (tqdm dropped).  ``noises[t]`` injects the step-t noise."""
+    """experiments/trainers.py:139-162 (tqdm dropped).  ``noises[t]`` / ``noise_fn(t)`` injects the step-t noise."""
     energy_potentials: List[float] = []
     early_stopper = EarlyStopper(patience=early_stopper_patience)
     for t in range(number_of_epochs):
+        step_noise = noise_fn(t) if noise_fn is not None else (None if noises is None else noises[t])
         update = pls.calculate_particle_update(
-            particles, step_size, noise=None if noises is None else noises[t]
+            particles, step_size, noise=step_noise
         )
         particles += update  # :157 in place
         energy = pls.calculate_energy_potential(particles)

@@ -1,0 +1,112 @@
+"""Device Cholesky factor of an SPD matrix and the solves with it (pls_chol_factor / pls_chol_solve).
+
+Replaces ``gpytorch.solve(lhs=K, input=K, rhs=U)`` of the reference (basis/inducing_point.py:89-93, :104-106, :130-132,
+:235-239).  gpytorch factorises through ``psd_safe_cholesky``: plain Cholesky first, then -- if a pivot fails -- with
+jitter 1e-8, 1e-7, 1e-6 added to the diagonal (float64 defaults: ``cholesky_jitter`` 1e-8, ``cholesky_max_tries`` 3),
+a warning per attempt and ``NotPSDError`` after the last.  Same schedule here; the factorisation itself (blocked
+right-looking, MFMA trailing updates) and the triangular solves run in libplship."""
+from __future__ import annotations
+
+import warnings
+
+import torch
+
+from . import _lib as L
+
+#: gpytorch.settings.cholesky_jitter (float64) and cholesky_max_tries defaults
+CHOLESKY_JITTER = 1e-8
+CHOLESKY_MAX_TRIES = 3
+
+
+class NotPSDError(RuntimeError):
+    """The matrix is not numerically positive definite even with the largest jitter (gpytorch's exception name)."""
+
+
+class CholeskyFactor:
+    """K (+ jitter I) = Lc Lc^T on the device: ``Lc`` (lower), ``LcT`` (upper) and the substitution operators."""
+
+    def __init__(self, lc: torch.Tensor, lct: torch.Tensor, sf: torch.Tensor, sb: torch.Tensor, jitter: float):
+        self.Lc, self.LcT, self.Sf, self.Sb, self.jitter = lc, lct, sf, sb, jitter
+        self.m = lc.shape[0]
+
+    def desc(self) -> L.CholDesc:
+        d = L.CholDesc()
+        d.m = self.m
+        d.Lc, d.ldlc = self.Lc.data_ptr(), L.ld(self.Lc)
+        d.LcT, d.ldlct = self.LcT.data_ptr(), L.ld(self.LcT)
+        d.Sf, d.ldsf = self.Sf.data_ptr(), L.ld(self.Sf)
+        d.Sb, d.ldsb = self.Sb.data_ptr(), L.ld(self.Sb)
+        return d
+
+    def solve(self, rhs: torch.Tensor) -> torch.Tensor:
+        """K^-1 rhs for a (M, J) device matrix: block forward + backward substitution, one launch."""
+        u = L.require_gpu_tensor(rhs, "rhs")
+        u = u if u.dim() == 2 and u.stride(1) == 1 else u.reshape(self.m, -1).contiguous()
+        j = u.shape[1]
+        v = torch.empty((self.m, j), dtype=torch.float64, device=u.device)
+        if j:
+            L.check(L.load().pls_chol_solve(self.desc(), u.data_ptr(), L.ld(u), j, v.data_ptr(), max(j, 1), L.stream_ptr()),
+                    "pls_chol_solve")
+        return v
+
+    def colour(self, xi: torch.Tensor) -> torch.Tensor:
+        """Lc xi: standard normals (M, J) -> N(0, K) samples (triangular product)."""
+        x = L.require_gpu_tensor(xi, "xi").contiguous()
+        j = x.shape[1]
+        out = torch.empty_like(x)
+        if j:
+            L.check(L.load().pls_tri_multiply(self.LcT.data_ptr(), L.ld(self.LcT), self.m, x.data_ptr(), L.ld(x), j,
+                                              out.data_ptr(), L.ld(out), L.stream_ptr()), "pls_tri_multiply")
+        return out
+
+
+def _alloc(m: int, device):
+    from .basis.base import alloc_matrix  # (imported here: basis/ imports this module)
+
+    return [alloc_matrix(m, m, device) for _ in range(4)]
+
+
+def cholesky_factor(k: torch.Tensor, jitter: float | None = None, max_tries: int | None = None) -> CholeskyFactor:
+    """psd_safe_cholesky on the device (schedule in the module docstring).  ``k``: (M, M) device float64, only read."""
+    k = L.require_gpu_tensor(k, "matrix")
+    assert k.dim() == 2 and k.shape[0] == k.shape[1], "square matrix expected"
+    k = k if k.stride(1) == 1 else k.contiguous()
+    m = k.shape[0]
+    if torch.isnan(k).any().item():
+        raise NotPSDError("cholesky: the matrix contains NaN")
+    jitter = CHOLESKY_JITTER if jitter is None else jitter
+    max_tries = CHOLESKY_MAX_TRIES if max_tries is None else max_tries
+    lc, lct, sf, sb = _alloc(m, k.device)
+    info = torch.zeros(1, dtype=torch.int32, device=k.device)
+    lib = L.load()
+    attempts = [0.0] + [jitter * 10**i for i in range(max_tries)]
+    for jit in attempts:
+        if jit > 0.0:
+            warnings.warn(f"A not p.d., added jitter of {jit:.1e} to the diagonal", RuntimeWarning, stacklevel=2)
+        L.check(
+            lib.pls_chol_factor(k.data_ptr(), L.ld(k), m, float(jit), lc.data_ptr(), L.ld(lc), lct.data_ptr(), L.ld(lct),
+                                sf.data_ptr(), L.ld(sf), sb.data_ptr(), L.ld(sb), info.data_ptr(), L.stream_ptr()),
+            "pls_chol_factor",
+        )
+        if int(info.item()) == 0:  # (one host sync per attempt; setup only)
+            return CholeskyFactor(lc, lct, sf, sb, jit)
+    raise NotPSDError(f"Matrix not positive definite after repeatedly adding jitter up to {attempts[-1]:.1e}.")
+
+
+def factor_from_host(chol_lower: torch.Tensor) -> CholeskyFactor:
+    """A factor computed elsewhere (e.g. the oracle's LAPACK Cholesky in a parity run): upload Lc and Lc^T, build the
+    substitution operators on the device (pls_chol_build_operators)."""
+    lh = torch.tril(chol_lower.detach().to(device="cpu", dtype=torch.float64))
+    m = lh.shape[0]
+    dev = torch.device("cuda", torch.cuda.current_device())
+    lc, lct, sf, sb = _alloc(m, dev)
+    lc.copy_(lh)
+    lct.copy_(lh.T)
+    sf.zero_()
+    sb.zero_()
+    L.check(
+        L.load().pls_chol_build_operators(lc.data_ptr(), L.ld(lc), lct.data_ptr(), L.ld(lct), m, sf.data_ptr(), L.ld(sf),
+                                          sb.data_ptr(), L.ld(sb), L.stream_ptr()),
+        "pls_chol_build_operators",
+    )
+    return CholeskyFactor(lc, lct, sf, sb, 0.0)

@@ -78,11 +78,34 @@ class IpbDesc(C.Structure):
         ("B", C.c_void_p),
         ("ldb", C.c_int64),
         ("c", C.c_void_p),
+        ("Sf", C.c_void_p),
+        ("ldsf", C.c_int64),
+        ("Sb", C.c_void_p),
+        ("ldsb", C.c_int64),
     ]
+
+
+class CholDesc(C.Structure):
+    _fields_ = [
+        ("m", C.c_int64),
+        ("Lc", C.c_void_p),
+        ("ldlc", C.c_int64),
+        ("LcT", C.c_void_p),
+        ("ldlct", C.c_int64),
+        ("Sf", C.c_void_p),
+        ("ldsf", C.c_int64),
+        ("Sb", C.c_void_p),
+        ("ldsb", C.c_int64),
+    ]
+
+
+class BlockDesc(C.Structure):
+    _fields_ = [("block_cols", C.c_int64), ("eta", C.c_void_p)]
 
 
 _P, _I64, _I32, _U64, _D, _SZ = C.c_void_p, C.c_int64, C.c_int32, C.c_uint64, C.c_double, C.c_size_t
 _CD, _ND, _OD, _ID = C.POINTER(CostDesc), C.POINTER(NoiseDesc), C.POINTER(OnbDesc), C.POINTER(IpbDesc)
+_CHD, _BD = C.POINTER(CholDesc), C.POINTER(BlockDesc)
 
 # name -> (restype, argtypes); every symbol include/plship.h declares
 SIGNATURES = {
@@ -122,7 +145,16 @@ SIGNATURES = {
     "pls_ipb_build_gaussian": (C.c_int, [_ID, _P, _P, _I64, _P, _P]),
     "pls_ipb_energy_workspace_bytes": (_SZ, [_ID, _I64, _I64]),
     "pls_ipb_energy": (C.c_int, [_ID, _CD, _P, _P, _I64, _I64, _P, _I32, _P, _SZ, _P]),
+    "pls_block_means": (C.c_int, [_P, _I64, _I64, _P, _P]),
+    "pls_chol_factor": (C.c_int, [_P, _I64, _I64, _D, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P]),
+    "pls_chol_build_operators": (C.c_int, [_P, _I64, _P, _I64, _I64, _P, _I64, _P, _I64, _P]),
+    "pls_chol_solve": (C.c_int, [_CHD, _P, _I64, _I64, _P, _I64, _P]),
+    "pls_tri_multiply": (C.c_int, [_P, _I64, _I64, _P, _I64, _I64, _P, _I64, _P]),
+    "pls_onb_step_blocks": (C.c_int, [_OD, _CD, _P, _P, _I64, _I64, _BD, _ND, _P, _I64, _I32, _I32, _P, _P, _SZ, _P]),
+    "pls_ipb_step_blocks": (C.c_int, [_ID, _CD, _P, _P, _I64, _I64, _BD, _ND, _P, _I64, _I32, _I32, _P, _P, _SZ, _P]),
 }
+
+ABI_VERSION = 2
 
 _lib = None
 
@@ -142,15 +174,17 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.pls_abi_version() != 1:
-        raise PlsHipError(f"libplship ABI {lib.pls_abi_version()} != 1")
+    if lib.pls_abi_version() != ABI_VERSION:
+        raise PlsHipError(f"libplship ABI {lib.pls_abi_version()} != {ABI_VERSION}: rebuild it (make -C csrc)")
     _lib = lib
     return lib
 
 
 OPT_SMALL_RANK_MAX = 1
+OPT_IPB_EXPLICIT_INVERSE = 2
 TAG_NAMES = {1: "gemm_store", 2: "gemm_cost_deriv", 3: "gemm_cost_value", 4: "gemm_langevin_gaussian",
-             5: "langevin_update", 6: "kernel_gram", 7: "other", 8: "small_rank_drift", 9: "small_rank_value"}
+             5: "langevin_update", 6: "kernel_gram", 7: "other", 8: "small_rank_drift", 9: "small_rank_value",
+             10: "tri_solve"}
 
 
 class Timeline:

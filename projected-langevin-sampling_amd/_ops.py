@@ -41,16 +41,43 @@ def row_power_sums(s: torch.Tensor, power: int, shift: torch.Tensor | None = Non
     return out
 
 
+ROW_QUANTILES_MAX_COLS = 16384
+
+
 def row_quantiles(s: torch.Tensor, qs) -> torch.Tensor:
     """(rows, len(qs)) quantiles over dim 1 with torch.quantile's linear interpolation (pls_row_quantiles)."""
     L.require_gpu_tensor(s, "samples")
     s = s if s.stride(1) == 1 else s.contiguous()
     rows, cols = s.shape
     q = torch.as_tensor(list(qs), dtype=torch.float64).to(s.device)
+    if cols > ROW_QUANTILES_MAX_COLS:
+        # pls_row_quantiles sorts one row per workgroup in LDS (<= 16384 samples).  Longer rows -- a calibration split above
+        # 16384 points, or the gathered samples of a J-sharded run -- go through torch's device sort: same interpolation rule
+        return torch.quantile(s, q, dim=1).T.contiguous()
     out = torch.empty((rows, q.numel()), dtype=torch.float64, device=s.device)
     L.check(
         L.load().pls_row_quantiles(s.data_ptr(), L.ld(s), rows, cols, q.data_ptr(), q.numel(), out.data_ptr(), q.numel(),
                                    L.stream_ptr()),
         "pls_row_quantiles",
     )
+    return out
+
+
+def block_means(e: torch.Tensor, block_cols: int | None = None, out: torch.Tensor | None = None, out_ptr: int | None = None) -> torch.Tensor | None:
+    """Means of consecutive blocks of ``block_cols`` entries of the per-particle vector ``e`` (pls_block_means; the whole
+    vector when block_cols is None): the ``.mean()`` of orthonormal.py:126 / inducing_point.py:115 as a fixed-order
+    libplship reduction.  ``out``: device vector to fill; ``out_ptr``: raw address instead (pinned host memory mapped into
+    the device: the value is read on the host after an event, with no copy kernel)."""
+    L.require_gpu_tensor(e, "energies")
+    e = e.contiguous()
+    j = e.numel()
+    bc = j if block_cols is None else int(block_cols)
+    nb = (j + bc - 1) // bc if j else 0
+    if out_ptr is None:
+        if out is None:
+            out = torch.empty(nb, dtype=torch.float64, device=e.device)
+        assert out.numel() >= nb and out.is_contiguous()
+        out_ptr = out.data_ptr()
+    if j:
+        L.check(L.load().pls_block_means(e.data_ptr(), j, max(bc, 1), out_ptr, L.stream_ptr()), "pls_block_means")
     return out

@@ -1,5 +1,5 @@
-from .base import NoiseSpec, PLSBasis
+from .base import BlockSpec, NoiseSpec, PLSBasis
 from .inducing_point import InducingPointBasis
 from .orthonormal import OrthonormalBasis
 
-__all__ = ["PLSBasis", "NoiseSpec", "InducingPointBasis", "OrthonormalBasis"]
+__all__ = ["PLSBasis", "NoiseSpec", "BlockSpec", "InducingPointBasis", "OrthonormalBasis"]

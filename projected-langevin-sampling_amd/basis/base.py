@@ -40,6 +40,23 @@ class NoiseSpec:
         return d
 
 
+class BlockSpec:
+    """One step size per column block of the particle matrix (pls_block_desc): the S candidates of a step-size search
+    run as S blocks of ``block_cols`` columns.  ``eta`` is a device float64 vector, one entry per block; writing 0
+    freezes a block."""
+
+    def __init__(self, block_cols: int, eta: torch.Tensor):
+        assert block_cols > 0
+        L.require_gpu_tensor(eta, "eta")
+        assert eta.dim() == 1 and eta.is_contiguous()
+        self.block_cols, self.eta = int(block_cols), eta
+
+    def desc(self) -> L.BlockDesc:
+        d = L.BlockDesc()
+        d.block_cols, d.eta = self.block_cols, self.eta.data_ptr()
+        return d
+
+
 class PLSBasis(ABC):
     """Function-space basis: initialise particles, energy potential, particle update, predictive samples."""
 
@@ -65,12 +82,22 @@ class PLSBasis(ABC):
         return NoiseSpec(seed=seed, step=0, j_offset=self.j_offset)
 
     def _workspace(self, nbytes: int, device) -> torch.Tensor:
+        """The basis' own scratch buffer for EAGER calls: grown on demand, so its address may change between calls.
+        Anything that freezes a pointer (a captured hipGraph) must own its buffer and pass it as ``workspace=``."""
         key = str(device)
         ws = self._ws.get(key)
         if ws is None or ws.numel() * 8 < nbytes:
             ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=device)
             self._ws[key] = ws
         return ws
+
+    def _pick_workspace(self, workspace: torch.Tensor | None, nbytes: int, device) -> torch.Tensor:
+        if workspace is None:
+            return self._workspace(nbytes, device)
+        L.require_gpu_tensor(workspace, "workspace")
+        if workspace.numel() * 8 < nbytes:
+            raise L.PlsHipError(f"workspace of {workspace.numel() * 8} bytes handed in, {nbytes} needed")
+        return workspace
 
     # ---- particles ---------------------------------------------------------------------------------------------
     def _initialise_particles_noise(self, number_of_particles: int, seed: int | None = None, mean: float = 0.0,
@@ -110,8 +137,9 @@ class PLSBasis(ABC):
         assert (
             particles.shape[0] == self.approximation_dimension
         ), f"Particles have shape {particles.shape} but requires ({self.approximation_dimension}, J) dimension."
+        extra = {} if noise is None else {"noise": noise}  # (subclasses with the reference's 3-argument signature keep working)
         return self._calculate_particle_update(
-            particles=particles, cost_derivative=cost_derivative, step_size=step_size, noise=noise
+            particles=particles, cost_derivative=cost_derivative, step_size=step_size, **extra
         )
 
     @abstractmethod

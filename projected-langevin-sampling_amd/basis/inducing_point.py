@@ -3,11 +3,12 @@ from __future__ import annotations
 
 import torch
 
+from .. import _chol
 from .. import _lib as L
 from .. import _ops
 from ..kernel import PLSKernel, _dev
 from ..samplers import sample_multivariate_normal
-from .base import NoiseSpec, PLSBasis, alloc_matrix
+from .base import BlockSpec, NoiseSpec, PLSBasis, alloc_matrix
 from .orthonormal import _rows_contiguous
 
 
@@ -15,9 +16,15 @@ class InducingPointBasis(PLSBasis):
     """Particles are function values at the M inducing points (inducing_point.py:23-50).
 
     The reference calls gpytorch.solve(k(Z,Z), .) twice per step and eigh(k(Z,Z)) once per step for the noise
-    (:130-137).  Here k(Z,Z) is factorised ONCE (host LAPACK Cholesky, fp64): W = k(Z,Z)^-1 and the factor L_c
-    are uploaded, the per-step solves become the fp64 MFMA contraction W U, and the noise is e = L_c xi
-    (same distribution N(0, k(Z,Z)) as the reference's Q sqrt(Lambda) xi; injected noise is used as-is)."""
+    (:130-137).  Here k(Z,Z) is factorised ONCE on the device (pls_chol_factor: blocked fp64 Cholesky with gpytorch's
+    psd_safe_cholesky jitter schedule, _chol.py); every per-step solve is a block forward + backward substitution with that
+    factor (pls_chol_solve, one launch), and the noise is e = L_c xi (same distribution N(0, k(Z,Z)) as the reference's
+    Q sqrt(Lambda) xi; injected noise is used as-is).
+
+    ``cholesky_factor`` (extension, parity runs): a lower Cholesky factor of k(Z,Z) computed elsewhere -- the oracle's
+    LAPACK factor -- so that both sides solve with the same factor (the analogue of ``spectrum=`` on the orthonormal
+    basis).  ``explicit_inverse`` (extension, A/B runs): also form W = k(Z,Z)^-1 on the host, for
+    pls_set_option(PLS_OPT_IPB_EXPLICIT_INVERSE, 1)."""
 
     def __init__(
         self,
@@ -26,6 +33,8 @@ class InducingPointBasis(PLSBasis):
         y_induce: torch.Tensor,
         x_train: torch.Tensor,
         additional_predictive_noise_distribution: torch.distributions.Distribution | None = None,
+        cholesky_factor: torch.Tensor | None = None,
+        explicit_inverse: bool = False,
     ):
         super().__init__(additional_predictive_noise_distribution=additional_predictive_noise_distribution)
         self.kernel = kernel
@@ -37,10 +46,13 @@ class InducingPointBasis(PLSBasis):
         dev = self.base_gram_induce.device
         m, n = self.base_gram_induce_train.shape
         self._n = n
-        k_host = self.base_gram_induce.cpu()
-        chol = torch.linalg.cholesky(k_host)  # what gpytorch.solve does for M <= 800
-        self._W = _dev(torch.cholesky_inverse(chol))
-        self._LcT = _dev(chol.T)
+        if cholesky_factor is None:
+            self._chol = _chol.cholesky_factor(self.base_gram_induce)  # what gpytorch.solve does, on the device
+        else:
+            self._chol = _chol.factor_from_host(cholesky_factor)
+        self._W = None
+        if explicit_inverse:  # A/B only: the contraction W U instead of the two triangular solves
+            self._W = _dev(torch.cholesky_inverse(self._chol.Lc.cpu()))
         # k(X,Z) as its own k-major operand for the back-projection k(Z,X) G
         self._Kxz = alloc_matrix(n, m, dev)
         self._Kxz.copy_(self.base_gram_induce_train.T)
@@ -57,8 +69,12 @@ class InducingPointBasis(PLSBasis):
         d.m, d.n = self.approximation_dimension, self._n
         d.Kzx, d.ldkzx = self.base_gram_induce_train.data_ptr(), L.ld(self.base_gram_induce_train)
         d.Kxz, d.ldkxz = self._Kxz.data_ptr(), L.ld(self._Kxz)
-        d.W, d.ldw = self._W.data_ptr(), L.ld(self._W)
-        d.LcT, d.ldlct = self._LcT.data_ptr(), L.ld(self._LcT)
+        if self._W is not None:
+            d.W, d.ldw = self._W.data_ptr(), L.ld(self._W)
+        f = self._chol
+        d.LcT, d.ldlct = f.LcT.data_ptr(), L.ld(f.LcT)
+        d.Sf, d.ldsf = f.Sf.data_ptr(), L.ld(f.Sf)
+        d.Sb, d.ldsb = f.Sb.data_ptr(), L.ld(f.Sb)
         if with_gaussian and self._B is not None:
             d.B, d.ldb, d.c = self._B.data_ptr(), L.ld(self._B), self._c.data_ptr()
         return d
@@ -116,7 +132,7 @@ class InducingPointBasis(PLSBasis):
         return e
 
     def calculate_energy_potential(self, particles: torch.Tensor, cost: torch.Tensor) -> float:
-        return self.particle_energy_potential(particles, cost).mean().item()  # :115
+        return _ops.block_means(self.particle_energy_potential(particles, cost)).item()  # :115
 
     def _calculate_particle_update(self, particles: torch.Tensor, cost_derivative: torch.Tensor, step_size: float,
                                    noise: torch.Tensor | None = None) -> torch.Tensor:
@@ -142,9 +158,11 @@ class InducingPointBasis(PLSBasis):
 
     def fused_step(self, cost, particles: torch.Tensor, step_size: float, out: torch.Tensor | None = None,
                    new_state: bool = False, noise: NoiseSpec | None = None, force_generic: bool = False,
-                   input_energy: torch.Tensor | None = None) -> torch.Tensor:
+                   input_energy: torch.Tensor | None = None, blocks: BlockSpec | None = None,
+                   workspace: torch.Tensor | None = None) -> torch.Tensor:
         """One whole Langevin step (pls_ipb_step).  ``input_energy`` (J,) receives the per-particle energy of
-        ``particles`` as a by-product (cost of the same F + (M/2)||K^-1 U||^2)."""
+        ``particles`` as a by-product (cost of the same F + (M/2)||K^-1 U||^2).  ``blocks``: one step size per column
+        block (pls_ipb_step_blocks; ``step_size`` is then ignored).  ``workspace``: a caller-owned buffer (graph captures)."""
         u = _rows_contiguous(L.require_gpu_tensor(particles, "particles"))
         j = u.shape[1]
         if out is None:
@@ -160,15 +178,32 @@ class InducingPointBasis(PLSBasis):
         need_min = lib.pls_ipb_step_workspace_bytes(desc, j, 128)
         need_full = lib.pls_ipb_step_workspace_bytes(desc, j, self._n)
         ws_bytes = max(need_min, min(need_full, self.workspace_bytes))
-        ws = self._workspace(ws_bytes, u.device)
+        ws = self._pick_workspace(workspace, ws_bytes, u.device)
         nd = (noise if noise is not None else self._draw_noise_spec(None)).desc()
-        L.check(
-            lib.pls_ipb_step(desc, cost.desc(), cost.y_device().data_ptr(), u.data_ptr(), L.ld(u), j, float(step_size), nd,
-                             out.data_ptr(), L.ld(out), L.OUT_NEW_STATE if new_state else L.OUT_DELTA, 1 if force_generic else 0,
-                             L.ptr(input_energy), ws.data_ptr(), ws_bytes, L.stream_ptr()),
-            "pls_ipb_step",
-        )
+        mode = L.OUT_NEW_STATE if new_state else L.OUT_DELTA
+        if blocks is None:
+            L.check(
+                lib.pls_ipb_step(desc, cost.desc(), cost.y_device().data_ptr(), u.data_ptr(), L.ld(u), j, float(step_size), nd,
+                                 out.data_ptr(), L.ld(out), mode, 1 if force_generic else 0, L.ptr(input_energy), ws.data_ptr(),
+                                 ws_bytes, L.stream_ptr()),
+                "pls_ipb_step",
+            )
+        else:
+            L.check(
+                lib.pls_ipb_step_blocks(desc, cost.desc(), cost.y_device().data_ptr(), u.data_ptr(), L.ld(u), j, blocks.desc(), nd,
+                                        out.data_ptr(), L.ld(out), mode, 1 if force_generic else 0, L.ptr(input_energy),
+                                        ws.data_ptr(), ws_bytes, L.stream_ptr()),
+                "pls_ipb_step_blocks",
+            )
         return out
+
+    def step_workspace_bytes(self, cost, j: int, with_energy: bool, force_generic: bool = False) -> int:
+        """Bytes fused_step asks of its workspace for ``j`` columns (graph captures allocate their own buffer)."""
+        lib = L.load()
+        desc = self._desc(with_gaussian=self._is_gaussian(cost, force_generic) and self._B is not None)
+        need_min = lib.pls_ipb_step_workspace_bytes(desc, j, 128)
+        need_full = lib.pls_ipb_step_workspace_bytes(desc, j, self._n)
+        return max(need_min, min(need_full, self.workspace_bytes))
 
     def supports_input_energy(self, cost) -> bool:
         return bool(cost.is_native())
@@ -209,7 +244,7 @@ class InducingPointBasis(PLSBasis):
 
     def predict_untransformed_samples(self, particles: torch.Tensor, x: torch.Tensor,
                                       noise: torch.Tensor | None = None) -> torch.Tensor:
-        """G(x) + r(x,Z) r(Z,Z)^-1 (U - G(Z))  (:204-240); the M x M solve is a host Cholesky (once per call)."""
+        """G(x) + r(x,Z) r(Z,Z)^-1 (U - G(Z))  (:204-240); r(Z,Z) is factorised on the device once per call."""
         u = _rows_contiguous(L.require_gpu_tensor(particles, "particles"))
         gram_induce_x = self.kernel.forward(x1=self.x_induce, x2=x, additional_approximation_samples=x)  # r(Z,x) (M,N*)
         gram_induce = self.kernel.forward(x1=self.x_induce, x2=self.x_induce, additional_approximation_samples=x)
@@ -217,8 +252,9 @@ class InducingPointBasis(PLSBasis):
             noise = self.sample_predictive_noise(particles=particles, x=x)
         noise = L.require_gpu_tensor(noise, "noise")
         m = self.approximation_dimension
-        w = _dev(torch.cholesky_inverse(torch.linalg.cholesky(gram_induce.cpu())))  # symmetric: W^T = W
-        q = _ops.gemm_tn(w, gram_induce_x)  # (M, N*) = r(Z,Z)^-1 r(Z,x)
+        # r(Z,Z)^-1 r(Z,x): gpytorch.solve(lhs=r(x,Z), input=r(Z,Z), rhs=...) at :235-239 -- a psd-safe Cholesky of r(Z,Z)
+        # (its condition number is the SQUARE of k(Z,Z)'s: the jitter schedule matters here) and two triangular solves
+        q = _chol.cholesky_factor(gram_induce).solve(gram_induce_x)  # (M, N*)
         out = noise[m:, :].contiguous().clone()
         _ops.gemm_tn(q, u, 1.0, 1.0, out=out)
         _ops.gemm_tn(q, noise[:m, :].contiguous(), -1.0, 1.0, out=out)

@@ -9,7 +9,7 @@ from .. import _lib as L
 from .. import _ops
 from ..kernel import PLSKernel, _dev
 from ..samplers import sample_multivariate_normal
-from .base import NoiseSpec, PLSBasis, alloc_matrix
+from .base import BlockSpec, NoiseSpec, PLSBasis, alloc_matrix
 
 
 class OrthonormalBasis(PLSBasis):
@@ -183,7 +183,7 @@ class OrthonormalBasis(PLSBasis):
         return e
 
     def calculate_energy_potential(self, particles: torch.Tensor, cost: torch.Tensor) -> float:
-        return self.particle_energy_potential(particles, cost).mean().item()  # :126 (host sync)
+        return _ops.block_means(self.particle_energy_potential(particles, cost)).item()  # :126 (host sync)
 
     def _calculate_particle_update(self, particles: torch.Tensor, cost_derivative: torch.Tensor, step_size: float,
                                    noise: torch.Tensor | None = None) -> torch.Tensor:
@@ -211,11 +211,25 @@ class OrthonormalBasis(PLSBasis):
         derivative is taken of (the reference recomputes F for the energy: projected_langevin_sampling.py:125-138)."""
         return bool(cost.is_native())
 
+    def step_workspace_bytes(self, cost, j: int, with_energy: bool, force_generic: bool = False) -> int:
+        """Bytes fused_step asks of its workspace for ``j`` columns (graph captures allocate their own buffer)."""
+        cd = cost.desc()
+        if cd.cost == L.COST_GAUSSIAN and cd.link == L.LINK_IDENTITY and not force_generic:
+            return ((self.approximation_dimension + 63) // 64) * j * 8 if with_energy else 0
+        lib = L.load()
+        desc = self._desc()
+        need_min = lib.pls_onb_step_workspace_bytes(desc, j, 128)
+        need_full = lib.pls_onb_step_workspace_bytes(desc, j, self._n)
+        return max(need_min, min(need_full, self.workspace_bytes))
+
     def fused_step(self, cost, particles: torch.Tensor, step_size: float, out: torch.Tensor | None = None,
                    new_state: bool = False, noise: NoiseSpec | None = None, force_generic: bool = False,
-                   input_energy: torch.Tensor | None = None) -> torch.Tensor:
+                   input_energy: torch.Tensor | None = None, blocks: BlockSpec | None = None,
+                   workspace: torch.Tensor | None = None) -> torch.Tensor:
         """One whole Langevin step in libplship (pls_onb_step): returns dU, or U + dU when new_state.
-        ``input_energy`` (J,) receives the per-particle energy of ``particles`` as a by-product."""
+        ``input_energy`` (J,) receives the per-particle energy of ``particles`` as a by-product.  ``blocks``: one step size
+        per column block (pls_onb_step_blocks; ``step_size`` is then ignored).  ``workspace``: a caller-owned buffer --
+        a captured hipGraph freezes its address, so captures never use the basis' own growable scratch."""
         u = _rows_contiguous(L.require_gpu_tensor(particles, "particles"))
         j = u.shape[1]
         if out is None:
@@ -234,7 +248,7 @@ class OrthonormalBasis(PLSBasis):
             ws, ws_bytes = None, 0
             if input_energy is not None:
                 ws_bytes = ((self.approximation_dimension + 63) // 64) * j * 8
-                ws = self._workspace(ws_bytes, u.device)
+                ws = self._pick_workspace(workspace, ws_bytes, u.device)
         else:
             wkey = (j, self.workspace_bytes)
             ws_bytes = self.__dict__.setdefault("_ws_bytes_cache", {}).get(wkey)
@@ -243,14 +257,22 @@ class OrthonormalBasis(PLSBasis):
                 need_full = lib.pls_onb_step_workspace_bytes(desc, j, self._n)
                 ws_bytes = max(need_min, min(need_full, self.workspace_bytes))
                 self._ws_bytes_cache[wkey] = ws_bytes
-            ws = self._workspace(ws_bytes, u.device)
+            ws = self._pick_workspace(workspace, ws_bytes, u.device)
         nd = (noise if noise is not None else self._draw_noise_spec(None)).desc()
-        L.check(
-            lib.pls_onb_step(desc, cd, y.data_ptr(), u.data_ptr(), L.ld(u), j, float(step_size), nd, out.data_ptr(), L.ld(out),
-                             L.OUT_NEW_STATE if new_state else L.OUT_DELTA, 1 if force_generic else 0, L.ptr(input_energy),
-                             L.ptr(ws), ws_bytes, L.stream_ptr()),
-            "pls_onb_step",
-        )
+        mode = L.OUT_NEW_STATE if new_state else L.OUT_DELTA
+        if blocks is None:
+            L.check(
+                lib.pls_onb_step(desc, cd, y.data_ptr(), u.data_ptr(), L.ld(u), j, float(step_size), nd, out.data_ptr(), L.ld(out),
+                                 mode, 1 if force_generic else 0, L.ptr(input_energy), L.ptr(ws), ws_bytes, L.stream_ptr()),
+                "pls_onb_step",
+            )
+        else:
+            L.check(
+                lib.pls_onb_step_blocks(desc, cd, y.data_ptr(), u.data_ptr(), L.ld(u), j, blocks.desc(), nd, out.data_ptr(),
+                                        L.ld(out), mode, 1 if force_generic else 0, L.ptr(input_energy), L.ptr(ws), ws_bytes,
+                                        L.stream_ptr()),
+                "pls_onb_step_blocks",
+            )
         return out
 
     def fused_particle_energy(self, cost, particles: torch.Tensor, force_generic: bool = False) -> torch.Tensor:

@@ -1,0 +1,407 @@
+// Device Cholesky factorisation of k(Z,Z) and the per-step solves  V = k(Z,Z)^-1 U  of the inducing-point basis.
+//
+// Reference: gpytorch.solve(lhs = k(Z,Z), input = rhs = U) at basis/inducing_point.py:89-93, :104-106, :130-132,
+// :235-239 (Cholesky + cholesky_solve for the sizes its tests pin) and the per-step eigh(k(Z,Z)) of the
+// noise sampler (samplers.py:27-44 via inducing_point.py:133-137), replaced by e = L xi.
+//
+// Factorisation (once per basis, everything stays on the device, nothing synchronises):
+//   right-looking blocked Cholesky, panels of CH_PB = 64 columns:
+//     chol_diag_kernel   the 64 x 64 diagonal block, one workgroup, in LDS
+//     chol_panel_kernel  the rows below it: x L11^T = a, one row per thread, L11 broadcast from LDS; writes L (lower,
+//                        row-major) AND L^T (upper) so that both are k-major operands of the MFMA contraction
+//     trailing update    A22 -= L21 L21^T through gemm_tn_f64_kernel (gemm_tn_ex)
+//   then the substitution operators: with D_b the inverse of the b-th TS_NB x TS_NB diagonal block of L,
+//     forward   y_b = D_b u_b   - sum_{k<b} (D_b L_bk) y_k          Sf[k][i] = (D_b L_bk)^T, D_b^T on the diagonal
+//     backward  v_b = D_b^T y_b - sum_{k>b} (D_b^T L_kb^T) v_k      Sb[k][i] = (L_kb D_b),   D_b   on the diagonal
+//   i.e. block forward / backward substitution whose diagonal solve is folded into the (pre-scaled) off-diagonal blocks:
+//   each block row of a solve is then ONE MFMA k-loop.  Only the 128 x 128 DIAGONAL blocks are inverted (by
+//   substitution, what rocBLAS / MAGMA trsm do); k(Z,Z)^-1 is never formed.
+//
+// Solve (every Langevin step): tri_solve_strip_kernel.  The particle columns are independent, so a workgroup owns a
+// strip of TS_SC = 32 columns for the WHOLE solve (forward then backward, block row after block row, one launch, no
+// inter-workgroup traffic): its own earlier block rows of V are the R operand of the later ones.
+#include <hip/hip_runtime.h>
+
+#include "../../include/plship.h"
+#include "chol.h"
+#include "common.h"
+#include "gemm_api.h"
+
+namespace plship {
+
+typedef double double4v __attribute__((ext_vector_type(4)));
+typedef double double2v __attribute__((ext_vector_type(2)));
+
+constexpr int CH_PB = 64;   // Cholesky panel width
+constexpr int TS_NB = 128;  // block size of the substitution operators
+constexpr int TS_SC = 32;   // particle columns per workgroup
+constexpr int TS_BK = 16;
+
+// Lc = K (+ jitter on the diagonal); LcT, Sf, Sb = 0
+__global__ __launch_bounds__(256) void chol_init_kernel(const double *__restrict__ K, int64_t ldk, int64_t m, double jitter,
+                                                         double *__restrict__ Lc, int64_t ldl, double *__restrict__ LcT,
+                                                         int64_t ldlt, double *__restrict__ Sf, int64_t ldsf,
+                                                         double *__restrict__ Sb, int64_t ldsb, int *info) {
+  const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && info) *info = 0;
+  if (col >= m) return;
+  for (int64_t row = blockIdx.y; row < m; row += gridDim.y) {
+    double v = K[row * ldk + col];
+    if (row == col) v += jitter;
+    Lc[row * ldl + col] = v;
+    LcT[row * ldlt + col] = 0.0;
+    if (Sf) Sf[row * ldsf + col] = 0.0;
+    if (Sb) Sb[row * ldsb + col] = 0.0;
+  }
+}
+
+// Factor the nb x nb diagonal block at (k0, k0) in LDS.  info (device int): 1-based index of the first pivot that is not
+// positive (the factor is then garbage and the caller escalates the jitter), 0 otherwise.
+__global__ __launch_bounds__(256) void chol_diag_kernel(double *Lc, int64_t ldl, double *LcT, int64_t ldlt, int64_t k0,
+                                                         int nb, int *info) {
+  __shared__ double S[CH_PB][CH_PB + 1];
+  __shared__ double colv[CH_PB];
+  const int tid = threadIdx.x;
+  for (int e = tid; e < CH_PB * CH_PB; e += 256) {
+    const int r = e / CH_PB, c = e % CH_PB;
+    S[r][c] = (r < nb && c < nb) ? Lc[(k0 + r) * ldl + k0 + c] : (r == c ? 1.0 : 0.0);
+  }
+  __syncthreads();
+  for (int c = 0; c < nb; ++c) {
+    const double d = S[c][c];
+    if (!(d > 0.0) && tid == 0 && info && *info == 0) *info = (int)(k0 + c) + 1;
+    const double sd = sqrt(d);
+    if (tid < CH_PB) colv[tid] = (tid > c) ? S[tid][c] / sd : 0.0;
+    __syncthreads();
+    for (int e = tid; e < CH_PB * CH_PB; e += 256) {
+      const int r = e / CH_PB, k = e % CH_PB;
+      if (k > c && r >= k) S[r][k] = fma(-colv[r], colv[k], S[r][k]);
+    }
+    if (tid < CH_PB) {
+      if (tid > c) S[tid][c] = colv[tid];
+      if (tid == c) S[c][c] = sd;
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < CH_PB * CH_PB; e += 256) {
+    const int r = e / CH_PB, c = e % CH_PB;
+    if (r < nb && c < nb) {
+      const double lo = (r >= c) ? S[r][c] : 0.0;  // L[r][c]
+      const double up = (c >= r) ? S[c][r] : 0.0;  // L^T[r][c] = L[c][r]
+      Lc[(k0 + r) * ldl + k0 + c] = lo;
+      LcT[(k0 + r) * ldlt + k0 + c] = up;
+    }
+  }
+}
+
+// Rows below a full 64-column panel: row r of A21 -> x with x L11^T = a (forward substitution along the row).
+__global__ __launch_bounds__(64) void chol_panel_kernel(double *Lc, int64_t ldl, double *LcT, int64_t ldlt, int64_t k0,
+                                                        int64_t m) {
+  __shared__ double L11[CH_PB][CH_PB + 1];
+  const int tid = threadIdx.x;
+  for (int e = tid; e < CH_PB * CH_PB; e += 64) {
+    const int r = e / CH_PB, c = e % CH_PB;
+    L11[r][c] = Lc[(k0 + r) * ldl + k0 + c];
+  }
+  __syncthreads();
+  const int64_t r = k0 + CH_PB + (int64_t)blockIdx.x * 64 + tid;
+  if (r >= m) return;
+  double x[CH_PB];
+  const double2v *src = reinterpret_cast<const double2v *>(Lc + r * ldl + k0);  // (k0 multiple of 64, ldl even: 16-B aligned)
+#pragma unroll
+  for (int c = 0; c < CH_PB / 2; ++c) {
+    const double2v v = src[c];
+    x[2 * c] = v.x;
+    x[2 * c + 1] = v.y;
+  }
+#pragma unroll
+  for (int c = 0; c < CH_PB; ++c) {
+    double s = x[c];
+#pragma unroll
+    for (int k = 0; k < c; ++k) s = fma(-x[k], L11[c][k], s);
+    x[c] = s / L11[c][c];
+  }
+  double2v *dst = reinterpret_cast<double2v *>(Lc + r * ldl + k0);
+#pragma unroll
+  for (int c = 0; c < CH_PB / 2; ++c) dst[c] = double2v{x[2 * c], x[2 * c + 1]};
+#pragma unroll
+  for (int c = 0; c < CH_PB; ++c) {
+    LcT[(k0 + c) * ldlt + r] = x[c];  // L^T[k0 + c][r]: coalesced across the block's rows
+    Lc[(k0 + c) * ldl + r] = 0.0;     // the mirrored entry above the diagonal (garbage of the trailing updates)
+  }
+}
+
+// D = inverse of the nbk x nbk lower-triangular diagonal block at r0 (nbk <= 128): thread c owns column c of D,
+// x_i = ([i == c] - sum_{k<i} L_ik x_k) / L_ii by rows; X lives in LDS ([i][c]: conflict-free), row i of L is staged
+// once per i.  Writes D into the diagonal block of Sb (row-major) and D^T into that of Sf.
+__global__ __launch_bounds__(TS_NB) void tri_block_inverse_kernel(const double *__restrict__ Lc, int64_t ldl, int64_t m,
+                                                                   double *__restrict__ Sf, int64_t ldsf,
+                                                                   double *__restrict__ Sb, int64_t ldsb) {
+  extern __shared__ __attribute__((aligned(16))) double xs[];  // [TS_NB][TS_NB] then one row of L
+  double *lrow = xs + TS_NB * TS_NB;
+  const int c = threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.x * TS_NB;
+  const int nbk = (int)((m - r0 < TS_NB) ? (m - r0) : TS_NB);
+  for (int i = 0; i < nbk; ++i) {
+    if (c <= i) lrow[c] = Lc[(r0 + i) * ldl + r0 + c];
+    __syncthreads();
+    if (c < nbk) {
+      double s = (i == c) ? 1.0 : 0.0;
+      double s2 = 0.0;
+      int k = c;  // x_k = 0 for k < c
+      for (; k + 1 < i; k += 2) {
+        s = fma(-lrow[k], xs[k * TS_NB + c], s);
+        s2 = fma(-lrow[k + 1], xs[(k + 1) * TS_NB + c], s2);
+      }
+      if (k < i) s = fma(-lrow[k], xs[k * TS_NB + c], s);
+      xs[i * TS_NB + c] = (i >= c) ? (s + s2) / lrow[i] : 0.0;
+    }
+    __syncthreads();
+  }
+  if (c < nbk) {
+    for (int i = 0; i < nbk; ++i) {
+      const double v = xs[i * TS_NB + c];  // D[i][c]
+      Sb[(r0 + i) * ldsb + r0 + c] = v;    // Sb diagonal block = D     (coalesced over c)
+      Sf[(r0 + c) * ldsf + r0 + i] = v;    // Sf diagonal block = D^T
+    }
+  }
+}
+
+// One block row of a strip solve:  acc(128 x 32) = sum_{k in [kbeg, kend)} S[k][i0 + i] * R[k][j0 + j], where R is
+// Rlo for k < ksw and Rhi for k >= ksw (forward: the rows already solved come from V, the block's own rows from U).
+struct StripArgs {
+  const double *Sf, *Sb;
+  int64_t ldsf, ldsb;
+  const double *U;
+  int64_t ldu;
+  double *V;
+  int64_t ldv;
+  int64_t m, j;
+};
+
+__device__ __forceinline__ void strip_block_row(const double *__restrict__ S, int64_t lds_, const double *Rlo, int64_t ldlo,
+                                                const double *Rhi, int64_t ldhi, int64_t ksw, int64_t kbeg, int64_t kend,
+                                                int64_t i0, int64_t j0, int64_t m, int64_t j, double *lds,
+                                                double4v (&acc)[2][2]) {
+  constexpr int SL = TS_NB + 16, SR = TS_SC + 16;
+  double *Ss = lds;                     // [2][BK][SL]
+  double *Rs = lds + 2 * TS_BK * SL;    // [2][BK][SR]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, c16 = lane & 15;
+  const int wi = wave * 32;
+  // loads: S tile 16 x 128 -> thread (row = tid / 16, 8 doubles from column (tid % 16) * 8); R tile 16 x 32 -> 2 doubles
+  const int lrow = tid >> 4, lcs = (tid & 15) * 8, lcr = (tid & 15) * 2;
+  double2v sreg[4], rreg;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = double4v{0.0, 0.0, 0.0, 0.0};
+  auto load_tiles = [&](int64_t k0) {
+    const int64_t k = k0 + lrow;
+    const bool kin = k < kend;
+    const int64_t kk = kin ? k : kbeg;  // any valid row: its values are zeroed below
+    const double *sp = S + kk * lds_;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int64_t ci = i0 + lcs + 2 * p;
+      double2v v;
+      v.x = (ci < m) ? sp[ci] : 0.0;
+      v.y = (ci + 1 < m) ? sp[ci + 1] : 0.0;
+      sreg[p].x = kin ? v.x : 0.0;
+      sreg[p].y = kin ? v.y : 0.0;
+    }
+    const double *rp = (kk >= ksw) ? Rhi + kk * ldhi : Rlo + kk * ldlo;
+    const int64_t cj = j0 + lcr;
+    rreg.x = (kin && cj < j) ? rp[cj] : 0.0;
+    rreg.y = (kin && cj + 1 < j) ? rp[cj + 1] : 0.0;
+  };
+  auto store_tiles = [&](int buf) {
+    double *s = Ss + buf * TS_BK * SL + lrow * SL + lcs;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) *reinterpret_cast<double2v *>(s + 2 * p) = sreg[p];
+    *reinterpret_cast<double2v *>(Rs + buf * TS_BK * SR + lrow * SR + lcr) = rreg;
+  };
+  auto compute = [&](int buf) {
+    const double *l = Ss + buf * TS_BK * SL + q * SL + wi + c16;
+    const double *r = Rs + buf * TS_BK * SR + q * SR + c16;
+#pragma unroll
+    for (int kq = 0; kq < TS_BK / 4; ++kq) {
+      double a[2], b[2];
+      a[0] = l[kq * 4 * SL];
+      a[1] = l[kq * 4 * SL + 16];
+      b[0] = r[kq * 4 * SR];
+      b[1] = r[kq * 4 * SR + 16];
+#pragma unroll
+      for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+    }
+  };
+  const int64_t nk = (kend - kbeg + TS_BK - 1) / TS_BK;
+  load_tiles(kbeg);
+  store_tiles(0);
+  __syncthreads();
+  for (int64_t kt = 0; kt < nk; ++kt) {
+    const int buf = (int)(kt & 1);
+    const bool more = kt + 1 < nk;
+    if (more) load_tiles(kbeg + (kt + 1) * TS_BK);
+    compute(buf);
+    if (more) store_tiles(buf ^ 1);
+    __syncthreads();
+  }
+}
+
+// acc -> V rows [i0, i0 + 128), columns [j0, j0 + 32): register (ta, tb, r) of lane l is row 16 ta + 4 r + (l >> 4) of the
+// wave's 32 rows, column 16 tb + (l & 15)
+__device__ __forceinline__ void strip_store(const double4v (&acc)[2][2], double *V, int64_t ldv, int64_t i0, int64_t j0,
+                                            int64_t m, int64_t j) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane >> 4, c16 = lane & 15;
+#pragma unroll
+  for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t row = i0 + wave * 32 + ta * 16 + 4 * r + q;
+        const int64_t col = j0 + tb * 16 + c16;
+        if (row < m && col < j) V[row * ldv + col] = acc[ta][tb][r];
+      }
+}
+
+// V = L^-T L^-1 U for one strip of TS_SC columns: forward block rows 0 .. nb-1 (reads U, writes V), then backward block
+// rows nb-1 .. 0 in place.  The strip is private to the workgroup: its earlier stores are ordered before the later
+// loads by the workgroup barrier (all waves of a workgroup share the CU's L1).
+// fwd_only != 0 stops after the forward solve (V = L^-1 U).
+__global__ __launch_bounds__(256) void tri_solve_strip_kernel(StripArgs a, int fwd_only) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int64_t j0 = (int64_t)blockIdx.x * TS_SC;
+  const int64_t nb = (a.m + TS_NB - 1) / TS_NB;
+  double4v acc[2][2];
+  for (int64_t b = 0; b < nb; ++b) {
+    const int64_t i0 = b * TS_NB;
+    const int64_t kend = (i0 + TS_NB < a.m) ? i0 + TS_NB : a.m;
+    strip_block_row(a.Sf, a.ldsf, a.V, a.ldv, a.U, a.ldu, i0, 0, kend, i0, j0, a.m, a.j, lds, acc);
+    strip_store(acc, a.V, a.ldv, i0, j0, a.m, a.j);
+    __syncthreads();  // (drains the stores: the next block row reads them)
+  }
+  if (fwd_only) return;
+  for (int64_t b = nb - 1; b >= 0; --b) {
+    const int64_t i0 = b * TS_NB;
+    strip_block_row(a.Sb, a.ldsb, a.V, a.ldv, a.V, a.ldv, 0, i0, a.m, i0, j0, a.m, a.j, lds, acc);
+    strip_store(acc, a.V, a.ldv, i0, j0, a.m, a.j);
+    __syncthreads();
+  }
+}
+
+static size_t strip_lds_bytes() { return (size_t)2 * TS_BK * ((TS_NB + 16) + (TS_SC + 16)) * sizeof(double); }
+
+int chol_solve_launch(const pls_chol_desc *f, const double *U, int64_t ldu, int64_t j, double *V, int64_t ldv,
+                      int fwd_only, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tri_solve_strip_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)strip_lds_bytes());
+    if (e != hipSuccess) return fail(PLS_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  StripArgs a{f->Sf, f->Sb, f->ldsf, f->ldsb, U, ldu, V, ldv, f->m, j};
+  {
+    LaunchScope scope(PLS_TAG_TRI_SOLVE, st);
+    hipLaunchKernelGGL(tri_solve_strip_kernel, dim3((unsigned)cdiv(j, TS_SC)), dim3(256), strip_lds_bytes(), st, a, fwd_only);
+  }
+  return check_launch("tri_solve_strip");
+}
+
+}  // namespace plship
+
+using namespace plship;
+
+extern "C" {
+
+int pls_chol_factor(const double *K, int64_t ldk, int64_t m, double jitter, double *Lc, int64_t ldlc, double *LcT,
+                    int64_t ldlct, double *Sf, int64_t ldsf, double *Sb, int64_t ldsb, int32_t *info, void *stream) {
+  PLS_REQUIRE(K && Lc && LcT && info, "chol_factor: NULL pointer");
+  PLS_REQUIRE((Sf == nullptr) == (Sb == nullptr), "chol_factor: Sf and Sb go together");
+  PLS_REQUIRE(m > 0 && ldk >= m && ldlc >= m && ldlct >= m, "chol_factor: bad sizes");
+  PLS_REQUIRE(!Sf || (ldsf >= m && ldsb >= m), "chol_factor: bad sizes");
+  PLS_REQUIRE((ldlc & 1) == 0 && (ldlct & 1) == 0 && (reinterpret_cast<uintptr_t>(Lc) & 15) == 0,
+              "chol_factor: Lc must be 16-byte aligned with even leading dimensions");
+  PLS_REQUIRE(jitter >= 0.0, "chol_factor: jitter must be >= 0");
+  PLS_REQUIRE(K != Lc, "chol_factor: the factor is built out of place");
+  hipStream_t st = S(stream);
+  {
+    const unsigned gy = (unsigned)(m < 1024 ? m : 1024);
+    hipLaunchKernelGGL(chol_init_kernel, dim3((unsigned)cdiv(m, 256), gy), dim3(256), 0, st, K, ldk, m, jitter, Lc, ldlc, LcT,
+                       ldlct, Sf, ldsf, Sb, ldsb, info);
+    int rc = check_launch("chol_init");
+    if (rc) return rc;
+  }
+  for (int64_t k0 = 0; k0 < m; k0 += CH_PB) {
+    const int nb = (int)((m - k0 < CH_PB) ? (m - k0) : CH_PB);
+    hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, st, Lc, ldlc, LcT, ldlct, k0, nb, info);
+    const int64_t rem = m - k0 - nb;
+    if (rem > 0) {  // (then nb == CH_PB)
+      hipLaunchKernelGGL(chol_panel_kernel, dim3((unsigned)cdiv(rem, 64)), dim3(64), 0, st, Lc, ldlc, LcT, ldlct, k0, m);
+      int rc = check_launch("chol_panel");
+      if (rc) return rc;
+      // A22 -= L21 L21^T :  L = R = L^T[k0 : k0 + 64, k0 + 64 : m]  (64 x rem, k-major)
+      const double *p = LcT + k0 * ldlct + (k0 + nb);
+      rc = gemm_tn_ex(p, ldlct, p, ldlct, Lc + (k0 + nb) * ldlc + (k0 + nb), ldlc, rem, rem, nb, -1.0, 1.0, 0, st);
+      if (rc) return rc;
+    }
+  }
+  int rc = check_launch("cholesky");
+  if (rc || !Sf) return rc;
+  return pls_chol_build_operators(Lc, ldlc, LcT, ldlct, m, Sf, ldsf, Sb, ldsb, stream);
+}
+
+int pls_chol_build_operators(const double *Lc, int64_t ldlc, const double *LcT, int64_t ldlct, int64_t m, double *Sf,
+                             int64_t ldsf, double *Sb, int64_t ldsb, void *stream) {
+  PLS_REQUIRE(Lc && LcT && Sf && Sb, "chol_build_operators: NULL pointer");
+  PLS_REQUIRE(m > 0 && ldlc >= m && ldlct >= m && ldsf >= m && ldsb >= m, "chol_build_operators: bad sizes");
+  hipStream_t st = S(stream);
+  int rc;
+  static bool attr_set = false;
+  const size_t inv_lds = (size_t)(TS_NB * TS_NB + TS_NB) * sizeof(double);
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tri_block_inverse_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)inv_lds);
+    if (e != hipSuccess) return fail(PLS_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  const int64_t nbk = cdiv(m, TS_NB);
+  hipLaunchKernelGGL(tri_block_inverse_kernel, dim3((unsigned)nbk), dim3(TS_NB), inv_lds, st, Lc, ldlc, m, Sf, ldsf, Sb, ldsb);
+  rc = check_launch("tri_block_inverse");
+  if (rc) return rc;
+  for (int64_t b = 0; b < nbk; ++b) {
+    const int64_t r0 = b * TS_NB, r1 = (r0 + TS_NB < m) ? r0 + TS_NB : m, w = r1 - r0;
+    if (r0 > 0) {  // Sf[0 : r0, r0 : r1] = -Lc[r0 : r1, 0 : r0]^T D_b^T
+      rc = gemm_tn_ex(Lc + r0 * ldlc, ldlc, Sf + r0 * ldsf + r0, ldsf, Sf + r0, ldsf, r0, w, w, -1.0, 0.0, 0, st);
+      if (rc) return rc;
+    }
+    if (r1 < m) {  // Sb[r1 : m, r0 : r1] = -LcT[r0 : r1, r1 : m]^T D_b
+      rc = gemm_tn_ex(LcT + r0 * ldlct + r1, ldlct, Sb + r0 * ldsb + r0, ldsb, Sb + r1 * ldsb + r0, ldsb, m - r1, w, w, -1.0,
+                      0.0, 0, st);
+      if (rc) return rc;
+    }
+  }
+  return PLS_OK;
+}
+
+int pls_chol_solve(const pls_chol_desc *f, const double *U, int64_t ldu, int64_t j, double *V, int64_t ldv, void *stream) {
+  PLS_REQUIRE(f && f->Sf && f->Sb && f->m > 0 && f->ldsf >= f->m && f->ldsb >= f->m, "chol_solve: bad factor descriptor");
+  PLS_REQUIRE(U && V && j >= 0 && ldu >= j && ldv >= j, "chol_solve: bad arguments");
+  PLS_REQUIRE(U != V, "chol_solve: V must not alias U");
+  if (j == 0) return PLS_OK;
+  return chol_solve_launch(f, U, ldu, j, V, ldv, 0, S(stream));
+}
+
+int pls_tri_multiply(const double *LcT, int64_t ldlct, int64_t m, const double *X, int64_t ldx, int64_t j, double *out,
+                     int64_t ldo, void *stream) {
+  PLS_REQUIRE(LcT && X && out && m > 0 && j >= 0 && ldlct >= m && ldx >= j && ldo >= j, "tri_multiply: bad arguments");
+  if (j == 0) return PLS_OK;
+  return gemm_tn_ex(LcT, ldlct, X, ldx, out, ldo, m, j, m, 1.0, 0.0, 1, S(stream));
+}
+
+}  // extern "C"

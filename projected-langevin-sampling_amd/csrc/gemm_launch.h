@@ -47,8 +47,8 @@ static inline bool use_big_tiles(int64_t I, int64_t J, int64_t nsplit = 1) { ret
 // kchunk > 0 (EpiStore only): split-K into cdiv(K, kchunk) slabs, one grid.y plane each
 template <class Epi>
 static int launch_gemm(const double *L, int64_t ldl, const double *R, int64_t ldr, int64_t I, int64_t J, int64_t K,
-                       const Epi &epi, hipStream_t st, int64_t kchunk = 0) {
-  GemmShape g{L, ldl, R, ldr, I, J, K, 0, 0, kchunk};
+                       const Epi &epi, hipStream_t st, int64_t kchunk = 0, int tri = 0) {
+  GemmShape g{L, ldl, R, ldr, I, J, K, 0, 0, kchunk, tri};
   const int64_t nsplit = (kchunk > 0 && kchunk < K) ? cdiv(K, kchunk) : 1;
   if (use_big_tiles(I, J, nsplit)) return launch_gemm_cfg<128, 128, 64, 64>(g, epi, st);
   return launch_gemm_cfg<64, 64, 32, 32>(g, epi, st);

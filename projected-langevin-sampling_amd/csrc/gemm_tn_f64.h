@@ -36,6 +36,7 @@ struct GemmShape {
   int64_t I, J, K;
   int nti, ntj;
   int64_t kchunk;  // split-K: block (x, y) contracts k in [y * kchunk, min(K, (y + 1) * kchunk)); gridDim.y slabs
+  int tri;         // L[k][i] == 0 for k > i (upper-triangular k-major operand): a tile contracts k < i0 + BI only
 #ifdef PLS_STAMP
   unsigned long long *stamps;  // diagnostic build only: 4 s_memtime stamps per workgroup (never read by the kernel)
 #endif
@@ -388,6 +389,7 @@ __global__ __launch_bounds__((BI / WI) * (BJ / WJ) * 64, MINW) void gemm_tn_f64_
     g.K = (g.K - k0 < g.kchunk) ? g.K - k0 : g.kchunk;
   }
 
+  if (g.tri && i0 + BI < g.K) g.K = i0 + BI;  // triangular operand: the rows below the tile's last column are zero
   PLS_STAMP_AT(0);
   AccFrag<TI, TJ> acc;
 #pragma unroll

@@ -11,8 +11,10 @@
 #include <vector>
 
 #include "../../include/plship.h"
+#include "chol.h"
 #include "common.h"
 #include "cost_device.h"
+#include "gemm_api.h"
 #include "gemm_tn_f64.h"
 #include "gemm_launch.h"
 #include "cost_epilogues.h"
@@ -88,11 +90,31 @@ struct NoiseP {
   uint64_t seed, step;
   int64_t j_offset;
   const uint64_t *step_base;  // optional device counter added to `step` at run time (graph replays)
+  int64_t block_cols;         // > 0: the columns are blocks of independent runs (pls_block_desc); Philox column = column inside the block
   __device__ uint64_t live_step() const { return step_base ? step + *step_base : step; }
+  __device__ int64_t global_column(int64_t col) const { return j_offset + (block_cols > 0 ? col % block_cols : col); }
 };
 
-static NoiseP make_noisep(const pls_noise_desc *n) {
+// step size of a column: one scalar, or one per column block (pls_block_desc; the batched step-size search)
+struct EtaP {
+  double eta;
+  const double *blocks;  // device array, NULL = the scalar
+  int64_t block_cols;
+  __device__ double at(int64_t col) const { return blocks ? blocks[col / block_cols] : eta; }
+};
+
+static EtaP make_etap(double eta, const pls_block_desc *b) {
+  EtaP e{eta, nullptr, 0};
+  if (b) {
+    e.blocks = b->eta;
+    e.block_cols = b->block_cols;
+  }
+  return e;
+}
+
+static NoiseP make_noisep(const pls_noise_desc *n, const pls_block_desc *blocks = nullptr) {
   NoiseP p;
+  p.block_cols = blocks ? blocks->block_cols : 0;
   if (!n) {
     p.kind = PLS_NOISE_NONE;
     p.xi = nullptr;
@@ -121,7 +143,8 @@ struct EpiLangevinGaussian {
   const double *U;
   int64_t ldu;
   const double *c, *lam;
-  double eta, inv_noise, sq2eta;
+  EtaP etap;
+  double inv_noise;
   int add_u;
   NoiseP nz;
   // optional by-product: energy partials of the INPUT particles (acc = B U is exactly what their cost needs):
@@ -138,12 +161,17 @@ struct EpiLangevinGaussian {
     const double laml = load_row_constants(lam, iw, lane, I);
     const double ilaml = (iw + lane < I) ? 1.0 / laml : 0.0;
     const uint64_t nstep = nz.live_step();
+    // a lane owns ONE column for the whole epilogue: its step size and Philox column are loop invariants
+    const int64_t jl = jw + lane % (TJ * 16);
+    const int64_t jc = jl < J ? jl : J - 1;
+    const double eta = etap.at(jc), sq2eta = sqrt(2.0 * eta);
+    const int64_t jg = nz.global_column(jc);
     epilogue_row_pairs<TI, TJ>(
         acc, iw, jw, lane, wave, I, J, lds, cl, ilaml,
         [&](int64_t i, int64_t j, double v0, bool hi, double v1, const RowConsts &rc) {
           double z0 = 0.0, z1 = 0.0;
           if (nz.kind == PLS_NOISE_PHILOX) {
-            normal_pair(nz.seed, nstep, i, nz.j_offset + j, z0, z1);  // rows i and i + 4 share one Philox call
+            normal_pair(nz.seed, nstep, i, jg, z0, z1);  // rows i and i + 4 share one Philox call
           } else if (nz.kind == PLS_NOISE_INJECTED) {
             z0 = nz.xi[i * nz.ldxi + j];
             if (hi) z1 = nz.xi[(i + 4) * nz.ldxi + j];
@@ -415,19 +443,21 @@ __global__ __launch_bounds__(256) void langevin_update_kernel(double *out, int64
                                                                int64_t slab_stride,
                                                                const double *__restrict__ P, int64_t ldp,
                                                                const double *__restrict__ lam, double pconst,
-                                                               int64_t rows, int64_t j, double eta, double sq2eta,
+                                                               int64_t rows, int64_t j, EtaP etap,
                                                                int add_u, NoiseP nz,
                                                                const double *__restrict__ dsub = nullptr,
                                                                double dsub_scale = 0.0) {
   const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (col >= j) return;
+  const double eta = etap.at(col), sq2eta = sqrt(2.0 * eta);
+  const int64_t jg = nz.global_column(col);
   const int64_t npairs = cdiv(rows, 8) * 4;
   for (int64_t pr = blockIdx.y; pr < npairs; pr += gridDim.y) {
     const int64_t ib = (pr >> 2) * 8 + (pr & 3);
     if (ib >= rows) continue;
     double z0 = 0.0, z1 = 0.0;
     if (nz.kind == PLS_NOISE_PHILOX) {
-      normal_pair(nz.seed, nz.live_step(), ib, nz.j_offset + col, z0, z1);
+      normal_pair(nz.seed, nz.live_step(), ib, jg, z0, z1);
     } else if (nz.kind == PLS_NOISE_INJECTED) {
       z0 = nz.xi[ib * nz.ldxi + col];
       if (ib + 4 < rows) z1 = nz.xi[(ib + 4) * nz.ldxi + col];
@@ -566,10 +596,11 @@ __global__ __launch_bounds__(256) void counter_add_kernel(uint64_t *counter, uin
 
 __global__ __launch_bounds__(256) void normal_fill_kernel(double *__restrict__ out, int64_t ldo, int64_t rows,
                                                            int64_t j, uint64_t seed, uint64_t step, int64_t j_offset,
-                                                           const uint64_t *__restrict__ step_base) {
+                                                           const uint64_t *__restrict__ step_base, int64_t block_cols) {
   const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (col >= j) return;
   if (step_base) step += *step_base;
+  j_offset += (block_cols > 0 ? col % block_cols : col) - col;  // Philox column = j_offset + column inside the block
   const int64_t npairs = cdiv(rows, 8) * 4;
   for (int64_t pr = blockIdx.y; pr < npairs; pr += gridDim.y) {
     const int64_t ib = (pr >> 2) * 8 + (pr & 3);
@@ -804,6 +835,7 @@ static int validate_noise(const pls_noise_desc *n, int64_t rows) {
 
 // ---- small projection ranks: fused kernels (small_rank.h) -------------------------------------------------------
 static std::atomic<int64_t> g_small_rank_max{128};  // pls_set_option(PLS_OPT_SMALL_RANK_MAX)
+static std::atomic<int64_t> g_ipb_explicit_inverse{0};  // pls_set_option(PLS_OPT_IPB_EXPLICIT_INVERSE)
 
 static bool small_rank_ok(const double *Lb, int64_t ldlb, int64_t kdim) {
   return kdim >= 1 && kdim <= g_small_rank_max.load() && (ldlb & 1) == 0 && (reinterpret_cast<uintptr_t>(Lb) & 15) == 0;
@@ -928,6 +960,32 @@ static int stream_cost(const double *Lf, int64_t ldlf, const double *Lb, int64_t
   return PLS_OK;
 }
 
+int gemm_tn_ex(const double *L, int64_t ldl, const double *R, int64_t ldr, double *C, int64_t ldc, int64_t I, int64_t J,
+               int64_t K, double alpha, double beta, int tri, hipStream_t st) {
+  PLS_REQUIRE(L && R && C, "gemm_tn: NULL pointer");
+  PLS_REQUIRE(I >= 0 && J >= 0 && K >= 0, "gemm_tn: negative size");
+  PLS_REQUIRE(ldl >= I && ldr >= J && ldc >= J, "gemm_tn: leading dimension too small (ldl=%lld I=%lld ldr=%lld J=%lld ldc=%lld)",
+              (long long)ldl, (long long)I, (long long)ldr, (long long)J, (long long)ldc);
+  if (I == 0 || J == 0) return PLS_OK;
+  EpiStore e{C, ldc, alpha, beta, 0};
+  return launch_gemm(L, ldl, R, ldr, I, J, K, e, st, 0, tri);
+}
+
+// out[b] = mean of e[b * bc, min(j, (b + 1) * bc)): one block per column block, fixed-order tree
+__global__ __launch_bounds__(256) void block_means_kernel(const double *__restrict__ e, int64_t j, int64_t bc, double *out) {
+  __shared__ double red[256];
+  const int64_t c0 = (int64_t)blockIdx.x * bc;
+  const int64_t c1 = (c0 + bc < j) ? c0 + bc : j;
+  double s = 0.0;
+  for (int64_t c = c0 + threadIdx.x; c < c1; c += 256) s += e[c];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = red[0] / (double)(c1 - c0);
+}
 
 }  // namespace plship
 
@@ -947,6 +1005,10 @@ int pls_set_option(int32_t option, int64_t value) {
       PLS_REQUIRE(value >= 0 && value <= 128, "set_option: small-rank limit %lld outside 0..128", (long long)value);
       g_small_rank_max.store(value);
       return PLS_OK;
+    case PLS_OPT_IPB_EXPLICIT_INVERSE:
+      PLS_REQUIRE(value == 0 || value == 1, "set_option: ipb explicit inverse must be 0 or 1");
+      g_ipb_explicit_inverse.store(value);
+      return PLS_OK;
     default: return fail(PLS_ERR_INVALID_ARGUMENT, "set_option: unknown option %d", (int)option);
   }
 }
@@ -962,6 +1024,7 @@ int pls_debug_math(int32_t op, const double *x, double *out, int64_t n, void *st
 int64_t pls_get_option(int32_t option) {
   switch (option) {
     case PLS_OPT_SMALL_RANK_MAX: return g_small_rank_max.load();
+    case PLS_OPT_IPB_EXPLICIT_INVERSE: return g_ipb_explicit_inverse.load();
     default: return -1;
   }
 }
@@ -1037,9 +1100,15 @@ int pls_gemm_tn(const double *L, int64_t ldl, const double *R, int64_t ldr, doub
   PLS_REQUIRE(I >= 0 && J >= 0 && K >= 0, "gemm_tn: negative size");
   PLS_REQUIRE(ldl >= I && ldr >= J && ldc >= J, "gemm_tn: leading dimension too small (ldl=%lld I=%lld ldr=%lld J=%lld ldc=%lld)",
               (long long)ldl, (long long)I, (long long)ldr, (long long)J, (long long)ldc);
-  if (I == 0 || J == 0) return PLS_OK;
-  EpiStore e{C, ldc, alpha, beta, 0};
-  return launch_gemm(L, ldl, R, ldr, I, J, K, e, S(stream));
+  return gemm_tn_ex(L, ldl, R, ldr, C, ldc, I, J, K, alpha, beta, 0, S(stream));
+}
+
+int pls_block_means(const double *e, int64_t j, int64_t block_cols, double *out, void *stream) {
+  PLS_REQUIRE(e && out && j >= 0 && block_cols > 0, "block_means: bad arguments");
+  if (j == 0) return PLS_OK;
+  PLS_REQUIRE(cdiv(j, block_cols) <= 0x7fffffff, "block_means: too many blocks");
+  hipLaunchKernelGGL(block_means_kernel, dim3((unsigned)cdiv(j, block_cols)), dim3(256), 0, S(stream), e, j, block_cols, out);
+  return check_launch("block_means");
 }
 
 int pls_cost_derivative(const pls_cost_desc *cost, const double *F, int64_t ldf, const double *y, int64_t n, int64_t j,
@@ -1131,7 +1200,7 @@ int pls_normal_fill(double *out, int64_t ldout, int64_t rows, int64_t j, uint64_
   PLS_REQUIRE(rows >= 0 && j >= 0 && ldout >= j, "normal_fill: bad sizes");
   if (rows == 0 || j == 0) return PLS_OK;
   hipLaunchKernelGGL(normal_fill_kernel, dim3((unsigned)cdiv(j, 256), rows_grid(cdiv(rows, 8) * 4)), dim3(256), 0,
-                     S(stream), out, ldout, rows, j, seed, step, j_offset, (const uint64_t *)nullptr);
+                     S(stream), out, ldout, rows, j, seed, step, j_offset, (const uint64_t *)nullptr, (int64_t)0);
   return check_launch("normal_fill");
 }
 
@@ -1200,8 +1269,8 @@ int pls_onb_particle_update(const pls_onb_desc *basis, const double *U, int64_t 
   rc = pls_gemm_tn(basis->At, basis->ldat, G, ldg, dU, lddu, basis->mk, j, basis->n, 1.0, 0.0, stream);
   if (rc) return rc;
   hipLaunchKernelGGL(langevin_update_kernel, dim3((unsigned)cdiv(j, 256), rows_grid(cdiv(basis->mk, 8) * 4)), dim3(256), 0,
-                     S(stream), dU, lddu, U, ldu, dU, lddu, 1, (int64_t)0, U, ldu, basis->lam, 0.0, basis->mk, j, eta, sqrt(2.0 * eta),
-                     0, make_noisep(noise));
+                     S(stream), dU, lddu, U, ldu, dU, lddu, 1, (int64_t)0, U, ldu, basis->lam, 0.0, basis->mk, j,
+                     make_etap(eta, nullptr), 0, make_noisep(noise));
   return check_launch("langevin_update");
 }
 
@@ -1248,14 +1317,24 @@ size_t pls_onb_step_workspace_bytes(const pls_onb_desc *basis, int64_t j, int64_
          onb_energy_partial_bytes(n_chunk, j) + (size_t)n_chunk * j * sizeof(double);
 }
 
-int pls_onb_step(const pls_onb_desc *basis, const pls_cost_desc *cost, const double *y, double *U, int64_t ldu,
-                 int64_t j, double eta, const pls_noise_desc *noise, double *out, int64_t ldo, int32_t out_mode,
-                 int32_t force_generic, double *energy_in, void *workspace, size_t workspace_bytes, void *stream) {
+static int validate_blocks(const pls_block_desc *b, int64_t j) {
+  if (!b) return PLS_OK;
+  PLS_REQUIRE(b->block_cols > 0 && b->eta != nullptr, "step_blocks: block_cols must be > 0 and eta set");
+  (void)j;
+  return PLS_OK;
+}
+
+static int onb_step_impl(const pls_onb_desc *basis, const pls_cost_desc *cost, const double *y, double *U, int64_t ldu,
+                         int64_t j, double eta, const pls_block_desc *blocks, const pls_noise_desc *noise, double *out,
+                         int64_t ldo, int32_t out_mode, int32_t force_generic, double *energy_in, void *workspace,
+                         size_t workspace_bytes, void *stream) {
   int rc = validate_onb(basis);
   if (rc) return rc;
   rc = validate_cost(cost);
   if (rc) return rc;
   rc = validate_noise(noise, basis->mk);
+  if (rc) return rc;
+  rc = validate_blocks(blocks, j);
   if (rc) return rc;
   PLS_REQUIRE(U && out && y, "onb_step: NULL pointer");
   PLS_REQUIRE(out != U, "onb_step: out must not alias U (ping-pong the particle buffers)");
@@ -1264,7 +1343,8 @@ int pls_onb_step(const pls_onb_desc *basis, const pls_cost_desc *cost, const dou
   PLS_REQUIRE(out_mode == 0 || out_mode == 1, "onb_step: out_mode must be 0 (delta) or 1 (new state)");
   if (j == 0) return PLS_OK;
   const CostP cp = make_costp(cost);
-  const NoiseP nz = make_noisep(noise);
+  const NoiseP nz = make_noisep(noise, blocks);
+  const EtaP etap = make_etap(eta, blocks);
   hipStream_t st = S(stream);
   if (onb_fast_path(basis, cost, force_generic)) {
     const bool big = use_big_tiles(basis->mk, j);
@@ -1276,7 +1356,7 @@ int pls_onb_step(const pls_onb_desc *basis, const pls_cost_desc *cost, const dou
                     (size_t)parts * j * sizeof(double));
       epart = static_cast<double *>(workspace);
     }
-    EpiLangevinGaussian e{out, ldo, U, ldu, basis->c, basis->lam, eta, 1.0 / cost->p[0], sqrt(2.0 * eta), out_mode, nz,
+    EpiLangevinGaussian e{out, ldo, U, ldu, basis->c, basis->lam, etap, 1.0 / cost->p[0], out_mode, nz,
                           epart, j, 2, big ? 128 : 64};
     rc = launch_gemm(basis->B, basis->ldb, U, ldu, basis->mk, j, basis->mk, e, st);
     if (rc || !energy_in) return rc;
@@ -1318,9 +1398,25 @@ int pls_onb_step(const pls_onb_desc *basis, const pls_cost_desc *cost, const dou
     LaunchScope scope(PLS_TAG_LANGEVIN_UPDATE, st);
     hipLaunchKernelGGL(langevin_update_kernel, dim3((unsigned)cdiv(j, 256), rows_grid(cdiv(basis->mk, 8) * 4)), dim3(256), 0,
                        st, out, ldo, U, ldu, D, j, (int)nslab, (int64_t)(d_bytes / sizeof(double)), U, ldu, basis->lam, 0.0,
-                       basis->mk, j, eta, sqrt(2.0 * eta), out_mode, nz);
+                       basis->mk, j, etap, out_mode, nz);
   }
   return check_launch("langevin_update");
+}
+
+int pls_onb_step(const pls_onb_desc *basis, const pls_cost_desc *cost, const double *y, double *U, int64_t ldu,
+                 int64_t j, double eta, const pls_noise_desc *noise, double *out, int64_t ldo, int32_t out_mode,
+                 int32_t force_generic, double *energy_in, void *workspace, size_t workspace_bytes, void *stream) {
+  return onb_step_impl(basis, cost, y, U, ldu, j, eta, nullptr, noise, out, ldo, out_mode, force_generic, energy_in, workspace,
+                       workspace_bytes, stream);
+}
+
+int pls_onb_step_blocks(const pls_onb_desc *basis, const pls_cost_desc *cost, const double *y, double *U, int64_t ldu,
+                        int64_t j, const pls_block_desc *blocks, const pls_noise_desc *noise, double *out, int64_t ldo,
+                        int32_t out_mode, int32_t force_generic, double *energy_in, void *workspace,
+                        size_t workspace_bytes, void *stream) {
+  PLS_REQUIRE(blocks != nullptr, "onb_step_blocks: block descriptor is NULL");
+  return onb_step_impl(basis, cost, y, U, ldu, j, 0.0, blocks, noise, out, ldo, out_mode, force_generic, energy_in, workspace,
+                       workspace_bytes, stream);
 }
 
 size_t pls_onb_energy_workspace_bytes(const pls_onb_desc *basis, int64_t j, int64_t n_chunk) {
@@ -1387,11 +1483,24 @@ int pls_onb_prior_energy(const pls_onb_desc *basis, const double *U, int64_t ldu
 static int validate_ipb(const pls_ipb_desc *b) {
   PLS_REQUIRE(b != nullptr, "ipb descriptor is NULL");
   PLS_REQUIRE(b->m > 0 && b->n > 0, "ipb: m and n must be positive");
-  PLS_REQUIRE(b->Kzx && b->Kxz && b->W, "ipb: Kzx, Kxz and W must be set");
-  PLS_REQUIRE(b->ldkzx >= b->n && b->ldkxz >= b->m && b->ldw >= b->m, "ipb: leading dimension too small");
+  PLS_REQUIRE(b->Kzx && b->Kxz, "ipb: Kzx and Kxz must be set");
+  PLS_REQUIRE((b->Sf && b->Sb) || b->W, "ipb: k(Z,Z) must enter as substitution operators Sf / Sb (pls_chol_factor) or as W");
+  PLS_REQUIRE((b->Sf == nullptr) == (b->Sb == nullptr), "ipb: Sf and Sb go together");
+  PLS_REQUIRE(b->ldkzx >= b->n && b->ldkxz >= b->m, "ipb: leading dimension too small");
+  if (b->W) PLS_REQUIRE(b->ldw >= b->m, "ipb: ldw < m");
+  if (b->Sf) PLS_REQUIRE(b->ldsf >= b->m && b->ldsb >= b->m, "ipb: ldsf / ldsb < m");
   if (b->LcT) PLS_REQUIRE(b->ldlct >= b->m, "ipb: ldlct < m");
   if (b->B) PLS_REQUIRE(b->ldb >= b->m && b->c, "ipb: fast-path constants need ldb >= m and c");
   return PLS_OK;
+}
+
+// V (m x j, ld j) = k(Z,Z)^-1 U: forward + backward substitution with the Cholesky factor (one launch), or -- A/B option,
+// or a descriptor without the substitution operators -- the contraction with the explicit inverse W.
+static int ipb_apply_kinv(const pls_ipb_desc *b, const double *U, int64_t ldu, int64_t j, double *V, void *stream) {
+  const bool explicit_inverse = !b->Sf || (g_ipb_explicit_inverse.load() != 0 && b->W);
+  if (explicit_inverse) return pls_gemm_tn(b->W, b->ldw, U, ldu, V, j, b->m, j, b->m, 1.0, 0.0, stream);  // W symmetric
+  pls_chol_desc f{b->m, nullptr, 0, b->LcT, b->ldlct, b->Sf, b->ldsf, b->Sb, b->ldsb};
+  return chol_solve_launch(&f, U, ldu, j, V, j, 0, S(stream));
 }
 
 int pls_ipb_forward(const pls_ipb_desc *basis, const double *U, int64_t ldu, int64_t j, double *F, int64_t ldf,
@@ -1404,7 +1513,7 @@ int pls_ipb_forward(const pls_ipb_desc *basis, const double *U, int64_t ldu, int
   if (!workspace || workspace_bytes < need)
     return fail(PLS_ERR_WORKSPACE_TOO_SMALL, "ipb_forward: workspace %zu < %zu bytes", workspace_bytes, need);
   double *V = static_cast<double *>(workspace);
-  rc = pls_gemm_tn(basis->W, basis->ldw, U, ldu, V, j, basis->m, j, basis->m, 1.0, 0.0, stream);  // W symmetric
+  rc = ipb_apply_kinv(basis, U, ldu, j, V, stream);
   if (rc) return rc;
   return pls_gemm_tn(basis->Kzx, basis->ldkzx, V, j, F, ldf, basis->n, j, basis->m, 1.0, 0.0, stream);
 }
@@ -1412,16 +1521,17 @@ int pls_ipb_forward(const pls_ipb_desc *basis, const double *U, int64_t ldu, int
 // shared tail of the IPB update: out = [U +] -eta*D - eta*M*V + sqrt(2 eta) e
 static int ipb_finish(const pls_ipb_desc *basis, const double *U, int64_t ldu, const double *D, int nslab,
                       int64_t slab_stride, const double *V, int64_t j, double eta, const pls_noise_desc *noise, double *out, int64_t ldo, int add_u,
-                      double *xi_buf, double *e_buf, hipStream_t st, const double *dsub = nullptr, double dsub_scale = 0.0) {
-  NoiseP nz = make_noisep(noise);
+                      double *xi_buf, double *e_buf, hipStream_t st, const double *dsub = nullptr, double dsub_scale = 0.0,
+                      const pls_block_desc *blocks = nullptr) {
+  NoiseP nz = make_noisep(noise, blocks);
   if (nz.kind == PLS_NOISE_PHILOX) {
     if (!basis->LcT) return fail(PLS_ERR_INVALID_ARGUMENT, "ipb: Philox noise needs the Cholesky factor LcT");
     hipLaunchKernelGGL(normal_fill_kernel, dim3((unsigned)cdiv(j, 256), rows_grid(cdiv(basis->m, 8) * 4)), dim3(256), 0, st,
-                       xi_buf, j, basis->m, j, nz.seed, nz.step, nz.j_offset, nz.step_base);
+                       xi_buf, j, basis->m, j, nz.seed, nz.step, nz.j_offset, nz.step_base, nz.block_cols);
     int rc = check_launch("normal_fill");
     if (rc) return rc;
-    // e = Lc xi :  L[k][i] = LcT[k][i] = Lc[i][k]
-    rc = pls_gemm_tn(basis->LcT, basis->ldlct, xi_buf, j, e_buf, j, basis->m, j, basis->m, 1.0, 0.0, st);
+    // e = Lc xi :  L[k][i] = LcT[k][i] = Lc[i][k], zero for k > i: a triangular product (half the contraction)
+    rc = gemm_tn_ex(basis->LcT, basis->ldlct, xi_buf, j, e_buf, j, basis->m, j, basis->m, 1.0, 0.0, 1, st);
     if (rc) return rc;
     nz.kind = PLS_NOISE_INJECTED;
     nz.xi = e_buf;
@@ -1429,7 +1539,7 @@ static int ipb_finish(const pls_ipb_desc *basis, const double *U, int64_t ldu, c
   }
   hipLaunchKernelGGL(langevin_update_kernel, dim3((unsigned)cdiv(j, 256), rows_grid(cdiv(basis->m, 8) * 4)), dim3(256), 0, st,
                      out, ldo, U, ldu, D, j, nslab, slab_stride, V, j, (const double *)nullptr, (double)basis->m, basis->m, j,
-                     eta, sqrt(2.0 * eta), add_u, nz, dsub, dsub_scale);
+                     make_etap(eta, blocks), add_u, nz, dsub, dsub_scale);
   return check_launch("langevin_update");
 }
 
@@ -1470,7 +1580,7 @@ int pls_ipb_particle_update(const pls_ipb_desc *basis, const double *U, int64_t 
   char *w = static_cast<char *>(workspace);
   double *V = reinterpret_cast<double *>(w), *D = reinterpret_cast<double *>(w + mj);
   double *xi = reinterpret_cast<double *>(w + 2 * mj), *e = reinterpret_cast<double *>(w + 3 * mj);
-  rc = pls_gemm_tn(basis->W, basis->ldw, U, ldu, V, j, basis->m, j, basis->m, 1.0, 0.0, stream);
+  rc = ipb_apply_kinv(basis, U, ldu, j, V, stream);
   if (rc) return rc;
   rc = pls_gemm_tn(basis->Kxz, basis->ldkxz, G, ldg, D, j, basis->m, j, basis->n, 1.0, 0.0, stream);
   if (rc) return rc;
@@ -1485,14 +1595,17 @@ size_t pls_ipb_step_workspace_bytes(const pls_ipb_desc *basis, int64_t j, int64_
          onb_energy_partial_bytes(n_chunk, j) + (size_t)n_chunk * j * sizeof(double);
 }
 
-int pls_ipb_step(const pls_ipb_desc *basis, const pls_cost_desc *cost, const double *y, double *U, int64_t ldu, int64_t j,
-                 double eta, const pls_noise_desc *noise, double *out, int64_t ldo, int32_t out_mode, int32_t force_generic,
-                 double *energy_in, void *workspace, size_t workspace_bytes, void *stream) {
+static int ipb_step_impl(const pls_ipb_desc *basis, const pls_cost_desc *cost, const double *y, double *U, int64_t ldu, int64_t j,
+                         double eta, const pls_block_desc *blocks, const pls_noise_desc *noise, double *out, int64_t ldo,
+                         int32_t out_mode, int32_t force_generic, double *energy_in, void *workspace, size_t workspace_bytes,
+                         void *stream) {
   int rc = validate_ipb(basis);
   if (rc) return rc;
   rc = validate_cost(cost);
   if (rc) return rc;
   rc = validate_noise(noise, basis->m);
+  if (rc) return rc;
+  rc = validate_blocks(blocks, j);
   if (rc) return rc;
   PLS_REQUIRE(U && out && y, "ipb_step: NULL pointer");
   PLS_REQUIRE(out != U, "ipb_step: out must not alias U");
@@ -1514,7 +1627,7 @@ int pls_ipb_step(const pls_ipb_desc *basis, const pls_cost_desc *cost, const dou
   double *vpart = reinterpret_cast<double *>(w + fixed);
   double *Gbuf = reinterpret_cast<double *>(w + fixed + onb_energy_partial_bytes(n_chunk, j));
   hipStream_t st = S(stream);
-  rc = pls_gemm_tn(basis->W, basis->ldw, U, ldu, V, j, basis->m, j, basis->m, 1.0, 0.0, stream);
+  rc = ipb_apply_kinv(basis, U, ldu, j, V, stream);
   if (rc) return rc;
   if (ipb_fast_path(basis, cost, force_generic)) {
     const double inv_noise = 1.0 / cost->p[0];
@@ -1526,7 +1639,8 @@ int pls_ipb_step(const pls_ipb_desc *basis, const pls_cost_desc *cost, const dou
       rc = check_launch("ipb_gaussian_energy");
       if (rc) return rc;
     }
-    return ipb_finish(basis, U, ldu, D, 1, (int64_t)0, V, j, eta, noise, out, ldo, out_mode, xi, e, st, basis->c, inv_noise);
+    return ipb_finish(basis, U, ldu, D, 1, (int64_t)0, V, j, eta, noise, out, ldo, out_mode, xi, e, st, basis->c, inv_noise,
+                      blocks);
   }
   EnergySink sink;
   if (energy_in) {  // e_j = cost_j(F(U)) + (M/2) ||K^-1 U_j||^2 of the INPUT particles (inducing_point.py:95-115)
@@ -1544,7 +1658,23 @@ int pls_ipb_step(const pls_ipb_desc *basis, const pls_cost_desc *cost, const dou
                     D, j, max_slabs, (int64_t)(mj / sizeof(double)), &nslab, Gbuf, n_chunk, st, energy_in ? &sink : nullptr);
   if (rc) return rc;
   return ipb_finish(basis, U, ldu, D, (int)nslab, (int64_t)(mj / sizeof(double)), V, j, eta, noise, out, ldo, out_mode, xi, e,
-                    st);
+                    st, nullptr, 0.0, blocks);
+}
+
+int pls_ipb_step(const pls_ipb_desc *basis, const pls_cost_desc *cost, const double *y, double *U, int64_t ldu, int64_t j,
+                 double eta, const pls_noise_desc *noise, double *out, int64_t ldo, int32_t out_mode, int32_t force_generic,
+                 double *energy_in, void *workspace, size_t workspace_bytes, void *stream) {
+  return ipb_step_impl(basis, cost, y, U, ldu, j, eta, nullptr, noise, out, ldo, out_mode, force_generic, energy_in, workspace,
+                       workspace_bytes, stream);
+}
+
+int pls_ipb_step_blocks(const pls_ipb_desc *basis, const pls_cost_desc *cost, const double *y, double *U, int64_t ldu,
+                        int64_t j, const pls_block_desc *blocks, const pls_noise_desc *noise, double *out, int64_t ldo,
+                        int32_t out_mode, int32_t force_generic, double *energy_in, void *workspace,
+                        size_t workspace_bytes, void *stream) {
+  PLS_REQUIRE(blocks != nullptr, "ipb_step_blocks: block descriptor is NULL");
+  return ipb_step_impl(basis, cost, y, U, ldu, j, 0.0, blocks, noise, out, ldo, out_mode, force_generic, energy_in, workspace,
+                       workspace_bytes, stream);
 }
 
 size_t pls_ipb_energy_workspace_bytes(const pls_ipb_desc *basis, int64_t j, int64_t n_chunk) {
@@ -1572,7 +1702,7 @@ int pls_ipb_energy(const pls_ipb_desc *basis, const pls_cost_desc *cost, const d
     if (workspace_bytes < 2 * mj) return fail(PLS_ERR_WORKSPACE_TOO_SMALL, "ipb_energy: workspace %zu < %zu bytes", workspace_bytes, 2 * mj);
     double *D = reinterpret_cast<double *>(static_cast<char *>(workspace) + mj);
     const double inv_noise = 1.0 / cost->p[0];
-    rc = pls_gemm_tn(basis->W, basis->ldw, U, ldu, V, j, basis->m, j, basis->m, 1.0, 0.0, stream);
+    rc = ipb_apply_kinv(basis, U, ldu, j, V, stream);
     if (rc) return rc;
     rc = pls_gemm_tn(basis->B, basis->ldb, V, j, D, j, basis->m, j, basis->m, inv_noise, 0.0, stream);
     if (rc) return rc;
@@ -1585,7 +1715,7 @@ int pls_ipb_energy(const pls_ipb_desc *basis, const pls_cost_desc *cost, const d
   int64_t n_chunk = max_parts * 64;
   if (n_chunk > basis->n) n_chunk = basis->n;
   else n_chunk = n_chunk / 128 * 128;
-  rc = pls_gemm_tn(basis->W, basis->ldw, U, ldu, V, j, basis->m, j, basis->m, 1.0, 0.0, stream);
+  rc = ipb_apply_kinv(basis, U, ldu, j, V, stream);
   if (rc) return rc;
   return stream_cost(basis->Kzx, basis->ldkzx, basis->Kxz, basis->ldkxz, basis->m, basis->n, V, j, j, make_costp(cost), y,
                      partial, max_parts, n_chunk, e, 2, V, j, basis->m, nullptr, 0.5 * (double)basis->m, S(stream));
@@ -1601,7 +1731,7 @@ int pls_ipb_prior_energy(const pls_ipb_desc *basis, const double *U, int64_t ldu
   if (!workspace || workspace_bytes < need)
     return fail(PLS_ERR_WORKSPACE_TOO_SMALL, "ipb_prior_energy: workspace %zu < %zu bytes", workspace_bytes, need);
   double *V = static_cast<double *>(workspace);
-  rc = pls_gemm_tn(basis->W, basis->ldw, U, ldu, V, j, basis->m, j, basis->m, 1.0, 0.0, stream);
+  rc = ipb_apply_kinv(basis, U, ldu, j, V, stream);
   if (rc) return rc;
   hipLaunchKernelGGL(column_reduce_kernel, dim3((unsigned)cdiv(j, 256)), dim3(256), 0, S(stream), cost, j,
                      (int64_t)(cost ? 1 : 0), j, e, 0, 2, (const double *)V, j, basis->m, (const double *)nullptr,

@@ -11,8 +11,18 @@ from __future__ import annotations
 import torch
 
 from . import _lib as L
+from . import _ops
 from .basis.base import NoiseSpec
 from .projected_langevin_sampling import PLS
+
+
+def _own_workspace(basis, cost, particles: torch.Tensor, with_energy: bool, force_generic: bool = False) -> torch.Tensor | None:
+    """A workspace buffer that belongs to ONE capture (never shared with, nor freed by, the basis)."""
+    cd = cost.desc()
+    if cd.cost == L.COST_GAUSSIAN and cd.link == L.LINK_IDENTITY and not force_generic:
+        basis.prepare_gaussian(cost.y_device())  # (allocates B and c: must not happen inside the capture)
+    nbytes = basis.step_workspace_bytes(cost, particles.shape[1], with_energy, force_generic)
+    return torch.empty(max(nbytes // 8 + 1, 1), dtype=torch.float64, device=particles.device)
 
 
 class CapturedSteps:
@@ -29,12 +39,16 @@ class CapturedSteps:
         self._pong = torch.empty_like(particles)
         self.counter = torch.zeros(1, dtype=torch.int64, device=particles.device)
         basis, cost = pls.basis, pls.cost
+        # the capture freezes the workspace ADDRESS: it owns the buffer (the basis' own scratch is reallocated whenever a
+        # later eager call asks for more bytes, e.g. an energy evaluation between two replays)
+        self._ws = _own_workspace(basis, cost, particles, with_energy=False, force_generic=force_generic)
 
         def body():
             cur, nxt = self.particles, self._pong
             for s in range(self.k):
                 spec = NoiseSpec(seed=seed, step=s, j_offset=basis.j_offset, step_base=self.counter)
-                basis.fused_step(cost, cur, float(step_size), out=nxt, new_state=True, noise=spec, force_generic=force_generic)
+                basis.fused_step(cost, cur, float(step_size), out=nxt, new_state=True, noise=spec, force_generic=force_generic,
+                                 workspace=self._ws)
                 cur, nxt = nxt, cur
             if cur is not self.particles:
                 self.particles.copy_(cur)
@@ -91,14 +105,16 @@ class CapturedTraining:
         self.means = torch.zeros(steps_per_replay, dtype=torch.float64, device=particles.device)
         self.counter = torch.zeros(1, dtype=torch.int64, device=particles.device)
         basis, cost = pls.basis, pls.cost
+        self._ws = _own_workspace(basis, cost, particles, with_energy=True)  # owned by the capture (see CapturedSteps)
 
         def body():
             self._start.copy_(self.particles)
             cur, nxt = self.particles, self._pong
             for s in range(self.k):
                 spec = NoiseSpec(seed=self.seed, step=s, j_offset=basis.j_offset, step_base=self.counter)
-                basis.fused_step(cost, cur, self.step_size, out=nxt, new_state=True, noise=spec, input_energy=self._e)
-                self.means[s: s + 1].copy_(self._e.mean().reshape(1))  # E(U_{k0 + s}), the INPUT of launch k0 + s
+                basis.fused_step(cost, cur, self.step_size, out=nxt, new_state=True, noise=spec, input_energy=self._e,
+                                 workspace=self._ws)
+                _ops.block_means(self._e, out=self.means[s: s + 1])  # E(U_{k0 + s}), the INPUT of launch k0 + s
                 cur, nxt = nxt, cur
             if cur is not self.particles:
                 self.particles.copy_(cur)

@@ -3,6 +3,7 @@ from __future__ import annotations
 
 import torch
 
+from . import _ops
 from .basis.base import NoiseSpec, PLSBasis
 from .costs.base import PLSCost
 
@@ -63,8 +64,11 @@ class PLS:
             spec = NoiseSpec(injected=noise) if noise is not None else None
             return self.basis.fused_step(self.cost, particles, step_size, noise=spec)
         cost_derivative = self.calculate_cost_derivative(particles=particles)
+        # `noise` is this library's extension: a user-defined basis written against the reference's abstract signature
+        # (particles, cost_derivative, step_size) never sees the keyword unless the caller injects noise
+        extra = {} if noise is None else {"noise": noise}
         return self.basis.calculate_particle_update(
-            particles=particles, cost_derivative=cost_derivative, step_size=step_size, noise=noise
+            particles=particles, cost_derivative=cost_derivative, step_size=step_size, **extra
         )
 
     def step_(self, particles: torch.Tensor, step_size: float, noise: torch.Tensor | None = None) -> torch.Tensor:
@@ -93,7 +97,8 @@ class PLS:
     def calculate_energy_potential(self, particles: torch.Tensor) -> float:
         """Average energy potential (:125-138); returns a Python float (device sync, like the reference)."""
         if hasattr(self.basis, "particle_energy_potential"):
-            return self.particle_energy_potential(particles).mean().item()
+            e = self.particle_energy_potential(particles)
+            return _ops.block_means(e).item() if e.is_cuda else e.mean().item()
         # a user-defined basis that only implements the reference's abstract interface
         assert (
             particles.shape[0] == self.basis.approximation_dimension

@@ -6,6 +6,7 @@ from typing import List, Tuple
 import numpy as np
 import torch
 
+from . import _ops
 from .projected_langevin_sampling import PLS
 
 
@@ -29,6 +30,12 @@ class EarlyStopper:
             return False
 
 
+def _mean_energy(e: torch.Tensor) -> float:
+    """Mean over the particles of the per-particle energies (orthonormal.py:126's .mean().item()): libplship's fixed-order
+    reduction for device vectors, so that every loop variant (plain, pipelined, captured) reports identical values."""
+    return _ops.block_means(e).item() if e.is_cuda else e.mean().item()
+
+
 def train_pls(
     pls: PLS,
     particles: torch.Tensor,
@@ -48,7 +55,7 @@ def train_pls(
     orthonormal basis), the loop is software-pipelined: the launch of step t+1 also produces the energy the reference
     evaluates after step t, so every iteration is ONE kernel.  Results (particles, energy list, stop index, torch RNG
     state) are those of the plain loop: a step launched speculatively past the stop is discarded."""
-    reduce = energy_reduce if energy_reduce is not None else (lambda e: e.mean().item())
+    reduce = energy_reduce if energy_reduce is not None else _mean_energy
     early_stopper = EarlyStopper(patience=early_stopper_patience)
     energy_potentials: List[float] = []
     pipelined = (
@@ -110,6 +117,7 @@ def _train_pls_two_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs
             torch.empty_like(particles, memory_format=torch.contiguous_format)]
     e_dev = [torch.empty(j, dtype=torch.float64, device=particles.device) for _ in range(3)]
     host = torch.empty(3, dtype=torch.float64).pin_memory()
+    host_ptr = host.data_ptr()  # (hipHostMalloc'ed by torch: host and device addresses coincide)
     events = [torch.cuda.Event() for _ in range(3)]
     rng_states = {}
     launched = 0
@@ -121,7 +129,9 @@ def _train_pls_two_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs
         spec = NoiseSpec(injected=noises[k]) if noises is not None else None
         pls.basis.fused_step(pls.cost, bufs[k % 3], float(step_size), out=bufs[(k + 1) % 3], new_state=True, noise=spec,
                              input_energy=e_dev[k % 3])
-        host[k % 3: k % 3 + 1].copy_(e_dev[k % 3].mean().reshape(1), non_blocking=True)  # E(U_k)
+        # E(U_k): the reduction kernel stores the mean straight into pinned host memory (mapped into the device's address
+        # space); the host reads it after the event -- no torch reduce kernel, no copy kernel per iteration
+        _ops.block_means(e_dev[k % 3], out_ptr=host_ptr + 8 * (k % 3))
         events[k % 3].record()
         launched += 1
 
@@ -134,7 +144,7 @@ def _train_pls_two_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs
             events[(t + 1) % 3].synchronize()
             energy_potential = host[(t + 1) % 3].item()
         else:  # the energy after the last update has no following launch to ride on
-            energy_potential = pls.particle_energy_potential(bufs[T % 3]).mean().item()
+            energy_potential = _mean_energy(pls.particle_energy_potential(bufs[T % 3]))
         if early_stopper.should_stop(loss=energy_potential, step_size=step_size):
             if launched > t + 1:
                 torch.set_rng_state(rng_states[t + 1])
@@ -193,14 +203,14 @@ def train_pls_captured(pls: PLS, particles: torch.Tensor, number_of_epochs: int,
             while t < T:
                 if cap.steps_done < t + 1:
                     cap.eager_steps(t + 1 - cap.steps_done)
-                e = pls.particle_energy_potential(particles).mean().item()
+                e = _mean_energy(pls.particle_energy_potential(particles))
                 if early_stopper.should_stop(loss=e, step_size=step_size):
                     return particles, energies
                 energies.append(e)
                 t += 1
             return particles, energies
         if cap.steps_done == T:  # all updates done; E(U_T) has no following launch to ride on
-            e = pls.particle_energy_potential(particles).mean().item()
+            e = _mean_energy(pls.particle_energy_potential(particles))
             if not early_stopper.should_stop(loss=e, step_size=step_size):
                 energies.append(e)
             return particles, energies

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared_functions():
         assert hasattr(raw, name), f"{name} declared in include/plship.h but not exported"
     assert set(pkg._lib.SIGNATURES) == set(declared_functions()), "ctypes table and header disagree"
-    assert lib.pls_abi_version() == 1
+    assert lib.pls_abi_version() == pkg._lib.ABI_VERSION
     assert lib.pls_last_error() is not None
 
 
@@ -46,6 +46,10 @@ def test_options_validate_without_touching_the_gpu():
     assert lib.pls_get_option(99) == -1
     assert lib.pls_set_option(L.OPT_SMALL_RANK_MAX, 64) == 0 and lib.pls_get_option(L.OPT_SMALL_RANK_MAX) == 64
     assert lib.pls_set_option(L.OPT_SMALL_RANK_MAX, 128) == 0
+    assert lib.pls_get_option(L.OPT_IPB_EXPLICIT_INVERSE) == 0
+    assert lib.pls_set_option(L.OPT_IPB_EXPLICIT_INVERSE, 2) != 0
+    assert lib.pls_set_option(L.OPT_IPB_EXPLICIT_INVERSE, 1) == 0 and lib.pls_get_option(L.OPT_IPB_EXPLICIT_INVERSE) == 1
+    assert lib.pls_set_option(L.OPT_IPB_EXPLICIT_INVERSE, 0) == 0
 
 
 def test_struct_layouts_match_the_header():
@@ -56,7 +60,9 @@ def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(L.CostDesc) == 4 * 4 + 4 * 8 + 8
     assert ctypes.sizeof(L.NoiseDesc) == 8 + 8 + 8 + 8 + 8 + 8 + 8
     assert ctypes.sizeof(L.OnbDesc) == 10 * 8
-    assert ctypes.sizeof(L.IpbDesc) == 13 * 8
+    assert ctypes.sizeof(L.IpbDesc) == 17 * 8
+    assert ctypes.sizeof(L.CholDesc) == 9 * 8
+    assert ctypes.sizeof(L.BlockDesc) == 2 * 8
     assert L.CostDesc.p.offset == 16 and L.CostDesc.jitter.offset == 48
 
 

@@ -113,12 +113,18 @@ def build_onb(P, pr, threshold=1e-6, kernel="rbf"):
     return ob, gb
 
 
-def build_ipb(P, pr):
+def build_ipb(P, pr, factor="device"):
+    """Oracle and GPU inducing-point bases.  factor = "device": k(Z,Z) is factorised by libplship (pls_chol_factor);
+    "shared": the GPU side is handed the oracle's LAPACK factor, so both solve with the SAME factor (the analogue of the
+    shared eigh gauge of build_onb) and only the substitution kernels are compared."""
     ok = O.RBFARDKernel(pr["ls"], 1.3)
     gk = P.pkg.ARDKernel(pr["ls"], 1.3)
     yz = pr["y"][: pr["z"].shape[0]]
     ob = O.InducingPointBasis(ok, pr["z"], yz, pr["x"])
-    gb = P.basis.InducingPointBasis(P.pkg.PLSKernel(gk, pr["z"]), pr["z"], yz, pr["x"])
+    kw = {}
+    if factor == "shared":
+        kw["cholesky_factor"] = torch.linalg.cholesky(ob.base_gram_induce)
+    gb = P.basis.InducingPointBasis(P.pkg.PLSKernel(gk, pr["z"]), pr["z"], yz, pr["x"], **kw)
     return ob, gb
 
 
@@ -446,12 +452,16 @@ def test_onb_step_all_costs(P, rank_path, n, m, j, d):
     u = pr["u"][:mk].contiguous()
     xi = torch.randn(mk, j, generator=pr["gen"])
     eta = 1e-3
+    checked, skipped = 0, []
     for name, oc, gc in make_costs(P, pr["y"], pr["fstar"], pr["gen"]):
         want = O.PLS(ob, oc).calculate_particle_update(u.clone(), eta, noise=xi)
         tol = step_tolerance(ob, oc, u, eta, xi, want)
         if tol >= 1e-8:
-            continue  # this (cost, data) pair cannot be held to 1e-8 by ANY fp64 implementation; stages are checked below
-
+            # this (cost, data) pair cannot be held to 1e-8 by ANY fp64 implementation (a 1/f pole inside the data);
+            # counted, reported, and bounded below -- never silently dropped
+            skipped.append((name, f"{tol:.1e}"))
+            continue
+        checked += 1
         pls = P.pkg.PLS(gb, gc)
         got = pls.calculate_particle_update(cu(u), eta, noise=cu(xi))
         assert relerr(got, want) < tol, f"fused {name}"
@@ -477,6 +487,9 @@ def test_onb_step_all_costs(P, rank_path, n, m, j, d):
             got3 = gb.fused_step(gc, cu(u), eta, noise=P.basis.NoiseSpec(injected=cu(xi)), force_generic=True)
             assert relerr(got3, want) < tol, "generic gaussian"
             assert gb._B is not None
+    print(f"onb step ({n},{m},{j},{d}): {checked} of 8 (cost, link) pairs held to the oracle; skipped for conditioning: {skipped}")
+    assert checked >= 6, f"only {checked} of 8 pairs were checked; skipped: {skipped}"
+    assert all(name.startswith("poisson") for name, _ in skipped), f"only the 1/f costs may be skipped: {skipped}"
 
 
 def test_onb_step_chunked_and_split_k(P, rank_path):
@@ -586,10 +599,11 @@ def test_ipb_gaussian_fast_path_equals_the_generic_path(P, n, m, j, d):
     fast = gb.fused_step(gc, cu(u), 1e-3, noise=noise, input_energy=e_fast_in)
     assert gb._B is not None
     gen = gb.fused_step(gc, cu(u), 1e-3, noise=noise, force_generic=True)
-    tol = max(1e-9, cond * 1e-13)
+    tol = 1e-9  # (both paths apply the same device factor; the oracle solves with LAPACK's -- still TOL for cond <= 1e8)
+    assert cond <= 1e8, f"test construction: cond(k(Z,Z)) = {cond:.1e}"
     assert relerr(fast, gen) < tol
     want = O.PLS(ob, oc).calculate_particle_update(u.clone(), 1e-3, noise=e_noise)
-    assert relerr(fast, want) < max(tol, cond * 1e-14)
+    assert relerr(fast, want) < tol, f"cond {cond:.1e}: {relerr(fast, want):.2e}"
     e_fast, e_gen = gb.fused_particle_energy(gc, cu(u)), gb.fused_particle_energy(gc, cu(u), force_generic=True)
     assert relerr(e_fast, e_gen) < tol and relerr(e_fast_in, e_gen) < tol
     e_want = O.PLS(ob, oc).calculate_energy_potential(u.clone())
@@ -789,12 +803,16 @@ def test_fuzz_inducing_point_basis_paths(P):
         pr = make_problem(n, m, j, d, seed=9000 + draw)
         pr["ls"] = pr["ls"] * 0.2
         try:
-            ob, gb = build_ipb(P, pr)
+            ob = O.InducingPointBasis(O.RBFARDKernel(pr["ls"], 1.3), pr["z"], pr["y"][:m], pr["x"])
+            torch.linalg.cholesky(ob.base_gram_induce)
         except torch.linalg.LinAlgError:
-            continue  # this draw's k(Z,Z) is numerically singular (the reference could not factorise it either)
+            singular = locals().get("singular", 0) + 1
+            continue  # this draw's k(Z,Z) is numerically singular: the jitter path is test_device_cholesky_jitter's subject
         cond = torch.linalg.cond(ob.base_gram_induce).item()
         if cond > 1e8:
+            ill = locals().get("ill", 0) + 1
             continue
+        ob, gb = build_ipb(P, pr)
         tested = locals().get("tested", 0) + 1
         costs = make_costs(P, pr["y"], pr["fstar"], pr["gen"])
         name, _, gc = costs[draw % 5]
@@ -804,7 +822,7 @@ def test_fuzz_inducing_point_basis_paths(P):
         fdev = gb.calculate_untransformed_train_prediction_samples(cu(u))
         if name.startswith("poisson") and fdev.abs().min().item() < 1e-3:
             name, _, gc = costs[2]
-        tol = max(1e-9, cond * 1e-13)
+        tol = 1e-9  # both sides of every comparison below solve with the same device factor and the same kernel
         e_in = torch.empty(j, dtype=torch.float64, device="cuda")
         fused = gb.fused_step(gc, cu(u), 1e-3, noise=noise, force_generic=True, input_energy=e_in)
         unfused = gb.calculate_particle_update(cu(u), gc.calculate_cost_derivative(fdev), 1e-3, noise=cu(e_noise))
@@ -816,6 +834,7 @@ def test_fuzz_inducing_point_basis_paths(P):
             e_fast_in = torch.empty(j, dtype=torch.float64, device="cuda")
             fast = gb.fused_step(gc, cu(u), 1e-3, noise=noise, input_energy=e_fast_in)
             assert relerr(fast, unfused) < tol and relerr(e_fast_in, e_unfused) < tol, tag
+    print(f"ipb fuzz: {tested} draws checked, {locals().get('singular', 0)} singular, {locals().get('ill', 0)} with cond > 1e8")
     assert tested >= 15, f"only {tested} of 30 draws were well conditioned"
 
 
@@ -824,6 +843,7 @@ def test_random_shape_sweep_against_the_oracle(P, rank_path):
     oracle, through whichever path `rank_path` selects (M <= 128 throughout, so `small_rank` really is the fused
     kernel and `two_gemm` the 64x64 / 128x128 GEMMs with their edge tiles)."""
     rng = np.random.default_rng(20260101)
+    checked, skipped = 0, []
     for draw in range(12):
         n = int(rng.integers(1, 1500))
         m = int(rng.integers(2, min(n, 128) + 1)) if n >= 2 else 1
@@ -843,35 +863,48 @@ def test_random_shape_sweep_against_the_oracle(P, rank_path):
             want = O.PLS(ob, oc).calculate_particle_update(u.clone(), 1e-3, noise=xi)
             tol = step_tolerance(ob, oc, u, 1e-3, xi, want)
             if tol >= 1e-8:
+                skipped.append((draw, name, f"{tol:.1e}"))
                 continue
+            checked += 1
             got = gb.fused_step(gc, cu(u), 1e-3, noise=P.basis.NoiseSpec(injected=cu(xi)), force_generic=True)
             assert relerr(got, want) < tol, f"draw {draw} ({n},{m}->{mk},{j},{d}) {name}"
             e_want = O.PLS(ob, oc).calculate_energy_potential(u.clone())
             e_got = gb.fused_particle_energy(gc, cu(u), force_generic=True).mean().item()
             assert abs(e_got - e_want) <= max(1e-9, tol) * abs(e_want), f"draw {draw} energy {name}"
+    print(f"shape sweep: {checked} steps held to the oracle; skipped for conditioning: {skipped}")
+    assert checked >= 18, f"only {checked} of <= 24 steps were checked; skipped: {skipped}"
 
 
-@pytest.mark.parametrize("n,m,j,d", [(512, 24, 64, 3), (100, 10, 7, 1), (700, 33, 130, 2)])
-def test_ipb_step_all_costs(P, rank_path, n, m, j, d):
+@pytest.mark.parametrize("factor", ["device", "shared"])
+@pytest.mark.parametrize("n,m,j,d", [(512, 24, 64, 3), (100, 10, 7, 1), (700, 33, 130, 2), (900, 150, 70, 3)])
+def test_ipb_step_all_costs(P, rank_path, n, m, j, d, factor):
+    """factor = "device": k(Z,Z) factorised by pls_chol_factor, the oracle by LAPACK -- TOL without any conditioning
+    allowance for the solves, for cond(k(Z,Z)) <= 1e8; "shared": both sides use the oracle's factor."""
     pr = make_problem(n, m, j, d, seed=7 * n + m)
-    pr["ls"] = pr["ls"] * 0.35  # keeps cond(k(Z,Z)) small enough for 1e-9 parity of the solves
-    ob, gb = build_ipb(P, pr)
+    pr["ls"] = pr["ls"] * 0.35
+    ob, gb = build_ipb(P, pr, factor=factor)
     cond = torch.linalg.cond(ob.base_gram_induce).item()
+    assert cond <= 1e8, f"test construction: cond(k(Z,Z)) = {cond:.1e}"
     u = pr["u"]
     e_noise = torch.randn(m, j, generator=pr["gen"])
     eta = 1e-3
+    checked, skipped = 0, []
     for name, oc, gc in make_costs(P, pr["y"], pr["fstar"], pr["gen"]):
         want = O.PLS(ob, oc).calculate_particle_update(u.clone(), eta, noise=e_noise)
-        # the two M x M solves lose cond(k(Z,Z)) * eps in BOTH implementations (explicit inverse here, Cholesky solve there)
-        tol = max(step_tolerance(ob, oc, u, eta, e_noise, want, solve_cond=cond), cond * 1e-14)
+        # TOL; only a cost with a 1/f pole (Poisson) gets the measured conditioning floor of ITS OWN nonlinearity
+        tol = step_tolerance(ob, oc, u, eta, e_noise, want)
         if tol >= 1e-8:
+            skipped.append((name, f"{tol:.1e}"))
             continue
+        checked += 1
         pls = P.pkg.PLS(gb, gc)
         assert relerr(pls.calculate_particle_update(cu(u), eta, noise=cu(e_noise)), want) < tol, name
         gdev = gc.calculate_cost_derivative(gb.calculate_untransformed_train_prediction_samples(cu(u)))
         assert relerr(gb.calculate_particle_update(cu(u), gdev, eta, noise=cu(e_noise)), want) < tol, name
         e_want = O.PLS(ob, oc).calculate_energy_potential(u.clone())
         assert abs(pls.calculate_energy_potential(cu(u)) - e_want) <= max(1e-10, tol) * abs(e_want), name
+    print(f"ipb step ({n},{m},{j},{d}) {factor} factor, cond {cond:.1e}: {checked} of 8 pairs held; skipped: {skipped}")
+    assert checked >= 6 and all(nm.startswith("poisson") for nm, _ in skipped), (checked, skipped)
 
 
 def test_ipb_philox_noise_is_coloured_by_kzz(P):
@@ -1475,36 +1508,349 @@ def test_conditional_variance_selector_full_size_properties(P):
 # ------------------------------------------------------------------------------------------------------------
 # 12. step-size search runner end to end on the device
 # ------------------------------------------------------------------------------------------------------------
-def test_train_pls_runner_end_to_end(P):
-    from projected_langevin_sampling_amd.runners import train_pls_runner
+def _search_problem(P, n=400, m=16, j=64, seed=81, basis="onb"):
+    pr = make_problem(n, m, j, 1, seed=seed)
+    if basis == "onb":
+        ob, gb = build_onb(P, pr, threshold=1e-4)
+    else:
+        pr["ls"] = pr["ls"] * 0.35
+        ob, gb = build_ipb(P, pr, factor="shared")
+    return pr, ob, gb
 
-    pr = make_problem(400, 16, 64, 1, seed=81)
-    ob, gb = build_onb(P, pr, threshold=1e-4)
+
+def _philox_noise_fn(rows, cols):
+    """The noise a stand-alone GPU run draws, restated on the host: per step one key from torch's global generator
+    (basis/base.py::_draw_noise_spec) feeding the counter-based stream (oracle/philox_ref.py)."""
+    def make():
+        def fn(t):
+            key = int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())
+            return torch.from_numpy(philox_ref.normal_matrix(rows, cols, key, 0))
+        return fn
+    return make
+
+
+@pytest.mark.parametrize("cost_idx,patience", [(0, 1.0), (0, 3e-4), (2, 1.0)])
+def test_batched_step_size_search_equals_the_sequential_oracle_search(P, cost_idx, patience):
+    """runners.train_pls_runner (all candidates as column blocks of one launch, per-block step size / noise column /
+    early stop) against oracle/runner_oracle.py (the reference's sequential search, one O.train_pls per candidate) at
+    configs[0]'s scale: same selected step size, same number of accepted energies, same particles, and the same energy
+    history for every candidate the sequential search got to."""
+    from oracle import runner_oracle
+    from projected_langevin_sampling_amd.runners import _CandidateRun, _SearchLedger, _run_blocks, candidate_step_sizes, train_pls_runner
+
+    pr, ob, gb = _search_problem(P)
+    name, oc, gc = make_costs(P, pr["y"], pr["fstar"], pr["gen"])[cost_idx]
+    mk = ob.approximation_dimension
+    u0 = pr["u"][:mk].contiguous()
+    kw = dict(simulation_duration=2e-3, maximum_number_of_steps=400, early_stopper_patience=patience, number_of_step_searches=5,
+              step_size_upper=2e-4, minimum_change_in_energy_potential=1e-9, seed=5)
+    want_u, want_lr, want_n, want_hist = runner_oracle.train_pls_runner(
+        O.PLS(ob, oc), u0.clone(), metric_to_optimise="loss", make_noise_fn=_philox_noise_fn(mk, 64), **kw)
+    pls = P.pkg.PLS(gb, gc)
+    u0_dev = cu(u0)
+    keep = u0_dev.clone()
+    got_u, got_lr, got_n = train_pls_runner(pls=pls, particle_name="t", x_train=pr["x"], y_train=pr["y"], particles=u0_dev,
+                                            metric_to_optimise="loss", **kw)
+    assert torch.equal(u0_dev, keep)  # the initial particles are cloned, never modified
+    assert got_lr == want_lr and got_n == want_n, (got_lr, want_lr, got_n, want_n)
+    assert relerr(got_u, want_u) < 1e-9
+    # every candidate's energy history, block by block
+    steps = candidate_step_sizes(kw["step_size_upper"], kw["simulation_duration"], kw["maximum_number_of_steps"], 5)
+    runs = [_CandidateRun(float(s), int(kw["simulation_duration"] / s)) for s in steps]
+    ledger = _SearchLedger(pls, "loss", pr["x"], pr["y"], -1.0, fallback_particles=u0_dev.clone())  # never closes early
+    _run_blocks(pls, u0_dev, runs, patience, kw["seed"], ledger)
+    assert all(r.finished for r in runs)
+    for r in runs:
+        if r.step_size in want_hist:
+            assert len(r.energies) == len(want_hist[r.step_size]), (r.step_size, len(r.energies), len(want_hist[r.step_size]))
+            assert np.allclose(r.energies, want_hist[r.step_size], rtol=1e-9, atol=0.0)
+    # reproducible: set_seed(seed) keys the whole search
+    again_u, again_lr, again_n = train_pls_runner(pls=pls, particle_name="t", x_train=pr["x"], y_train=pr["y"], particles=u0_dev,
+                                                  metric_to_optimise="loss", **kw)
+    assert again_lr == got_lr and again_n == got_n and torch.equal(again_u, got_u)
+
+
+def test_batched_search_blocks_equal_stand_alone_runs(P):
+    """A block of the batched launch IS a stand-alone run: per-block step size, Philox column restart and energy means
+    (pls_onb_step_blocks / pls_ipb_step_blocks / pls_block_means) against one fused_step per candidate -- for the
+    orthonormal basis (Gaussian fast path, generic two-GEMM path, small-rank path) and the inducing-point basis."""
+    for basis in ("onb", "ipb"):
+        pr, ob, gb = _search_problem(P, n=700, m=40, j=96, seed=33, basis=basis)
+        mk = gb.approximation_dimension
+        costs = make_costs(P, pr["y"], pr["fstar"], pr["gen"])
+        etas = [3e-4, 0.0, 1e-5]
+        for name, _, gc in (costs[0], costs[2]):
+            for force_generic in (False, True):
+                u = cu(torch.randn(mk, 96, generator=pr["gen"]))
+                ub = u.repeat(1, 3).contiguous()
+                eta_dev = cu(torch.tensor(etas))
+                e_b = torch.empty(3 * 96, dtype=torch.float64, device="cuda")
+                spec = P.basis.NoiseSpec(seed=77, step=4)
+                out_b = gb.fused_step(gc, ub, 0.0, new_state=True, noise=spec, input_energy=e_b, force_generic=force_generic,
+                                      blocks=P.basis.BlockSpec(96, eta_dev))
+                from projected_langevin_sampling_amd import _ops
+                means = _ops.block_means(e_b, block_cols=96).cpu()
+                for b, eta in enumerate(etas):
+                    e_1 = torch.empty(96, dtype=torch.float64, device="cuda")
+                    out_1 = gb.fused_step(gc, u, eta, new_state=True, noise=P.basis.NoiseSpec(seed=77, step=4), input_energy=e_1,
+                                          force_generic=force_generic)
+                    tag = f"{basis} {name} generic={force_generic} block {b}"
+                    assert relerr(out_b[:, 96 * b: 96 * (b + 1)], out_1) < 1e-12, tag
+                    assert relerr(e_b[96 * b: 96 * (b + 1)], e_1) < 1e-12, tag
+                    assert abs(means[b].item() - e_1.mean().item()) <= 1e-12 * abs(e_1.mean().item()), tag
+                assert torch.equal(out_b[:, 96:192], u), "a block with step size 0 is frozen exactly"
+
+
+def test_step_size_search_with_a_prediction_metric_and_a_user_defined_cost(P):
+    """metric_to_optimise = "mse" goes through pls.predict per accepted candidate; a user-defined Python cost has no fused
+    step, so its candidates train one at a time -- same rules, same return value."""
+    from projected_langevin_sampling_amd.runners import candidate_step_sizes, train_pls_runner
+
+    pr, ob, gb = _search_problem(P)
     gc = P.costs.GaussianCost(0.05, pr["y"], P.links.IdentityLinkFunction())
     pls = P.pkg.PLS(gb, gc)
     u0 = pls.initialise_particles(64, seed=0)
-    u0_copy = u0.clone()
     kw = dict(pls=pls, particle_name="t", x_train=pr["x"], y_train=pr["y"], simulation_duration=2e-3, maximum_number_of_steps=400,
               early_stopper_patience=1.0, number_of_step_searches=4, step_size_upper=2e-4,
               minimum_change_in_energy_potential=1e-9, seed=5, particles=u0)
+    steps = candidate_step_sizes(2e-4, 2e-3, 400, 4)
+    out_c, lr_c, n_c = train_pls_runner(metric_to_optimise="mse", **kw)
+    assert lr_c in steps and n_c == int(2e-3 / lr_c) and torch.isfinite(out_c).all()
+    out_d, lr_d, n_d = train_pls_runner(metric_to_optimise="mse", **kw)
+    assert lr_d == lr_c and torch.equal(out_c, out_d)
+    # sequential fall-back (explicit train_fn) agrees with the batched search on the "loss" metric
     out_a, lr_a, n_a = train_pls_runner(metric_to_optimise="loss", **kw)
-    out_b, lr_b, n_b = train_pls_runner(metric_to_optimise="loss", **kw)
-    steps = np.logspace(np.log10(2e-4), np.log10(2e-3 / 400), 4)
-    assert lr_a in steps and n_a == int(2e-3 / lr_a) and torch.isfinite(out_a).all()
-    assert torch.equal(u0, u0_copy)                       # the initial particles are cloned, never modified
-    assert lr_a == lr_b and torch.equal(out_a, out_b)     # set_seed(seed) before every candidate: the search is reproducible
-    out_c, lr_c, _ = train_pls_runner(metric_to_optimise="mse", **kw)
-    assert lr_c in steps and torch.isfinite(out_c).all()
-    # the chosen run really is the best by its metric among the candidates
-    from projected_langevin_sampling_amd.utils import set_seed
-    finals = []
-    for s in steps:
-        set_seed(5)
-        _, e = P.pkg.train_pls(pls, u0.clone(), int(2e-3 / s), s, 1.0)
-        finals.append(e[-1] if e else float("inf"))
-    assert lr_a == steps[int(np.argmin(finals))]
-    # the graph-replay training loop plugs in as train_fn (launch-bound problem sizes); reproducible for the same reason
-    out_d, lr_d, n_d = train_pls_runner(metric_to_optimise="loss", train_fn=P.pkg.train_pls_captured, **kw)
-    out_e, lr_e, n_e = train_pls_runner(metric_to_optimise="loss", train_fn=P.pkg.train_pls_captured, **kw)
-    assert lr_d in steps and n_d == int(2e-3 / lr_d) and torch.isfinite(out_d).all()
-    assert lr_d == lr_e and torch.equal(out_d, out_e)
+    out_b, lr_b, n_b = train_pls_runner(metric_to_optimise="loss", train_fn=P.pkg.train_pls, **kw)
+    assert lr_a == lr_b and n_a == n_b and relerr(out_a, out_b) < 1e-10
+    with pytest.raises(NotImplementedError):
+        train_pls_runner(metric_to_optimise="bogus", **kw)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# 12. device Cholesky + block substitution (pls_chol_factor / pls_chol_solve / pls_tri_multiply)
+# ------------------------------------------------------------------------------------------------------------
+def _spd(m, d, seed, scale=0.35):
+    g = torch.Generator().manual_seed(seed)
+    z = torch.rand(m, d, generator=g) * 2 - 1
+    ls = (0.5 + torch.rand(d, generator=g)) * scale
+    return O.RBFARDKernel(ls, 1.3)(z, z), g
+
+
+@pytest.mark.parametrize("m,d,j", [(1, 1, 3), (2, 1, 1), (63, 2, 5), (64, 2, 33), (65, 3, 64), (128, 3, 31), (129, 3, 100),
+                                   (200, 3, 257), (300, 4, 64), (640, 6, 96), (1024, 8, 512)])
+def test_device_cholesky_and_solves_against_lapack(P, m, d, j):
+    from projected_langevin_sampling_amd import _chol
+
+    k, g = _spd(m, d, 31 * m + d, scale=0.35 if m <= 300 else 0.8)
+    cond = torch.linalg.cond(k).item()
+    if cond > 1e9:
+        pytest.skip(f"test construction: cond = {cond:.1e}")
+    f = _chol.cholesky_factor(cu(k))
+    assert f.jitter == 0.0
+    lc, lct = f.Lc.cpu(), f.LcT.cpu()
+    assert torch.equal(lc, torch.tril(lc)) and torch.equal(lct, lc.T.contiguous())  # exact zeros above, exact transpose
+    assert relerr(lc @ lc.T, k) < 1e-14, "reconstruction"
+    l_ref = torch.linalg.cholesky(k)
+    assert relerr(lc, l_ref) < max(1e-13, cond * 2e-16)  # two factorisations differ by the conditioning of the problem
+    u = torch.randn(m, j, generator=g)
+    v = f.solve(cu(u))
+    v_ref = torch.cholesky_solve(u, l_ref)
+    assert relerr(k @ v.cpu(), u) < max(1e-12, cond * 1e-16), "residual"
+    assert relerr(v, v_ref) < max(TOL, cond * 1e-16), f"cond {cond:.1e}: {relerr(v, v_ref):.2e}"
+    # with LAPACK's factor uploaded, the substitution kernel alone reproduces LAPACK's solve
+    fs = _chol.factor_from_host(l_ref)
+    assert relerr(fs.solve(cu(u)), v_ref) < 1e-11
+    # e = L xi as a triangular product
+    assert relerr(f.colour(cu(u)), lc @ u) < 1e-13
+    # non-contiguous / padded right-hand sides
+    wide = cu(torch.randn(m, j + 5, generator=g))
+    assert relerr(f.solve(wide[:, 2: 2 + j]), torch.cholesky_solve(wide[:, 2: 2 + j].cpu(), l_ref)) < max(TOL, cond * 1e-16)
+
+
+def test_device_cholesky_jitter_schedule_and_failure(P):
+    """gpytorch's psd_safe_cholesky schedule: duplicated inducing points make k(Z,Z) exactly singular -- the bare
+    factorisation fails (LAPACK raises there), jitter 1e-8 rescues it with a warning; a matrix with a negative
+    eigenvalue far below the largest jitter raises NotPSDError; NaN raises."""
+    from projected_langevin_sampling_amd import _chol
+
+    k, g = _spd(50, 2, 5)
+    z = torch.rand(40, 2, generator=g)
+    z = torch.cat([z, z[:10]], dim=0)  # 10 duplicated points
+    ks = O.RBFARDKernel(torch.tensor([0.7, 0.9]), 1.0)(z, z)
+    with pytest.raises(torch.linalg.LinAlgError):
+        torch.linalg.cholesky(ks)
+    with pytest.warns(RuntimeWarning, match="added jitter of 1.0e-08"):
+        f = _chol.cholesky_factor(cu(ks))
+    assert f.jitter == 1e-8
+    lc = f.Lc.cpu()
+    assert relerr(lc @ lc.T, ks + 1e-8 * torch.eye(50)) < 1e-13
+    # the basis built on duplicated inducing points now constructs and steps (the round-1 constructor raised LinAlgError)
+    x = torch.rand(300, 2, generator=g)
+    y = torch.sin(3 * x[:, 0])
+    with pytest.warns(RuntimeWarning):
+        gb = P.basis.InducingPointBasis(P.pkg.PLSKernel(P.pkg.ARDKernel([0.7, 0.9], 1.0), z), z, y[:50], x)
+    gc = P.costs.GaussianCost(0.1, y, P.links.IdentityLinkFunction())
+    out = gb.fused_step(gc, cu(torch.randn(50, 8, generator=g)) * 1e-3, 1e-9, noise=P.basis.NoiseSpec(seed=1))
+    assert torch.isfinite(out).all()
+    bad = k - 0.5 * torch.eye(50)
+    with pytest.warns(RuntimeWarning), pytest.raises(_chol.NotPSDError, match="1.0e-06"):
+        _chol.cholesky_factor(cu(bad))
+    nanm = k.clone()
+    nanm[3, 3] = float("nan")
+    with pytest.raises(_chol.NotPSDError):
+        _chol.cholesky_factor(cu(nanm))
+
+
+def test_ipb_triangular_solves_against_the_explicit_inverse_ab(P):
+    """PLS_OPT_IPB_EXPLICIT_INVERSE: the round-1 W U contraction stays available as an A/B of the two triangular solves."""
+    pr = make_problem(600, 140, 80, 3, seed=12)
+    pr["ls"] = pr["ls"] * 0.5
+    yz = pr["y"][:140]
+    gk = P.pkg.ARDKernel(pr["ls"], 1.3)
+    gb = P.basis.InducingPointBasis(P.pkg.PLSKernel(gk, pr["z"]), pr["z"], yz, pr["x"], explicit_inverse=True)
+    cond = torch.linalg.cond(gb.base_gram_induce.cpu()).item()
+    gc = P.costs.BernoulliCost((pr["fstar"] > 0).double(), P.links.SigmoidLinkFunction())
+    u = cu(pr["u"])
+    ns = P.basis.NoiseSpec(seed=4, step=2)
+    lib, L = P.pkg._lib.load(), P.pkg._lib
+    solves = gb.fused_step(gc, u, 1e-3, noise=ns)
+    L.check(lib.pls_set_option(L.OPT_IPB_EXPLICIT_INVERSE, 1), "pls_set_option")
+    try:
+        inverse = gb.fused_step(gc, u, 1e-3, noise=ns)
+    finally:
+        L.check(lib.pls_set_option(L.OPT_IPB_EXPLICIT_INVERSE, 0), "pls_set_option")
+    assert not torch.equal(solves, inverse)
+    assert relerr(solves, inverse) < max(1e-9, cond * 1e-15)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# 13. regressions of the round-1 review
+# ------------------------------------------------------------------------------------------------------------
+def test_graph_replays_survive_an_interleaved_energy_evaluation(P):
+    """A captured graph owns its workspace: an eager call that makes the basis grow ITS scratch buffer between two replays
+    (the Gaussian step's workspace is cdiv(mk,64)*j doubles, the energy pass asks for cdiv(n,64)*j) must not disturb it."""
+    from projected_langevin_sampling_amd.graph import CapturedSteps, CapturedTraining
+
+    pr = make_problem(4096, 96, 256, 3, seed=8)
+    ob, gb = build_onb(P, pr)
+    mk = gb.approximation_dimension
+    costs = make_costs(P, pr["y"], pr["fstar"], pr["gen"])
+    for name, _, gc in (costs[0], costs[2]):
+        for force_generic in (False, True):
+            pls = P.pkg.PLS(gb, gc)
+            u0 = cu(torch.randn(mk, 256, generator=pr["gen"]))
+            gb._ws.clear()
+            cap = CapturedSteps(pls, u0.clone(), 1e-4, steps_per_replay=3, seed=9, force_generic=force_generic)
+            ref = CapturedSteps(pls, u0.clone(), 1e-4, steps_per_replay=3, seed=9, force_generic=force_generic)
+            ref.replay(3)
+            cap.replay(1)
+            gb._ws.clear()  # the basis drops / regrows its own scratch ...
+            pls.calculate_energy_potential(cap.particles)  # ... for an energy pass of a different size
+            junk = torch.full((1 << 22,), float("nan"), dtype=torch.float64, device="cuda")  # whoever gets the freed block
+            cap.replay(2)
+            del junk
+            assert torch.equal(cap.particles, ref.particles), f"{name} generic={force_generic}"
+    pls = P.pkg.PLS(gb, costs[2][2])
+    u0 = cu(torch.randn(mk, 256, generator=pr["gen"]))
+    a = CapturedTraining(pls, u0.clone(), 1e-4, 4, seed=3)
+    b = CapturedTraining(pls, u0.clone(), 1e-4, 4, seed=3)
+    ea = [a.replay().clone()]
+    gb._ws.clear()
+    pls.calculate_energy_potential(a.particles)
+    ea.append(a.replay().clone())
+    eb = [b.replay().clone(), b.replay().clone()]
+    assert torch.equal(a.particles, b.particles) and all(torch.equal(x, y) for x, y in zip(ea, eb))
+
+
+def test_checkpoint_round_trip_resumes_a_sharded_run_exactly(P, tmp_path):
+    """experiments/uci/regression/main.py:300-308 / loaders.py:10-28 on the device: a 2-shard run saved after 5 steps
+    (particles, observation noise, noise_step, number_of_particles) and resumed for 5 more equals 10 uninterrupted steps,
+    shard by shard and against the unsharded run; the file loads as the reference's plain dictionary."""
+    from projected_langevin_sampling_amd import checkpoint
+
+    pr = make_problem(900, 30, 64, 2, seed=19)
+    ob, gb = build_onb(P, pr)
+    mk = gb.approximation_dimension
+    gc = P.costs.StudentTCost(3.0, pr["y"], P.links.IdentityLinkFunction(), 0.7)
+    pls = P.pkg.PLS(gb, gc)
+    j, eta, seed = 64, 1e-4, 1234
+    u0 = torch.randn(mk, j, generator=pr["gen"])
+
+    def run(u, j0, first, count):
+        cur, nxt = u.clone(), torch.empty_like(u)
+        for t in range(first, first + count):
+            gb.fused_step(gc, cur, eta, out=nxt, new_state=True, noise=P.basis.NoiseSpec(seed=seed, step=t, j_offset=j0))
+            cur, nxt = nxt, cur
+        return cur
+
+    whole = run(cu(u0), 0, 0, 10)
+    for rank in range(2):
+        j0, j1 = P.dist.shard_bounds(j, rank, 2)
+        shard = cu(u0[:, j0:j1].contiguous())
+        mid = run(shard, j0, 0, 5)
+        path = str(tmp_path / f"pls-rank{rank}.pth")
+        checkpoint.save_pls(pls, mid, path, best_lr=eta, number_of_epochs=5, noise_step=5, number_of_particles=j)
+        raw = torch.load(path, map_location="cpu")
+        assert set(raw) >= {"particles", "observation_noise", "best_lr", "number_of_epochs"}  # the reference's keys
+        assert raw["particles"].device.type == "cpu" and raw["noise_step"] == 5 and raw["number_of_particles"] == j
+        pls2 = P.pkg.PLS(gb, P.costs.StudentTCost(3.0, pr["y"], P.links.IdentityLinkFunction(), 0.7))
+        pls2, restored, lr, epochs = checkpoint.load_pls(pls2, path)
+        assert restored.is_cuda and restored.dtype == torch.float64 and torch.equal(restored, mid)
+        assert (lr, epochs) == (eta, 5) and pls2.observation_noise == pls.observation_noise
+        resumed = run(restored, j0, raw["noise_step"], 5)
+        assert torch.equal(resumed, run(shard, j0, 0, 10)), "resume != uninterrupted shard"
+        assert relerr(resumed, whole[:, j0:j1]) < 1e-13, "shard != unsharded run"
+
+
+def test_user_defined_basis_with_the_reference_signature(P):
+    """A PLSBasis subclass written against the reference's abstract interface -- _calculate_particle_update(particles,
+    cost_derivative, step_size), no ``noise`` keyword, no particle_energy_potential -- composes with a native cost."""
+    pr = make_problem(200, 8, 16, 2, seed=2)
+    ob, inner = build_onb(P, pr)
+    mk = inner.approximation_dimension
+
+    class ReferenceStyleBasis(P.basis.PLSBasis):
+        @property
+        def approximation_dimension(self):
+            return mk
+
+        def _initialise_particles(self, number_of_particles, noise_only=True, seed=None):
+            return self._initialise_particles_noise(number_of_particles, seed=seed)
+
+        def calculate_untransformed_train_prediction_samples(self, particles):
+            return inner.calculate_untransformed_train_prediction_samples(particles)
+
+        def calculate_energy_potential(self, particles, cost):
+            return inner.calculate_energy_potential(particles, cost)
+
+        def _calculate_particle_update(self, particles, cost_derivative, step_size):  # the reference's signature
+            return -step_size * P.pkg._ops.gemm_tn(inner._At, cost_derivative) if hasattr(P.pkg, "_ops") else None
+
+        def sample_predictive_noise(self, particles, x):
+            raise NotImplementedError
+
+        def predict_untransformed_samples(self, particles, x, noise=None):
+            raise NotImplementedError
+
+    from projected_langevin_sampling_amd import _ops
+
+    P.pkg._ops = _ops
+    gc = P.costs.GaussianCost(0.3, pr["y"], P.links.IdentityLinkFunction())
+    pls = P.pkg.PLS(ReferenceStyleBasis(), gc)
+    u = cu(pr["u"][:mk].contiguous())
+    du = pls.calculate_particle_update(u, 1e-3)  # round 1: TypeError: unexpected keyword 'noise'
+    g = gc.calculate_cost_derivative(inner.calculate_untransformed_train_prediction_samples(u))
+    assert relerr(du, -1e-3 * (inner._A @ g)) < 1e-12
+    assert abs(pls.calculate_energy_potential(u) - P.pkg.PLS(inner, gc).calculate_energy_potential(u)) < 1e-9 * 1e3
+
+
+def test_quantiles_beyond_one_lds_sort(P):
+    """More than 16 384 samples per row (a large calibration split, or the gathered samples of a J-sharded run): the
+    quantile falls back to the device sort instead of raising PLS_ERR_UNSUPPORTED (advisor finding, round 1)."""
+    from projected_langevin_sampling_amd import _ops
+
+    g = torch.Generator().manual_seed(0)
+    s = torch.randn(2, 20000, generator=g)
+    got = _ops.row_quantiles(cu(s), [0.05, 0.5, 0.95])
+    assert relerr(got, torch.quantile(s, torch.tensor([0.05, 0.5, 0.95]), dim=1).T) < 1e-14
+    assert _ops.row_quantiles(cu(s[:, :16384].contiguous()), [0.5]).shape == (2, 1)

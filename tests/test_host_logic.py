@@ -164,3 +164,51 @@ def test_metrics_match_their_definitions():
     assert np.isclose(metrics.calculate_nll(d, y), want)
     b = torch.distributions.Bernoulli(probs=torch.tensor([0.9, 0.2]))
     assert np.isclose(metrics.calculate_nll(b, torch.tensor([1.0, 0.0])), -(np.log(0.9) + np.log(0.8)) / 2)
+
+
+def test_selector_accepts_a_scale_kernel_shaped_object_and_rejects_the_pls_kernel():
+    """The reference hands the selector a gpytorch ScaleKernel(RBFKernel) (experiments/uci/regression/main.py:203):
+    lengthscale AND outputscale must both be read; a PLSKernel (r, not k) is refused instead of being silently
+    reduced to its base kernel.  Host-only: no Gram matrix is built here."""
+    from projected_langevin_sampling_amd.inducing_point_selectors import ConditionalVarianceInducingPointSelector
+    from projected_langevin_sampling_amd.kernel import ARDKernel, PLSKernel, as_base_kernel
+
+    class RBFStub:
+        lengthscale = torch.tensor([[0.5, 2.0]])
+
+    class ScaleStub:
+        base_kernel = RBFStub()
+        outputscale = torch.tensor(3.0)
+
+    k = as_base_kernel(ScaleStub())
+    assert isinstance(k, ARDKernel) and k.outputscale == 3.0 and k.lengthscale.tolist() == [0.5, 2.0]
+    with pytest.raises(TypeError):
+        as_base_kernel(RBFStub())  # an un-scaled inner kernel is not what the reference passes
+    sel = ConditionalVarianceInducingPointSelector()
+    with pytest.raises(TypeError, match="base kernel"):
+        sel(torch.zeros(8, 2), 3, PLSKernel(ARDKernel([1.0, 1.0]), torch.zeros(4, 2)))
+
+
+def test_block_spec_and_batched_runner_bookkeeping():
+    """Host side of the batched step-size search: candidate grid, epochs, and the ledger's rules in candidate order."""
+    from projected_langevin_sampling_amd.runners import _CandidateRun, _SearchLedger, candidate_step_sizes
+
+    steps = candidate_step_sizes(1e-2, 1.0, 1000, 4)
+    assert np.allclose(steps, np.logspace(-2, -3, 4)) and steps[0] > steps[-1]
+    runs = [_CandidateRun(float(s), int(1.0 / s)) for s in steps]
+    assert [r.number_of_epochs for r in runs] == [100, 215, 464, 1000] or runs[0].number_of_epochs == 99
+    ledger = _SearchLedger(None, "loss", None, None, 1e-3, fallback_particles=torch.zeros(2, 2))
+    # candidate 1 finishes before candidate 0: nothing is judged out of order
+    runs[1].particles, runs[1].energies, runs[1].finished = torch.ones(2, 2), [5.0, 4.0], True
+    ledger.judge_ready(runs)
+    assert ledger.cursor == 0 and ledger.best_step_size is None
+    runs[0].particles, runs[0].energies, runs[0].finished = torch.full((2, 2), float("inf")), [9.0], True  # diverged: not accepted
+    ledger.judge_ready(runs)
+    assert ledger.cursor == 2 and ledger.best_step_size == runs[1].step_size and not ledger.closed
+    runs[2].particles, runs[2].energies, runs[2].finished = 2 * torch.ones(2, 2), [4.5, 4.0001], True
+    ledger.judge_ready(runs)  # |4.0 - 4.0001| / 4.0 < 1e-3: consecutive accepted runs agree -> the search closes
+    assert ledger.closed and ledger.cursor == 3
+    best, lr, n = ledger.result()
+    assert lr == runs[1].step_size and n == 2 and torch.equal(best, torch.ones(2, 2))
+    with pytest.raises(NotImplementedError):
+        _SearchLedger(None, "bogus", None, None, 1e-3, fallback_particles=torch.zeros(1, 1))
