@@ -339,7 +339,7 @@ int pls_onb_particle_update(const pls_onb_desc *basis, const double *U, int64_t 
  * `particles += update`, trainers.py:157, fused).  out must not alias U: other workgroups still read U as
  * the GEMM operand, so callers ping-pong two particle buffers.
  * energy_in (may be NULL): receives e_j(U) of the INPUT particles -- the value pls_onb_energy returns -- as a
- * by-product: on the fast path from the same B U product (it then needs cdiv(mk, 64) * j workspace doubles), otherwise
+ * by-product: on the fast path from the same B U product (it then needs 2 * cdiv(mk, 128) * j workspace doubles), otherwise
  * from the same F tile the cost derivative is taken of, so a train loop (trainers.py:153-159, which recomputes F for the
  * energy) pays no separate energy pass.
  * workspace: pls_onb_step_workspace_bytes(...) bytes (any larger size lets it use bigger N chunks). */

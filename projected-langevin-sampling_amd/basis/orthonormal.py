@@ -215,7 +215,7 @@ class OrthonormalBasis(PLSBasis):
         """Bytes fused_step asks of its workspace for ``j`` columns (graph captures allocate their own buffer)."""
         cd = cost.desc()
         if cd.cost == L.COST_GAUSSIAN and cd.link == L.LINK_IDENTITY and not force_generic:
-            return ((self.approximation_dimension + 63) // 64) * j * 8 if with_energy else 0
+            return 2 * ((self.approximation_dimension + 127) // 128) * j * 8 if with_energy else 0
         lib = L.load()
         desc = self._desc()
         need_min = lib.pls_onb_step_workspace_bytes(desc, j, 128)
@@ -247,7 +247,7 @@ class OrthonormalBasis(PLSBasis):
         if gaussian:
             ws, ws_bytes = None, 0
             if input_energy is not None:
-                ws_bytes = ((self.approximation_dimension + 63) // 64) * j * 8
+                ws_bytes = 2 * ((self.approximation_dimension + 127) // 128) * j * 8  # one partial row per 64 data rows
                 ws = self._pick_workspace(workspace, ws_bytes, u.device)
         else:
             wkey = (j, self.workspace_bytes)

@@ -91,7 +91,9 @@ struct EpiGaussDeriv {
     }
   }
   template <int TI, int TJ>
-  __device__ void apply_direct(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int) const {
+  static constexpr bool direct_tile() { return true; }
+  template <int TI, int TJ>
+  __device__ void apply_direct(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int, double *) const {
 #if defined(__HIP_DEVICE_COMPILE__)
     // y of the 16 row groups this lane's registers belong to: rows iw + 4 s + (lane >> 4), s = 0..4 TI - 1
     const __amdgpu_buffer_rsrc_t ys =

@@ -11,6 +11,19 @@
 
 namespace plship {
 
+// a * b + k for a compile-time constant k.  Written as v_fma_f64 with the constant in a SCALAR register pair: the
+// compiler's own choice for a Horner step is v_mov_b64 (copy the constant) + v_fmac_f64 (two-address form), i.e. two
+// vector instructions per coefficient, and every vector instruction of these kernels costs matrix-pipe issue slots.
+__device__ __forceinline__ double fma_k(double a, double b, double k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(k));
+  return d;
+#else
+  return fma(a, b, k);
+#endif
+}
+
 // exp(x): n = rint(x log2 e), r = x - n ln 2 (two-piece ln 2), degree-13 Taylor polynomial in Horner form
 // (|r| <= 0.347: truncation 4e-18 relative), scaled by 2^n with v_ldexp (gradual underflow as libm).
 __device__ __forceinline__ double fast_exp(double x) {
@@ -18,16 +31,16 @@ __device__ __forceinline__ double fast_exp(double x) {
   double r = fma(n, -6.93147180369123816490e-01, x);
   r = fma(n, -1.90821492927058770002e-10, r);
   double p = 1.6059043836821613e-10;  // 1/13!
-  p = fma(p, r, 2.0876756987868098e-09);
-  p = fma(p, r, 2.5052108385441720e-08);
-  p = fma(p, r, 2.7557319223985893e-07);
-  p = fma(p, r, 2.7557319223985888e-06);
-  p = fma(p, r, 2.4801587301587302e-05);
-  p = fma(p, r, 1.9841269841269841e-04);
-  p = fma(p, r, 1.3888888888888889e-03);
-  p = fma(p, r, 8.3333333333333332e-03);
-  p = fma(p, r, 4.1666666666666664e-02);
-  p = fma(p, r, 1.6666666666666666e-01);
+  p = fma_k(p, r, 2.0876756987868098e-09);
+  p = fma_k(p, r, 2.5052108385441720e-08);
+  p = fma_k(p, r, 2.7557319223985893e-07);
+  p = fma_k(p, r, 2.7557319223985888e-06);
+  p = fma_k(p, r, 2.4801587301587302e-05);
+  p = fma_k(p, r, 1.9841269841269841e-04);
+  p = fma_k(p, r, 1.3888888888888889e-03);
+  p = fma_k(p, r, 8.3333333333333332e-03);
+  p = fma_k(p, r, 4.1666666666666664e-02);
+  p = fma_k(p, r, 1.6666666666666666e-01);
   p = fma(p, r, 0.5);
   p = fma(p, r, 1.0);
   p = fma(p, r, 1.0);
@@ -59,10 +72,10 @@ __device__ __forceinline__ double fast_log(double x) {
   const double dk = (double)k;
   const double s = fast_div_normal(f, 2.0 + f);
   const double z = s * s, w = z * z;
-  const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+  const double t1 = w * fma_k(w, fma_k(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
   const double t2 =
-      z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01),
-              6.666666666666735130e-01);
+      z * fma_k(w, fma_k(w, fma_k(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01),
+                6.666666666666735130e-01);
   const double R = t2 + t1;
   const double hfsq = 0.5 * f * f;
   double v = dk * 6.93147180369123816490e-01 - ((hfsq - fma(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f);

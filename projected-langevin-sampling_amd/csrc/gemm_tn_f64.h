@@ -416,12 +416,14 @@ __global__ __launch_bounds__((BI / WI) * (BJ / WJ) * 64, MINW) void gemm_tn_f64_
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wi = (wave / (BJ / WJ)) * WI, wj = (wave % (BJ / WJ)) * WJ;
   if constexpr (Epilogue::kDirect) {
-    // interior tile: registers -> global without the LDS transpose (see epilogue_direct)
-    if (!edge && epi.direct_ld() < kDirectMaxLd) {
-      const int wu = __builtin_amdgcn_readfirstlane(wave);
-      epi.template apply_direct<TI, TJ>(acc, i0 + (wu / (BJ / WJ)) * WI, j0 + (wu % (BJ / WJ)) * WJ, lane, split);
-      PLS_STAMP_AT(3);
-      return;
+    if constexpr (Epilogue::template direct_tile<TI, TJ>()) {
+      // interior tile: registers -> global without the LDS transpose (see epilogue_direct)
+      if (!edge && epi.direct_ld() < kDirectMaxLd) {
+        const int wu = __builtin_amdgcn_readfirstlane(wave);
+        epi.template apply_direct<TI, TJ>(acc, i0 + (wu / (BJ / WJ)) * WI, j0 + (wu % (BJ / WJ)) * WJ, lane, split, lds + wu * 128);
+        PLS_STAMP_AT(3);
+        return;
+      }
     }
   }
   epi.template apply<TI, TJ>(acc, i0 + wi, j0 + wj, lane, wave, g.I, g.J, tile_i, split, lds);
@@ -587,7 +589,9 @@ struct EpiStore {  // C = alpha * acc + beta * C   (split-K: slab `split` of C, 
   int64_t slab;
   __device__ int64_t direct_ld() const { return ldc; }
   template <int TI, int TJ>
-  __device__ void apply_direct(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int split) const {
+  static constexpr bool direct_tile() { return true; }
+  template <int TI, int TJ>
+  __device__ void apply_direct(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int split, double *) const {
 #if defined(__HIP_DEVICE_COMPILE__)
     double *corner = C0 + (int64_t)split * slab + iw * ldc + jw;
     if (beta == 0.0 && alpha == 1.0) {  // (the usual case: no VALU instruction at all)

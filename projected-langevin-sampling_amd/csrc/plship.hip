@@ -137,7 +137,115 @@ static NoiseP make_noisep(const pls_noise_desc *n, const pls_block_desc *blocks 
 // Gaussian/identity fast path: acc = (B U)_ij;  out = [U +] -eta*(acc - c_i)/sigma2 - eta*U_ij/lam_i + sqrt(2 eta)*xi_ij
 struct EpiLangevinGaussian {
   static constexpr int kTag = PLS_TAG_GEMM_LANGEVIN_GAUSSIAN;
-  static constexpr bool kDirect = false;
+  static constexpr bool kDirect = true;
+  __device__ int64_t direct_ld() const { return ldo > ldu ? ldo : ldu; }
+  template <int TI, int TJ>
+  static constexpr bool direct_tile() { return TI == 4 && TJ == 4; }  // the 128 x 128 configuration (64 x 64 per wave)
+
+  // Interior tiles of the big configuration: the whole Langevin update in the MFMA register layout, no LDS transpose.
+  // Register r of block (ta, tb) is row iw + 16 ta + 4 r + (lane >> 4), column jw + 16 tb + (lane & 15):
+  //   * registers r = 0, 1 (rows q, q + 4) and r = 2, 3 (rows q + 8, q + 12) are the two Philox pairs of a lane;
+  //   * U is read and `out` written with one buffer instruction per register (four 128-byte row segments), addressed by
+  //     a descriptor at the wave's corner, one lane-offset VGPR and a scalar row / column offset: no address VALU;
+  //   * a lane owns FOUR columns (tb): their step sizes and Philox columns are hoisted out of the slab loop;
+  //   * c_i and 1 / lambda_i of the wave's 64 rows go through a 1 KiB wave-private LDS table (lane l computes row
+  //     iw + l once, with the same IEEE division as the LDS path), read back per (ta, r) by one ds_read_b64;
+  //   * the slab loop is a run-time loop (the accumulators of slab ta are copied out by a wave-uniform switch), so the
+  //     eight inlined Philox / Box-Muller bodies exist once, not four times.
+  template <int TI, int TJ>
+  __device__ void apply_direct(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int, double *wlds) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int q = lane >> 4, c16 = lane & 15;
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out + iw * ldo + jw, 0, 0x7FFFFFF0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ru =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(U + iw * ldu + jw), 0, 0x7FFFFFF0, 0x00020000);
+    const int voff_o = (int)(((int64_t)q * ldo + c16) * 8), voff_u = (int)(((int64_t)q * ldu + c16) * 8);
+    const int ldo4 = (int)(ldo * 32), ldu4 = (int)(ldu * 32);  // bytes per 4 rows
+    // per-row constants of the wave's 64 rows -> wave-private LDS
+    wlds[lane] = c[iw + lane];
+    wlds[64 + lane] = 1.0 / lam[iw + lane];
+    // per-column constants of this lane's TJ columns
+    double a2[TJ], s2[TJ], es[TJ];
+    uint32_t jg[TJ];
+    const uint64_t nstep = nz.live_step();
+#pragma unroll
+    for (int tb = 0; tb < TJ; ++tb) {
+      const int64_t jl = jw + tb * 16 + c16;
+      const double eta = etap.at(jl);
+      a2[tb] = -eta;
+      s2[tb] = sqrt(2.0 * eta);
+      jg[tb] = (uint32_t)nz.global_column(jl);
+      es[tb] = 0.0;
+    }
+    const double pscale = 0.5 * inv_noise;
+    __builtin_amdgcn_wave_barrier();
+    // run-time loop over the 2 TI row pairs of the wave block (slot = 2 ta + rp: rows 8 slot + q and + 4); the pair's
+    // 2 TJ accumulators are copied out by a wave-uniform switch, so the TJ inlined noise bodies exist once
+#pragma unroll 1
+    for (int slot = 0; slot < 2 * TI; ++slot) {
+      double v[2][TJ];
+#define PLS_PAIR_CASE(S)                                            \
+  case S:                                                           \
+    _Pragma("unroll") for (int tb = 0; tb < TJ; ++tb) {             \
+      v[0][tb] = acc.v[((S) / 2) % TI][tb][2 * ((S) % 2)];          \
+      v[1][tb] = acc.v[((S) / 2) % TI][tb][2 * ((S) % 2) + 1];      \
+    }                                                               \
+    break;
+      switch (slot) {
+        PLS_PAIR_CASE(0)
+        PLS_PAIR_CASE(1)
+        PLS_PAIR_CASE(2)
+        PLS_PAIR_CASE(3)
+        PLS_PAIR_CASE(4)
+        PLS_PAIR_CASE(5)
+        PLS_PAIR_CASE(6)
+        default:
+          PLS_PAIR_CASE(7)
+      }
+#undef PLS_PAIR_CASE
+      const int so_u = slot * 2 * ldu4, so_o = slot * 2 * ldo4;  // scalar byte offsets of row 8 slot (4 rows = ld4 bytes)
+      double ur[2][TJ];
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int tb = 0; tb < TJ; ++tb)
+          ur[h][tb] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(ru, voff_u, so_u + h * ldu4 + tb * 128, 0));
+      const double cr0 = wlds[slot * 8 + q], cr1 = wlds[slot * 8 + 4 + q];
+      const double il0 = wlds[64 + slot * 8 + q], il1 = wlds[64 + slot * 8 + 4 + q];
+      const int64_t irow = iw + slot * 8 + q;  // bit 2 clear: the pair is rows irow, irow + 4
+#pragma unroll
+      for (int tb = 0; tb < TJ; ++tb) {
+        double z[2] = {0.0, 0.0};
+        if (nz.kind == PLS_NOISE_PHILOX) {
+          normal_pair(nz.seed, nstep, irow, (int64_t)jg[tb], z[0], z[1]);
+        } else if (nz.kind == PLS_NOISE_INJECTED) {
+          const int64_t jl = jw + tb * 16 + c16;
+          z[0] = nz.xi[irow * nz.ldxi + jl];
+          z[1] = nz.xi[(irow + 4) * nz.ldxi + jl];
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const double vv = v[h][tb], u = ur[h][tb], cr = h ? cr1 : cr0, il = h ? il1 : il0;
+          const double d = fma(a2[tb], fma(inv_noise, vv - cr, u * il), s2[tb] * z[h]);
+          const double o = add_u ? u + d : d;
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, o), ro, voff_o, so_o + h * ldo4 + tb * 128, 0);
+          if (epart) es[tb] += pscale * u * (vv - 2.0 * cr) + 0.5 * u * u * il;
+        }
+      }
+    }
+    if (epart) {  // per wave row (64 data rows): the four lane groups hold different rows of the same column
+#pragma unroll
+      for (int tb = 0; tb < TJ; ++tb) {
+        double t = es[tb];
+        t += __shfl_xor(t, 16);
+        t += __shfl_xor(t, 32);
+        if (lane < 16) epart[(iw >> 6) * ldp + jw + tb * 16 + lane] = t;
+      }
+    }
+#else
+    (void)acc, (void)iw, (void)jw, (void)lane, (void)wlds;
+#endif
+  }
   double *out;
   int64_t ldo;
   const double *U;
@@ -204,7 +312,14 @@ struct EpiLangevinGaussian {
         double tot = 0.0;
         for (int w = 0; w < nwi; ++w) tot += red[w * bj + t];
         const int64_t j = (jw - wcol * WJ) + t;
-        if (j < J) epart[(int64_t)tile_i * ldp + j] = tot;
+        if (j < J) {
+          if (bj == 128) {  // big configuration: partial rows are per 64 data rows (the direct path writes one per wave row)
+            epart[(int64_t)(2 * tile_i) * ldp + j] = tot;
+            epart[(int64_t)(2 * tile_i + 1) * ldp + j] = 0.0;
+          } else {
+            epart[(int64_t)tile_i * ldp + j] = tot;
+          }
+        }
       }
     }
   }
@@ -1350,7 +1465,7 @@ static int onb_step_impl(const pls_onb_desc *basis, const pls_cost_desc *cost, c
     const bool big = use_big_tiles(basis->mk, j);
     double *epart = nullptr;
     if (energy_in) {
-      const int64_t parts = big ? cdiv(basis->mk, 128) : cdiv(basis->mk, 64);
+      const int64_t parts = big ? 2 * cdiv(basis->mk, 128) : cdiv(basis->mk, 64);
       if (!workspace || workspace_bytes < (size_t)parts * j * sizeof(double))
         return fail(PLS_ERR_WORKSPACE_TOO_SMALL, "onb_step: energy by-product needs %zu workspace bytes",
                     (size_t)parts * j * sizeof(double));
@@ -1360,7 +1475,7 @@ static int onb_step_impl(const pls_onb_desc *basis, const pls_cost_desc *cost, c
                           epart, j, 2, big ? 128 : 64};
     rc = launch_gemm(basis->B, basis->ldb, U, ldu, basis->mk, j, basis->mk, e, st);
     if (rc || !energy_in) return rc;
-    const int64_t parts = big ? cdiv(basis->mk, 128) : cdiv(basis->mk, 64);
+    const int64_t parts = big ? 2 * cdiv(basis->mk, 128) : cdiv(basis->mk, 64);
     hipLaunchKernelGGL(gaussian_energy_finish_kernel, dim3((unsigned)cdiv(j, 256)), dim3(256), 0, st, epart, j, parts, j,
                        energy_in, 0.5 / cost->p[0], basis->c + basis->mk);
     return check_launch("gaussian_energy_finish");

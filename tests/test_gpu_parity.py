@@ -876,12 +876,13 @@ def test_random_shape_sweep_against_the_oracle(P, rank_path):
 
 
 @pytest.mark.parametrize("factor", ["device", "shared"])
-@pytest.mark.parametrize("n,m,j,d", [(512, 24, 64, 3), (100, 10, 7, 1), (700, 33, 130, 2), (900, 150, 70, 3)])
-def test_ipb_step_all_costs(P, rank_path, n, m, j, d, factor):
+@pytest.mark.parametrize("n,m,j,d,ls_scale", [(512, 24, 64, 3, 0.35), (100, 10, 7, 1, 0.35), (700, 33, 130, 2, 0.35),
+                                              (900, 150, 70, 3, 0.35), (600, 60, 50, 2, 0.8), (600, 60, 50, 2, 0.95)])
+def test_ipb_step_all_costs(P, rank_path, n, m, j, d, ls_scale, factor):
     """factor = "device": k(Z,Z) factorised by pls_chol_factor, the oracle by LAPACK -- TOL without any conditioning
     allowance for the solves, for cond(k(Z,Z)) <= 1e8; "shared": both sides use the oracle's factor."""
     pr = make_problem(n, m, j, d, seed=7 * n + m)
-    pr["ls"] = pr["ls"] * 0.35
+    pr["ls"] = pr["ls"] * ls_scale  # cond(k(Z,Z)) from 1e1 (0.35) to ~5e7 (0.95)
     ob, gb = build_ipb(P, pr, factor=factor)
     cond = torch.linalg.cond(ob.base_gram_induce).item()
     assert cond <= 1e8, f"test construction: cond(k(Z,Z)) = {cond:.1e}"
