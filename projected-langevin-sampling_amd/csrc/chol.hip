@@ -22,6 +22,8 @@
 // inter-workgroup traffic): its own earlier block rows of V are the R operand of the later ones.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "../../include/plship.h"
 #include "chol.h"
 #include "common.h"
@@ -179,116 +181,170 @@ struct StripArgs {
   int64_t m, j;
 };
 
+template <bool VEC>
 __device__ __forceinline__ void strip_block_row(const double *__restrict__ S, int64_t lds_, const double *Rlo, int64_t ldlo,
                                                 const double *Rhi, int64_t ldhi, int64_t ksw, int64_t kbeg, int64_t kend,
                                                 int64_t i0, int64_t j0, int64_t m, int64_t j, double *lds,
-                                                double4v (&acc)[2][2]) {
+                                                double4v (&acc)[2]) {
+  // 8 waves: wave w owns rows [16 w, 16 w + 16) x the strip's 32 columns (one A fragment, two B fragments, two MFMAs per
+  // k-quad); two waves per SIMD, so one wave's LDS / memory waits sit under the other's MFMAs.
   constexpr int SL = TS_NB + 16, SR = TS_SC + 16;
   double *Ss = lds;                     // [2][BK][SL]
   double *Rs = lds + 2 * TS_BK * SL;    // [2][BK][SR]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = lane >> 4, c16 = lane & 15;
-  const int wi = wave * 32;
-  // loads: S tile 16 x 128 -> thread (row = tid / 16, 8 doubles from column (tid % 16) * 8); R tile 16 x 32 -> 2 doubles
-  const int lrow = tid >> 4, lcs = (tid & 15) * 8, lcr = (tid & 15) * 2;
-  double2v sreg[4], rreg;
+  const int wi = wave * 16;
+  // loads: S tile 16 x 128 -> thread (row = tid / 32, 4 doubles from column (tid % 32) * 4); R tile 16 x 32 -> threads < 256,
+  // (row = tid / 16, 2 doubles from column (tid % 16) * 2)
+  const int lrow = tid >> 5, lcs = (tid & 31) * 4;
+  const int rrow = (tid >> 4) & 15, lcr = (tid & 15) * 2;
+  const bool rload = tid < 256;
+  double2v sreg[2], rreg;
+  acc[0] = double4v{0.0, 0.0, 0.0, 0.0};
+  acc[1] = double4v{0.0, 0.0, 0.0, 0.0};
+  // Loop-invariant addressing: a column past the matrix edge is CLAMPED, not zeroed -- column i of S only ever reaches
+  // output row i, column j of R output column j, and the store drops rows >= m and columns >= j.  Only the rows of a
+  // K tail (k >= kend: they do not exist) must read as zero, and only the last k-step of the last block row has one.
+  // VEC (wave-uniform, chosen per block row by the caller): full block, full strip, 16-byte aligned operands -> one
+  // 16-byte load per pair.  The loads sit in straight-line code: a divergent branch around them makes the compiler wait
+  // for them at the join, i.e. BEFORE the MFMAs they are meant to fly under.
+  const int64_t ci0 = i0 + lcs, cj0 = j0 + lcr;
+  int64_t cs[4], cr[2];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int e = 0; e < 4; ++e) cs[e] = (ci0 + e < m) ? ci0 + e : 0;
 #pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] = double4v{0.0, 0.0, 0.0, 0.0};
-  auto load_tiles = [&](int64_t k0) {
-    const int64_t k = k0 + lrow;
-    const bool kin = k < kend;
-    const int64_t kk = kin ? k : kbeg;  // any valid row: its values are zeroed below
-    const double *sp = S + kk * lds_;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int64_t ci = i0 + lcs + 2 * p;
-      double2v v;
-      v.x = (ci < m) ? sp[ci] : 0.0;
-      v.y = (ci + 1 < m) ? sp[ci + 1] : 0.0;
-      sreg[p].x = kin ? v.x : 0.0;
-      sreg[p].y = kin ? v.y : 0.0;
+  for (int e = 0; e < 2; ++e) cr[e] = (cj0 + e < j) ? cj0 + e : 0;
+  auto load_tiles = [&](int64_t k0, auto tail_tag) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
+    {
+      const int64_t k = k0 + lrow;
+      const bool kin = !TAIL || k < kend;
+      const double *sp = S + (kin ? k : kbeg) * lds_;
+      if constexpr (VEC) {
+        sreg[0] = *reinterpret_cast<const double2v *>(sp + ci0);
+        sreg[1] = *reinterpret_cast<const double2v *>(sp + ci0 + 2);
+      } else {
+        sreg[0].x = sp[cs[0]];
+        sreg[0].y = sp[cs[1]];
+        sreg[1].x = sp[cs[2]];
+        sreg[1].y = sp[cs[3]];
+      }
+      if (TAIL) {
+        sreg[0].x = kin ? sreg[0].x : 0.0;
+        sreg[0].y = kin ? sreg[0].y : 0.0;
+        sreg[1].x = kin ? sreg[1].x : 0.0;
+        sreg[1].y = kin ? sreg[1].y : 0.0;
+      }
     }
-    const double *rp = (kk >= ksw) ? Rhi + kk * ldhi : Rlo + kk * ldlo;
-    const int64_t cj = j0 + lcr;
-    rreg.x = (kin && cj < j) ? rp[cj] : 0.0;
-    rreg.y = (kin && cj + 1 < j) ? rp[cj + 1] : 0.0;
+    {  // (threads >= 256 load a duplicate of the R tile and do not store it: no branch around the load)
+      const int64_t k = k0 + rrow;
+      const bool kin = !TAIL || k < kend;
+      const int64_t kk = kin ? k : kbeg;
+      const double *rp = (k0 >= ksw) ? Rhi + kk * ldhi : Rlo + kk * ldlo;  // (a k-step never straddles ksw: both multiples of 16)
+      if constexpr (VEC) {
+        rreg = *reinterpret_cast<const double2v *>(rp + cj0);
+      } else {
+        rreg.x = rp[cr[0]];
+        rreg.y = rp[cr[1]];
+      }
+      if (TAIL) {
+        rreg.x = kin ? rreg.x : 0.0;
+        rreg.y = kin ? rreg.y : 0.0;
+      }
+    }
   };
   auto store_tiles = [&](int buf) {
-    double *s = Ss + buf * TS_BK * SL + lrow * SL + lcs;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) *reinterpret_cast<double2v *>(s + 2 * p) = sreg[p];
-    *reinterpret_cast<double2v *>(Rs + buf * TS_BK * SR + lrow * SR + lcr) = rreg;
+    double *sdst = Ss + buf * TS_BK * SL + lrow * SL + lcs;
+    *reinterpret_cast<double2v *>(sdst) = sreg[0];
+    *reinterpret_cast<double2v *>(sdst + 2) = sreg[1];
+    if (rload) *reinterpret_cast<double2v *>(Rs + buf * TS_BK * SR + rrow * SR + lcr) = rreg;
   };
   auto compute = [&](int buf) {
     const double *l = Ss + buf * TS_BK * SL + q * SL + wi + c16;
     const double *r = Rs + buf * TS_BK * SR + q * SR + c16;
+    double a[2], b[2][2];  // fragments of k-quad kq + 1 are fetched before the MFMAs of k-quad kq
+    a[0] = l[0];
+    b[0][0] = r[0];
+    b[0][1] = r[16];
 #pragma unroll
     for (int kq = 0; kq < TS_BK / 4; ++kq) {
-      double a[2], b[2];
-      a[0] = l[kq * 4 * SL];
-      a[1] = l[kq * 4 * SL + 16];
-      b[0] = r[kq * 4 * SR];
-      b[1] = r[kq * 4 * SR + 16];
-#pragma unroll
-      for (int ta = 0; ta < 2; ++ta)
-#pragma unroll
-        for (int tb = 0; tb < 2; ++tb) acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+      const int cur = kq & 1, nxt = cur ^ 1;
+      if (kq + 1 < TS_BK / 4) {
+        a[nxt] = l[(kq + 1) * 4 * SL];
+        b[nxt][0] = r[(kq + 1) * 4 * SR];
+        b[nxt][1] = r[(kq + 1) * 4 * SR + 16];
+      }
+      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur], b[cur][0], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur], b[cur][1], acc[1], 0, 0, 0);
     }
   };
+  using full_t = std::integral_constant<bool, false>;
+  using tail_t = std::integral_constant<bool, true>;
   const int64_t nk = (kend - kbeg + TS_BK - 1) / TS_BK;
-  load_tiles(kbeg);
+  const int64_t nk_full = (kend - kbeg) / TS_BK;
+  if (nk_full > 0) load_tiles(kbeg, full_t{});
+  else load_tiles(kbeg, tail_t{});
   store_tiles(0);
   __syncthreads();
   for (int64_t kt = 0; kt < nk; ++kt) {
     const int buf = (int)(kt & 1);
     const bool more = kt + 1 < nk;
-    if (more) load_tiles(kbeg + (kt + 1) * TS_BK);
+    if (more) {
+      if (kt + 1 < nk_full) load_tiles(kbeg + (kt + 1) * TS_BK, full_t{});
+      else load_tiles(kbeg + (kt + 1) * TS_BK, tail_t{});
+    }
     compute(buf);
     if (more) store_tiles(buf ^ 1);
     __syncthreads();
   }
 }
 
-// acc -> V rows [i0, i0 + 128), columns [j0, j0 + 32): register (ta, tb, r) of lane l is row 16 ta + 4 r + (l >> 4) of the
-// wave's 32 rows, column 16 tb + (l & 15)
-__device__ __forceinline__ void strip_store(const double4v (&acc)[2][2], double *V, int64_t ldv, int64_t i0, int64_t j0,
+// acc -> V rows [i0, i0 + 128), columns [j0, j0 + 32): register (tb, r) of lane l is row 4 r + (l >> 4) of the wave's 16
+// rows, column 16 tb + (l & 15)
+__device__ __forceinline__ void strip_store(const double4v (&acc)[2], double *V, int64_t ldv, int64_t i0, int64_t j0,
                                             int64_t m, int64_t j) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane >> 4, c16 = lane & 15;
 #pragma unroll
-  for (int ta = 0; ta < 2; ++ta)
+  for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
-    for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int64_t row = i0 + wave * 32 + ta * 16 + 4 * r + q;
-        const int64_t col = j0 + tb * 16 + c16;
-        if (row < m && col < j) V[row * ldv + col] = acc[ta][tb][r];
-      }
+    for (int r = 0; r < 4; ++r) {
+      const int64_t row = i0 + wave * 16 + 4 * r + q;
+      const int64_t col = j0 + tb * 16 + c16;
+      if (row < m && col < j) V[row * ldv + col] = acc[tb][r];
+    }
 }
 
 // V = L^-T L^-1 U for one strip of TS_SC columns: forward block rows 0 .. nb-1 (reads U, writes V), then backward block
 // rows nb-1 .. 0 in place.  The strip is private to the workgroup: its earlier stores are ordered before the later
 // loads by the workgroup barrier (all waves of a workgroup share the CU's L1).
 // fwd_only != 0 stops after the forward solve (V = L^-1 U).
-__global__ __launch_bounds__(256) void tri_solve_strip_kernel(StripArgs a, int fwd_only) {
+__global__ __launch_bounds__(512) void tri_solve_strip_kernel(StripArgs a, int fwd_only) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int64_t j0 = (int64_t)blockIdx.x * TS_SC;
   const int64_t nb = (a.m + TS_NB - 1) / TS_NB;
-  double4v acc[2][2];
+  // 16-byte loads: a full strip, even leading dimensions, 16-byte aligned bases (workgroup-uniform)
+  const bool vec = (j0 + TS_SC <= a.j) && (((a.ldsf | a.ldsb | a.ldu | a.ldv) & 1) == 0) &&
+                   (((reinterpret_cast<uintptr_t>(a.Sf) | reinterpret_cast<uintptr_t>(a.Sb) | reinterpret_cast<uintptr_t>(a.U) |
+                      reinterpret_cast<uintptr_t>(a.V)) & 15) == 0);
+  double4v acc[2];
   for (int64_t b = 0; b < nb; ++b) {
     const int64_t i0 = b * TS_NB;
     const int64_t kend = (i0 + TS_NB < a.m) ? i0 + TS_NB : a.m;
-    strip_block_row(a.Sf, a.ldsf, a.V, a.ldv, a.U, a.ldu, i0, 0, kend, i0, j0, a.m, a.j, lds, acc);
+    if (vec && i0 + TS_NB <= a.m)
+      strip_block_row<true>(a.Sf, a.ldsf, a.V, a.ldv, a.U, a.ldu, i0, 0, kend, i0, j0, a.m, a.j, lds, acc);
+    else
+      strip_block_row<false>(a.Sf, a.ldsf, a.V, a.ldv, a.U, a.ldu, i0, 0, kend, i0, j0, a.m, a.j, lds, acc);
     strip_store(acc, a.V, a.ldv, i0, j0, a.m, a.j);
     __syncthreads();  // (drains the stores: the next block row reads them)
   }
   if (fwd_only) return;
   for (int64_t b = nb - 1; b >= 0; --b) {
     const int64_t i0 = b * TS_NB;
-    strip_block_row(a.Sb, a.ldsb, a.V, a.ldv, a.V, a.ldv, 0, i0, a.m, i0, j0, a.m, a.j, lds, acc);
+    if (vec && i0 + TS_NB <= a.m)
+      strip_block_row<true>(a.Sb, a.ldsb, a.V, a.ldv, a.V, a.ldv, 0, i0, a.m, i0, j0, a.m, a.j, lds, acc);
+    else
+      strip_block_row<false>(a.Sb, a.ldsb, a.V, a.ldv, a.V, a.ldv, 0, i0, a.m, i0, j0, a.m, a.j, lds, acc);
     strip_store(acc, a.V, a.ldv, i0, j0, a.m, a.j);
     __syncthreads();
   }
@@ -308,7 +364,7 @@ int chol_solve_launch(const pls_chol_desc *f, const double *U, int64_t ldu, int6
   StripArgs a{f->Sf, f->Sb, f->ldsf, f->ldsb, U, ldu, V, ldv, f->m, j};
   {
     LaunchScope scope(PLS_TAG_TRI_SOLVE, st);
-    hipLaunchKernelGGL(tri_solve_strip_kernel, dim3((unsigned)cdiv(j, TS_SC)), dim3(256), strip_lds_bytes(), st, a, fwd_only);
+    hipLaunchKernelGGL(tri_solve_strip_kernel, dim3((unsigned)cdiv(j, TS_SC)), dim3(512), strip_lds_bytes(), st, a, fwd_only);
   }
   return check_launch("tri_solve_strip");
 }

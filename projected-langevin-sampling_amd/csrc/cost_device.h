@@ -53,7 +53,7 @@ __device__ inline double link_eval(int link, double f, double jit, double *slope
       return f * f;
     case PLS_LINK_SIGMOID: {  // :67-70
       const double ex = fast_exp(-f);
-      double raw = 1.0 / (1.0 + ex);
+      double raw = fast_div(1.0, 1.0 + ex);
       bool inside = (raw >= jit) && (raw <= 1.0 - jit);
       // d/df 1/(1+e^-f) = e^-f / (1+e^-f)^2, the form autograd differentiates (raw*(1-raw) cancels near raw = 1)
       *slope = inside ? ex * raw * raw : 0.0;
@@ -109,14 +109,14 @@ __device__ inline double cost_deriv(const CostP &c, double y, double f) {
     case PLS_COST_GAUSSIAN:  // gaussian.py:86-88 closed form == chain rule for the identity link
       return (p - y) * c.ip0 * slope;  // (* 1/sigma2 instead of / sigma2: <= 1 ulp, and no fp64 division per element)
     case PLS_COST_POISSON:  // poisson.py:76-82 (square link closed form == chain rule); else autograd value
-      return -2.0 * y / f + slope;
+      return fast_div(-2.0 * y, f) + slope;
     case PLS_COST_BERNOULLI:
       if (ref && c.link == PLS_LINK_SIGMOID)  // bernoulli.py:64-77, uses the CLIPPED p
         return -y * (1.0 - p) + (1.0 - y) * p;
-      return (-y / p + (1.0 - y) / (1.0 - p)) * slope;
+      return (fast_div(-y, p) + fast_div(1.0 - y, 1.0 - p)) * slope;
     case PLS_COST_STUDENT_T: {  // student_t.py:82-88
       double e = p - y;
-      return (c.p0 + 1.0) * e / (c.p0 * c.p1 * c.p1 + e * e) * slope;
+      return fast_div((c.p0 + 1.0) * e, c.p0 * c.p1 * c.p1 + e * e) * slope;
     }
     default: {  // multimodal.py:79-91: always the autograd value
       double e1 = y - p + c.p1, e2 = y - p;
@@ -124,7 +124,7 @@ __device__ inline double cost_deriv(const CostP &c, double y, double f) {
       double a2 = c.mm_l2 - 0.5 * e2 * e2 * c.mm_is2;
       double m = fmax(a1, a2);
       double w1 = fast_exp(a1 - m), w2 = fast_exp(a2 - m);
-      return -(w1 * e1 + w2 * e2) / (w1 + w2) * c.mm_is2 * slope;
+      return -fast_div(w1 * e1 + w2 * e2, w1 + w2) * c.mm_is2 * slope;
     }
   }
 }

@@ -14,8 +14,15 @@ namespace plship {
 // a * b + k for a compile-time constant k.  Written as v_fma_f64 with the constant in a SCALAR register pair: the
 // compiler's own choice for a Horner step is v_mov_b64 (copy the constant) + v_fmac_f64 (two-address form), i.e. two
 // vector instructions per coefficient, and every vector instruction of these kernels costs matrix-pipe issue slots.
+// Each such constant occupies a scalar register pair for as long as the compiler keeps it live, so this form is for
+// translation units whose kernels have scalar registers to spare (PLS_SCALAR_POLY_CONSTANTS = 1: plship.hip -- noise
+// generator, Langevin epilogue, Gram build); in the cost-epilogue and small-rank units it pushed the scalar file into
+// spilling (84 spilled SGPRs and 340 B/lane of scratch in the Poisson drift+value kernel), so they keep the plain fma.
+#ifndef PLS_SCALAR_POLY_CONSTANTS
+#define PLS_SCALAR_POLY_CONSTANTS 0
+#endif
 __device__ __forceinline__ double fma_k(double a, double b, double k) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && PLS_SCALAR_POLY_CONSTANTS
   double d;
   asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(k));
   return d;
@@ -58,6 +65,22 @@ __device__ __forceinline__ double fast_div_normal(double a, double b) {
   r = fma(fma(-b, r, 1.0), r, r);
   const double q = a * r;
   return fma(fma(-b, q, a), r, q);
+}
+
+// a / b for per-element cost code: reciprocal seed, two Newton steps, one residual correction of the quotient (<= 1 ulp
+// for |b| and |a / b| inside the normal range), then v_div_fixup_f64, which puts the IEEE results of the special cases
+// back (b = 0, infinities, NaN).  9 vector instructions against the ~15 of the compiler's scaled division sequence;
+// what is given up is correct rounding and the rescaling of operands within a factor 2^-1022 .. 2^1022 of the limits.
+__device__ __forceinline__ double fast_div(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(b);
+  r = fma(fma(-b, r, 1.0), r, r);
+  r = fma(fma(-b, r, 1.0), r, r);
+  const double q = a * r;
+  return __builtin_amdgcn_div_fixup(fma(fma(-b, q, a), r, q), b, a);
+#else
+  return a / b;
+#endif
 }
 
 // log(x) after fdlibm's e_log.c: x = 2^k (1 + f) with 1 + f in [sqrt(1/2), sqrt(2)), s = f / (2 + f),

@@ -105,8 +105,10 @@ __device__ __forceinline__ void gemm_tn_mainloop(const GemmShape &g, int64_t i0,
   constexpr int SL = BI + PAD, SR = BJ + PAD;
   constexpr int LROWS = NT / (BI / 2);  // k-rows of the L tile covered by one pass of all threads
   constexpr int RROWS = NT / (BJ / 2);
-  constexpr int LPASS = BK / LROWS, RPASS = BK / RROWS;
-  static_assert(BK % LROWS == 0 && BK % RROWS == 0 && BK % 4 == 0, "tile/thread mismatch");
+  // a narrow L tile (BI = 16: the 16-row remainder configuration) is covered by the first BK * BI / 2 threads alone
+  constexpr bool LPART = LROWS > BK;
+  constexpr int LPASS = LPART ? 1 : BK / LROWS, RPASS = BK / RROWS;
+  static_assert((LPART || BK % LROWS == 0) && BK % RROWS == 0 && BK % 4 == 0, "tile/thread mismatch");
   double *Ls = lds;                // [2][BK][SL]
   double *Rs = lds + 2 * BK * SL;  // [2][BK][SR]
 
@@ -164,6 +166,7 @@ __device__ __forceinline__ void gemm_tn_mainloop(const GemmShape &g, int64_t i0,
     constexpr bool TAIL = decltype(tail_tag)::value;
 #pragma unroll
     for (int p = 0; p < LPASS; ++p) {
+      if (LPART && lrow >= BK) break;  // (this thread has no element of the narrow L tile)
       int64_t k = k0 + lrow + p * LROWS;
       lkin[p] = true;
       if (TAIL) {
@@ -201,6 +204,7 @@ __device__ __forceinline__ void gemm_tn_mainloop(const GemmShape &g, int64_t i0,
     double *r = Rs + buf * BK * SR;
 #pragma unroll
     for (int p = 0; p < LPASS; ++p) {
+      if (LPART && lrow >= BK) break;
       double2_t v = lreg[p];
       if (EDGE || TAIL) {
         v.x = (l0 && lkin[p]) ? v.x : 0.0;
@@ -220,7 +224,8 @@ __device__ __forceinline__ void gemm_tn_mainloop(const GemmShape &g, int64_t i0,
   };
   // Fragments are double-buffered in registers: the ds_reads of k-quad q+1 are issued before the MFMAs of
   // k-quad q, so their LDS latency hides under 16 (TI*TJ) 64-cycle MFMAs instead of stalling the wave.
-  auto compute = [&](int buf) {
+  // nq: k-quads of the step that hold data (4, except in the K tail: a rank of 129 contracts 33 quads, not 36)
+  auto compute = [&](int buf, int nq = BK / 4) {
     const double *l = Ls + buf * BK * SL + q * SL + wi + c16;
     const double *r = Rs + buf * BK * SR + q * SR + wj + c16;
     double a[2][TI], b[2][TJ];
@@ -230,6 +235,7 @@ __device__ __forceinline__ void gemm_tn_mainloop(const GemmShape &g, int64_t i0,
     for (int t = 0; t < TJ; ++t) b[0][t] = r[t * 16];
 #pragma unroll
     for (int kq = 0; kq < BK / 4; ++kq) {
+      if (kq >= nq) break;  // wave-uniform
       const int cur = kq & 1, nxt = cur ^ 1;
       if (kq + 1 < BK / 4) {
 #pragma unroll
@@ -362,7 +368,8 @@ __device__ __forceinline__ void gemm_tn_mainloop(const GemmShape &g, int64_t i0,
     const int buf = (int)(kt & 1);
     const bool more = kt + 1 < nk;
     if (more) load_global((kt + 1) * BK, tail_t{});
-    compute(buf);
+    const int64_t kleft = g.K - kt * BK;
+    compute(buf, kleft >= BK ? BK / 4 : (int)((kleft + 3) >> 2));
     if (more) store_lds(buf ^ 1, tail_t{});
     __syncthreads();
   }

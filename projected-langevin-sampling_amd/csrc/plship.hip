@@ -10,6 +10,7 @@
 #include <string>
 #include <vector>
 
+#define PLS_SCALAR_POLY_CONSTANTS 1  // (fmath.h: polynomial constants as scalar operands in this unit's kernels)
 #include "../../include/plship.h"
 #include "chol.h"
 #include "common.h"
@@ -380,16 +381,16 @@ __device__ __forceinline__ double exp_nonpos(double x) {
   double r = fma(n, -6.93147180369123816490e-01, x);
   r = fma(n, -1.90821492927058770002e-10, r);
   double p = 1.6059043836821613e-10;  // 1/13!
-  p = fma(p, r, 2.0876756987868098e-09);
-  p = fma(p, r, 2.5052108385441720e-08);
-  p = fma(p, r, 2.7557319223985893e-07);
-  p = fma(p, r, 2.7557319223985888e-06);
-  p = fma(p, r, 2.4801587301587302e-05);
-  p = fma(p, r, 1.9841269841269841e-04);
-  p = fma(p, r, 1.3888888888888889e-03);
-  p = fma(p, r, 8.3333333333333332e-03);
-  p = fma(p, r, 4.1666666666666664e-02);
-  p = fma(p, r, 1.6666666666666666e-01);
+  p = fma_k(p, r, 2.0876756987868098e-09);
+  p = fma_k(p, r, 2.5052108385441720e-08);
+  p = fma_k(p, r, 2.7557319223985893e-07);
+  p = fma_k(p, r, 2.7557319223985888e-06);
+  p = fma_k(p, r, 2.4801587301587302e-05);
+  p = fma_k(p, r, 1.9841269841269841e-04);
+  p = fma_k(p, r, 1.3888888888888889e-03);
+  p = fma_k(p, r, 8.3333333333333332e-03);
+  p = fma_k(p, r, 4.1666666666666664e-02);
+  p = fma_k(p, r, 1.6666666666666666e-01);
   p = fma(p, r, 0.5);
   p = fma(p, r, 1.0);
   p = fma(p, r, 1.0);
@@ -1027,14 +1028,28 @@ static int stream_drift(const double *Lf, int64_t ldlf, const double *Lb, int64_
     EpiStore e2{D, ldd, 1.0, c == 0 ? 0.0 : 1.0, slab_stride};
     const int64_t kc2 = nslab > 1 ? kchunk : 0;
     const int64_t main_rows = kdim / 128 * 128, rem_rows = kdim - main_rows;
-    if (main_rows > 0 && rem_rows > 0 && rem_rows <= 64 && use_big_tiles(kdim, j, nslab)) {
-      // a rank just above a multiple of 128 (129: the back-projection would compute 256 rows): the full 128-row tiles
-      // with the big configuration, the remainder with 64-row tiles
+    if (main_rows > 0 && rem_rows > 0 && rem_rows <= 112 && use_big_tiles(kdim, j, nslab)) {
+      // a rank that is not a multiple of 128 (129: one more 128-row tile would compute 256 rows for 129): the full
+      // 128-row tiles with the big configuration, the remainder in pieces of 64, 32 and 16 rows (at most 15 idle rows)
       rc = launch_gemm(Lb + r0 * ldlb, ldlb, Gbuf, j, main_rows, j, rows, e2, st, kc2);
-      if (rc) return rc;
-      EpiStore e3{D + main_rows * ldd, ldd, 1.0, c == 0 ? 0.0 : 1.0, slab_stride};
-      GemmShape g3{Lb + r0 * ldlb + main_rows, ldlb, Gbuf, j, rem_rows, j, rows, 0, 0, kc2};
-      rc = launch_gemm_cfg<64, 64, 32, 32>(g3, e3, st);
+      for (int64_t at = main_rows; !rc && at < kdim;) {
+        const int64_t left = kdim - at;
+        EpiStore e3{D + at * ldd, ldd, 1.0, c == 0 ? 0.0 : 1.0, slab_stride};
+        if (left > 32) {
+          const int64_t take = left < 64 ? left : 64;
+          GemmShape g3{Lb + r0 * ldlb + at, ldlb, Gbuf, j, take, j, rows, 0, 0, kc2};
+          rc = launch_gemm_cfg<64, 64, 32, 32>(g3, e3, st);
+          at += take;
+        } else if (left > 16) {
+          GemmShape g3{Lb + r0 * ldlb + at, ldlb, Gbuf, j, left, j, rows, 0, 0, kc2};
+          rc = launch_gemm_cfg<32, 128, 32, 32>(g3, e3, st);
+          at += left;
+        } else {
+          GemmShape g3{Lb + r0 * ldlb + at, ldlb, Gbuf, j, left, j, rows, 0, 0, kc2};
+          rc = launch_gemm_cfg<16, 128, 16, 32>(g3, e3, st);
+          at += left;
+        }
+      }
     } else {
       rc = launch_gemm(Lb + r0 * ldlb, ldlb, Gbuf, j, kdim, j, rows, e2, st, kc2);
     }

@@ -78,6 +78,7 @@ __global__ __launch_bounds__(256, 2) void small_rank_kernel(SmallRankP p) {
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = lane >> 4, c = lane & 15;
+  const int nq_live = (p.K + 3) >> 2;  // k-quads of the first contraction that hold data
   const int64_t jcol = (int64_t)blockIdx.x * 64 + wave * 16 + c;
   const bool jin = jcol < p.J;
   const int split = blockIdx.y;
@@ -155,6 +156,8 @@ __global__ __launch_bounds__(256, 2) void small_rank_kernel(SmallRankP p) {
       const double *a0p = T + c * STR + q, *a1p = T + (16 + c) * STR + q;
 #pragma unroll
       for (int kq = 0; kq < NQ; ++kq) {
+        // only the last three k-quads of the padded rank can be empty (rank 89: 23 quads of 24); a wave-uniform skip
+        if (KB <= 6 && kq >= NQ - 3 && kq >= nq_live) continue;  // (KB >= 7 is at the register limit: no extra control flow)
         const double a0 = a0p[4 * kq], a1 = a1p[4 * kq];
         f0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, ufrag[kq], f0, 0, 0, 0);
         f1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, ufrag[kq], f1, 0, 0, 0);
