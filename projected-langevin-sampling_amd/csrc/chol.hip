@@ -37,7 +37,7 @@ typedef double double2v __attribute__((ext_vector_type(2)));
 constexpr int CH_PB = 64;   // Cholesky panel width
 constexpr int TS_NB = 128;  // block size of the substitution operators
 constexpr int TS_SC = 32;   // particle columns per workgroup
-constexpr int TS_BK = 16;
+constexpr int TS_BK = 32;  // k-depth of a strip-solve step
 
 // Lc = K (+ jitter on the diagonal); LcT, Sf, Sb = 0
 __global__ __launch_bounds__(256) void chol_init_kernel(const double *__restrict__ K, int64_t ldk, int64_t m, double jitter,
@@ -187,19 +187,20 @@ __device__ __forceinline__ void strip_block_row(const double *__restrict__ S, in
                                                 int64_t i0, int64_t j0, int64_t m, int64_t j, double *lds,
                                                 double4v (&acc)[2]) {
   // 8 waves: wave w owns rows [16 w, 16 w + 16) x the strip's 32 columns (one A fragment, two B fragments, two MFMAs per
-  // k-quad); two waves per SIMD, so one wave's LDS / memory waits sit under the other's MFMAs.
+  // k-quad); two waves per SIMD, so one wave's LDS / memory waits sit under the other's MFMAs.  A k-step is TS_BK = 32
+  // deep: 16 MFMAs per wave between two barriers (with 16-deep steps the barrier and the exposed first fragment fetch
+  // were a third of a step).
   constexpr int SL = TS_NB + 16, SR = TS_SC + 16;
+  constexpr int SPASS = TS_BK / 16;  // the 512 threads cover 16 rows of the S tile per pass (32 threads x 4 doubles a row)
+  static_assert(TS_BK == 32, "R tile: 32 rows x 16 threads x 2 doubles = one pass of the 512 threads");
   double *Ss = lds;                     // [2][BK][SL]
   double *Rs = lds + 2 * TS_BK * SL;    // [2][BK][SR]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = lane >> 4, c16 = lane & 15;
   const int wi = wave * 16;
-  // loads: S tile 16 x 128 -> thread (row = tid / 32, 4 doubles from column (tid % 32) * 4); R tile 16 x 32 -> threads < 256,
-  // (row = tid / 16, 2 doubles from column (tid % 16) * 2)
   const int lrow = tid >> 5, lcs = (tid & 31) * 4;
-  const int rrow = (tid >> 4) & 15, lcr = (tid & 15) * 2;
-  const bool rload = tid < 256;
-  double2v sreg[2], rreg;
+  const int rrow = tid >> 4, lcr = (tid & 15) * 2;
+  double2v sreg[SPASS][2], rreg;
   acc[0] = double4v{0.0, 0.0, 0.0, 0.0};
   acc[1] = double4v{0.0, 0.0, 0.0, 0.0};
   // Loop-invariant addressing: a column past the matrix edge is CLAMPED, not zeroed -- column i of S only ever reaches
@@ -216,31 +217,33 @@ __device__ __forceinline__ void strip_block_row(const double *__restrict__ S, in
   for (int e = 0; e < 2; ++e) cr[e] = (cj0 + e < j) ? cj0 + e : 0;
   auto load_tiles = [&](int64_t k0, auto tail_tag) {
     constexpr bool TAIL = decltype(tail_tag)::value;
-    {
-      const int64_t k = k0 + lrow;
+#pragma unroll
+    for (int p = 0; p < SPASS; ++p) {
+      const int64_t k = k0 + lrow + 16 * p;
       const bool kin = !TAIL || k < kend;
       const double *sp = S + (kin ? k : kbeg) * lds_;
       if constexpr (VEC) {
-        sreg[0] = *reinterpret_cast<const double2v *>(sp + ci0);
-        sreg[1] = *reinterpret_cast<const double2v *>(sp + ci0 + 2);
+        sreg[p][0] = *reinterpret_cast<const double2v *>(sp + ci0);
+        sreg[p][1] = *reinterpret_cast<const double2v *>(sp + ci0 + 2);
       } else {
-        sreg[0].x = sp[cs[0]];
-        sreg[0].y = sp[cs[1]];
-        sreg[1].x = sp[cs[2]];
-        sreg[1].y = sp[cs[3]];
+        sreg[p][0].x = sp[cs[0]];
+        sreg[p][0].y = sp[cs[1]];
+        sreg[p][1].x = sp[cs[2]];
+        sreg[p][1].y = sp[cs[3]];
       }
       if (TAIL) {
-        sreg[0].x = kin ? sreg[0].x : 0.0;
-        sreg[0].y = kin ? sreg[0].y : 0.0;
-        sreg[1].x = kin ? sreg[1].x : 0.0;
-        sreg[1].y = kin ? sreg[1].y : 0.0;
+        sreg[p][0].x = kin ? sreg[p][0].x : 0.0;
+        sreg[p][0].y = kin ? sreg[p][0].y : 0.0;
+        sreg[p][1].x = kin ? sreg[p][1].x : 0.0;
+        sreg[p][1].y = kin ? sreg[p][1].y : 0.0;
       }
     }
-    {  // (threads >= 256 load a duplicate of the R tile and do not store it: no branch around the load)
+    {
       const int64_t k = k0 + rrow;
       const bool kin = !TAIL || k < kend;
       const int64_t kk = kin ? k : kbeg;
-      const double *rp = (k0 >= ksw) ? Rhi + kk * ldhi : Rlo + kk * ldlo;  // (a k-step never straddles ksw: both multiples of 16)
+      // (a k-step never straddles ksw: ksw and the step boundaries are multiples of TS_BK)
+      const double *rp = (k0 >= ksw) ? Rhi + kk * ldhi : Rlo + kk * ldlo;
       if constexpr (VEC) {
         rreg = *reinterpret_cast<const double2v *>(rp + cj0);
       } else {
@@ -254,10 +257,13 @@ __device__ __forceinline__ void strip_block_row(const double *__restrict__ S, in
     }
   };
   auto store_tiles = [&](int buf) {
-    double *sdst = Ss + buf * TS_BK * SL + lrow * SL + lcs;
-    *reinterpret_cast<double2v *>(sdst) = sreg[0];
-    *reinterpret_cast<double2v *>(sdst + 2) = sreg[1];
-    if (rload) *reinterpret_cast<double2v *>(Rs + buf * TS_BK * SR + rrow * SR + lcr) = rreg;
+#pragma unroll
+    for (int p = 0; p < SPASS; ++p) {
+      double *sdst = Ss + buf * TS_BK * SL + (lrow + 16 * p) * SL + lcs;
+      *reinterpret_cast<double2v *>(sdst) = sreg[p][0];
+      *reinterpret_cast<double2v *>(sdst + 2) = sreg[p][1];
+    }
+    *reinterpret_cast<double2v *>(Rs + buf * TS_BK * SR + rrow * SR + lcr) = rreg;
   };
   auto compute = [&](int buf) {
     const double *l = Ss + buf * TS_BK * SL + q * SL + wi + c16;

@@ -212,3 +212,31 @@ def test_block_spec_and_batched_runner_bookkeeping():
     assert lr == runs[1].step_size and n == 2 and torch.equal(best, torch.ones(2, 2))
     with pytest.raises(NotImplementedError):
         _SearchLedger(None, "bogus", None, None, 1e-3, fallback_particles=torch.zeros(1, 1))
+
+
+def test_bench_self_launches_its_ranks(monkeypatch):
+    """`python bench.py --gpus N` without a launcher starts N ranks under torch.distributed.run as a CHILD process
+    (rendezvous on 127.0.0.1) before anything touches the GPU, and returns the child's exit code."""
+    import subprocess
+    import sys
+
+    import bench
+
+    seen = {}
+
+    class Done:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return Done()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    assert bench.self_launch(4) == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
