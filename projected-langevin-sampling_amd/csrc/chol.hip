@@ -188,121 +188,101 @@ __device__ __forceinline__ void strip_block_row(const double *__restrict__ S, in
                                                 double4v (&acc)[2]) {
   // 8 waves: wave w owns rows [16 w, 16 w + 16) x the strip's 32 columns (one A fragment, two B fragments, two MFMAs per
   // k-quad); two waves per SIMD, so one wave's LDS / memory waits sit under the other's MFMAs.  A k-step is TS_BK = 32
-  // deep: 16 MFMAs per wave between two barriers (with 16-deep steps the barrier and the exposed first fragment fetch
-  // were a third of a step).
-  constexpr int SL = TS_NB + 16, SR = TS_SC + 16;
-  constexpr int SPASS = TS_BK / 16;  // the 512 threads cover 16 rows of the S tile per pass (32 threads x 4 doubles a row)
+  // deep: 16 MFMAs per wave between two barriers.
+  //   * The A operand (the substitution operator S) is NOT shared between the waves -- each owns different output rows --
+  //     so it never touches LDS: lane l fetches S[k0 + 4 kq + (l >> 4)][i0 + 16 w + (l & 15)] straight into the MFMA
+  //     operand register (16 consecutive doubles per lane group: four 128-byte segments per wave-instruction), one k-step
+  //     ahead.  (Staged through LDS it cost 32 KB of ds_write per step, ~500 cycles of a 3 600-cycle step.)
+  //   * The B operand (the strip's rows of R) is shared by all eight waves: 8 KB per step through LDS, double-buffered.
+  constexpr int SR = TS_SC + 16;
+  constexpr int NQ = TS_BK / 4;
   static_assert(TS_BK == 32, "R tile: 32 rows x 16 threads x 2 doubles = one pass of the 512 threads");
-  double *Ss = lds;                     // [2][BK][SL]
-  double *Rs = lds + 2 * TS_BK * SL;    // [2][BK][SR]
+  double *Rs = lds;  // [2][BK][SR]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = lane >> 4, c16 = lane & 15;
-  const int wi = wave * 16;
-  const int lrow = tid >> 5, lcs = (tid & 31) * 4;
   const int rrow = tid >> 4, lcr = (tid & 15) * 2;
-  double2v sreg[SPASS][2], rreg;
+  double afr[2][NQ];
+  double2v rreg;
   acc[0] = double4v{0.0, 0.0, 0.0, 0.0};
   acc[1] = double4v{0.0, 0.0, 0.0, 0.0};
-  // Loop-invariant addressing: a column past the matrix edge is CLAMPED, not zeroed -- column i of S only ever reaches
-  // output row i, column j of R output column j, and the store drops rows >= m and columns >= j.  Only the rows of a
-  // K tail (k >= kend: they do not exist) must read as zero, and only the last k-step of the last block row has one.
-  // VEC (wave-uniform, chosen per block row by the caller): full block, full strip, 16-byte aligned operands -> one
-  // 16-byte load per pair.  The loads sit in straight-line code: a divergent branch around them makes the compiler wait
-  // for them at the join, i.e. BEFORE the MFMAs they are meant to fly under.
-  const int64_t ci0 = i0 + lcs, cj0 = j0 + lcr;
-  int64_t cs[4], cr[2];
+  // Addressing costs no vector instruction in the k-loop (every VALU instruction is paid in matrix-pipe issue slots):
+  // buffer loads with a descriptor whose base is the step's first row (two scalar adds per step), the row inside the step
+  // as a scalar offset, and ONE loop-invariant lane offset.  The descriptor's range ends at row kend, so the rows of a K
+  // tail read as zero without a branch.  A column past the matrix edge is CLAMPED, not zeroed: column i of S only ever
+  // reaches output row i, column j of R output column j, and the store drops rows >= m and columns >= j.
+  // VEC (workgroup-uniform, chosen by the caller): a full strip -> one 16-byte load per R pair.
+  const int64_t ca = (i0 + wave * 16 + c16 < m) ? i0 + wave * 16 + c16 : 0;
+  const int64_t cj0 = j0 + lcr;
+  const int64_t cr0 = (cj0 < j) ? cj0 : 0, cr1 = (cj0 + 1 < j) ? cj0 + 1 : 0;
+  const int voff_a = (int)((q * lds_ + ca) * 8);
+  const int voff_rlo0 = (int)((rrow * ldlo + cr0) * 8), voff_rlo1 = (int)((rrow * ldlo + cr1) * 8);
+  const int voff_rhi0 = (int)((rrow * ldhi + cr0) * 8), voff_rhi1 = (int)((rrow * ldhi + cr1) * 8);
+  const int row4 = (int)(lds_ * 32);  // bytes per 4 rows of S
+  auto load_tiles = [&](int64_t k0, int nxt) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int64_t left = kend - k0;  // > 0 rows from k0 on
+    auto clamp = [](int64_t bytes) { return (int)(bytes < 0x7FFFFF00 ? bytes : 0x7FFFFF00); };
+    const __amdgpu_buffer_rsrc_t ra =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(S + k0 * lds_), 0, clamp(left * lds_ * 8), 0x00020000);
 #pragma unroll
-  for (int e = 0; e < 4; ++e) cs[e] = (ci0 + e < m) ? ci0 + e : 0;
-#pragma unroll
-  for (int e = 0; e < 2; ++e) cr[e] = (cj0 + e < j) ? cj0 + e : 0;
-  auto load_tiles = [&](int64_t k0, auto tail_tag) {
-    constexpr bool TAIL = decltype(tail_tag)::value;
-#pragma unroll
-    for (int p = 0; p < SPASS; ++p) {
-      const int64_t k = k0 + lrow + 16 * p;
-      const bool kin = !TAIL || k < kend;
-      const double *sp = S + (kin ? k : kbeg) * lds_;
-      if constexpr (VEC) {
-        sreg[p][0] = *reinterpret_cast<const double2v *>(sp + ci0);
-        sreg[p][1] = *reinterpret_cast<const double2v *>(sp + ci0 + 2);
-      } else {
-        sreg[p][0].x = sp[cs[0]];
-        sreg[p][0].y = sp[cs[1]];
-        sreg[p][1].x = sp[cs[2]];
-        sreg[p][1].y = sp[cs[3]];
-      }
-      if (TAIL) {
-        sreg[p][0].x = kin ? sreg[p][0].x : 0.0;
-        sreg[p][0].y = kin ? sreg[p][0].y : 0.0;
-        sreg[p][1].x = kin ? sreg[p][1].x : 0.0;
-        sreg[p][1].y = kin ? sreg[p][1].y : 0.0;
-      }
+    for (int kq = 0; kq < NQ; ++kq)
+      afr[nxt][kq] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(ra, voff_a, kq * row4, 0));
+    const bool hi = k0 >= ksw;  // (a k-step never straddles ksw: ksw and the step boundaries are multiples of TS_BK)
+    const double *rbase = hi ? Rhi + k0 * ldhi : Rlo + k0 * ldlo;
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(rbase), 0,
+                                                                       clamp(left * (hi ? ldhi : ldlo) * 8), 0x00020000);
+    const int v0 = hi ? voff_rhi0 : voff_rlo0, v1 = hi ? voff_rhi1 : voff_rlo1;
+    if constexpr (VEC) {
+      rreg = __builtin_bit_cast(double2v, __builtin_amdgcn_raw_buffer_load_b128(rr, v0, 0, 0));
+    } else {
+      rreg.x = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rr, v0, 0, 0));
+      rreg.y = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rr, v1, 0, 0));
     }
-    {
-      const int64_t k = k0 + rrow;
-      const bool kin = !TAIL || k < kend;
-      const int64_t kk = kin ? k : kbeg;
-      // (a k-step never straddles ksw: ksw and the step boundaries are multiples of TS_BK)
-      const double *rp = (k0 >= ksw) ? Rhi + kk * ldhi : Rlo + kk * ldlo;
-      if constexpr (VEC) {
-        rreg = *reinterpret_cast<const double2v *>(rp + cj0);
-      } else {
-        rreg.x = rp[cr[0]];
-        rreg.y = rp[cr[1]];
-      }
-      if (TAIL) {
-        rreg.x = kin ? rreg.x : 0.0;
-        rreg.y = kin ? rreg.y : 0.0;
-      }
-    }
+#else
+    (void)k0, (void)nxt, (void)voff_a, (void)voff_rlo0, (void)voff_rlo1, (void)voff_rhi0, (void)voff_rhi1, (void)row4;
+#endif
   };
-  auto store_tiles = [&](int buf) {
-#pragma unroll
-    for (int p = 0; p < SPASS; ++p) {
-      double *sdst = Ss + buf * TS_BK * SL + (lrow + 16 * p) * SL + lcs;
-      *reinterpret_cast<double2v *>(sdst) = sreg[p][0];
-      *reinterpret_cast<double2v *>(sdst + 2) = sreg[p][1];
-    }
-    *reinterpret_cast<double2v *>(Rs + buf * TS_BK * SR + rrow * SR + lcr) = rreg;
-  };
+  auto store_tiles = [&](int buf) { *reinterpret_cast<double2v *>(Rs + buf * TS_BK * SR + rrow * SR + lcr) = rreg; };
   auto compute = [&](int buf) {
-    const double *l = Ss + buf * TS_BK * SL + q * SL + wi + c16;
+    // ALL B fragments of the step are fetched in one burst (16 ds_read_b64, 32 VGPRs) and the MFMAs wait on them with
+    // counted lgkmcnt: with one k-quad of look-ahead the two MFMAs of a quad (128 cycles) did not cover the LDS latency,
+    // and the two waves of a SIMD run this loop in lockstep -- both stalled at every quad (56 % MFMA-pipe utilisation).
     const double *r = Rs + buf * TS_BK * SR + q * SR + c16;
-    double a[2], b[2][2];  // fragments of k-quad kq + 1 are fetched before the MFMAs of k-quad kq
-    a[0] = l[0];
-    b[0][0] = r[0];
-    b[0][1] = r[16];
+    double b[NQ][2];
 #pragma unroll
-    for (int kq = 0; kq < TS_BK / 4; ++kq) {
-      const int cur = kq & 1, nxt = cur ^ 1;
-      if (kq + 1 < TS_BK / 4) {
-        a[nxt] = l[(kq + 1) * 4 * SL];
-        b[nxt][0] = r[(kq + 1) * 4 * SR];
-        b[nxt][1] = r[(kq + 1) * 4 * SR + 16];
-      }
-      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur], b[cur][0], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur], b[cur][1], acc[1], 0, 0, 0);
+    for (int kq = 0; kq < NQ; ++kq) {
+      b[kq][0] = r[kq * 4 * SR];
+      b[kq][1] = r[kq * 4 * SR + 16];
     }
+    __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise sinks every read to just before its MFMA pair)
+#pragma unroll
+    for (int kq = 0; kq < NQ; ++kq) {
+      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[buf][kq], b[kq][0], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[buf][kq], b[kq][1], acc[1], 0, 0, 0);
+    }
+    // (and it otherwise hoists the next tile's ds_write + barrier -- hence the wait for the loads issued a moment ago --
+    // above these MFMAs, which are what those loads are meant to fly under)
+    __builtin_amdgcn_sched_barrier(0);
   };
-  using full_t = std::integral_constant<bool, false>;
-  using tail_t = std::integral_constant<bool, true>;
   const int64_t nk = (kend - kbeg + TS_BK - 1) / TS_BK;
-  const int64_t nk_full = (kend - kbeg) / TS_BK;
-  if (nk_full > 0) load_tiles(kbeg, full_t{});
-  else load_tiles(kbeg, tail_t{});
+  load_tiles(kbeg, 0);
   store_tiles(0);
   __syncthreads();
-  for (int64_t kt = 0; kt < nk; ++kt) {
-    const int buf = (int)(kt & 1);
+  // unrolled by two so that the A-fragment register buffers are compile-time indices
+  auto step = [&](int64_t kt, auto buf_tag) {
+    constexpr int buf = decltype(buf_tag)::value;
     const bool more = kt + 1 < nk;
-    if (more) {
-      if (kt + 1 < nk_full) load_tiles(kbeg + (kt + 1) * TS_BK, full_t{});
-      else load_tiles(kbeg + (kt + 1) * TS_BK, tail_t{});
-    }
+    if (more) load_tiles(kbeg + (kt + 1) * TS_BK, buf ^ 1);
     compute(buf);
     if (more) store_tiles(buf ^ 1);
     __syncthreads();
+  };
+  int64_t kt = 0;
+  for (; kt + 1 < nk; kt += 2) {
+    step(kt, std::integral_constant<int, 0>{});
+    step(kt + 1, std::integral_constant<int, 1>{});
   }
+  if (kt < nk) step(kt, std::integral_constant<int, 0>{});
 }
 
 // acc -> V rows [i0, i0 + 128), columns [j0, j0 + 32): register (tb, r) of lane l is row 4 r + (l >> 4) of the wave's 16
@@ -329,15 +309,14 @@ __global__ __launch_bounds__(512) void tri_solve_strip_kernel(StripArgs a, int f
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int64_t j0 = (int64_t)blockIdx.x * TS_SC;
   const int64_t nb = (a.m + TS_NB - 1) / TS_NB;
-  // 16-byte loads: a full strip, even leading dimensions, 16-byte aligned bases (workgroup-uniform)
-  const bool vec = (j0 + TS_SC <= a.j) && (((a.ldsf | a.ldsb | a.ldu | a.ldv) & 1) == 0) &&
-                   (((reinterpret_cast<uintptr_t>(a.Sf) | reinterpret_cast<uintptr_t>(a.Sb) | reinterpret_cast<uintptr_t>(a.U) |
-                      reinterpret_cast<uintptr_t>(a.V)) & 15) == 0);
+  // 16-byte loads of the R operand: a full strip, even leading dimensions, 16-byte aligned bases (workgroup-uniform)
+  const bool vec = (j0 + TS_SC <= a.j) && (((a.ldu | a.ldv) & 1) == 0) &&
+                   (((reinterpret_cast<uintptr_t>(a.U) | reinterpret_cast<uintptr_t>(a.V)) & 15) == 0);
   double4v acc[2];
   for (int64_t b = 0; b < nb; ++b) {
     const int64_t i0 = b * TS_NB;
     const int64_t kend = (i0 + TS_NB < a.m) ? i0 + TS_NB : a.m;
-    if (vec && i0 + TS_NB <= a.m)
+    if (vec)
       strip_block_row<true>(a.Sf, a.ldsf, a.V, a.ldv, a.U, a.ldu, i0, 0, kend, i0, j0, a.m, a.j, lds, acc);
     else
       strip_block_row<false>(a.Sf, a.ldsf, a.V, a.ldv, a.U, a.ldu, i0, 0, kend, i0, j0, a.m, a.j, lds, acc);
@@ -347,7 +326,7 @@ __global__ __launch_bounds__(512) void tri_solve_strip_kernel(StripArgs a, int f
   if (fwd_only) return;
   for (int64_t b = nb - 1; b >= 0; --b) {
     const int64_t i0 = b * TS_NB;
-    if (vec && i0 + TS_NB <= a.m)
+    if (vec)
       strip_block_row<true>(a.Sb, a.ldsb, a.V, a.ldv, a.V, a.ldv, 0, i0, a.m, i0, j0, a.m, a.j, lds, acc);
     else
       strip_block_row<false>(a.Sb, a.ldsb, a.V, a.ldv, a.V, a.ldv, 0, i0, a.m, i0, j0, a.m, a.j, lds, acc);
@@ -356,7 +335,7 @@ __global__ __launch_bounds__(512) void tri_solve_strip_kernel(StripArgs a, int f
   }
 }
 
-static size_t strip_lds_bytes() { return (size_t)2 * TS_BK * ((TS_NB + 16) + (TS_SC + 16)) * sizeof(double); }
+static size_t strip_lds_bytes() { return (size_t)2 * TS_BK * (TS_SC + 16) * sizeof(double); }
 
 int chol_solve_launch(const pls_chol_desc *f, const double *U, int64_t ldu, int64_t j, double *V, int64_t ldv,
                       int fwd_only, hipStream_t st) {

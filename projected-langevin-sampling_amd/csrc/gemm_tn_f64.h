@@ -243,11 +243,20 @@ __device__ __forceinline__ void gemm_tn_mainloop(const GemmShape &g, int64_t i0,
 #pragma unroll
         for (int t = 0; t < TJ; ++t) b[nxt][t] = r[(kq + 1) * 4 * SR + t * 16];
       }
+      // fence the prefetch: left alone, the scheduler sinks these reads to just in front of the MFMAs that use them
+      // (ds_read, s_waitcnt lgkmcnt(0), MFMAs, ds_read, ...), i.e. the LDS latency is exposed once per k-quad -- with the
+      // 2 x 2 tiles of the small configuration that is once per 256 MFMA-cycles
+#ifndef PLS_NO_COMPUTE_FENCE
+      __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
       for (int ta = 0; ta < TI; ++ta)
 #pragma unroll
         for (int tb = 0; tb < TJ; ++tb)
           acc.v[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][ta], b[cur][tb], acc.v[ta][tb], 0, 0, 0);
+#ifndef PLS_NO_COMPUTE_FENCE
+      __builtin_amdgcn_sched_barrier(0);
+#endif
     }
   };
 

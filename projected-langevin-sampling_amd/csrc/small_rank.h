@@ -154,13 +154,45 @@ __global__ __launch_bounds__(256, 2) void small_rank_kernel(SmallRankP p) {
     sr_double4_t f0{0.0, 0.0, 0.0, 0.0}, f1{0.0, 0.0, 0.0, 0.0};
     {
       const double *a0p = T + c * STR + q, *a1p = T + (16 + c) * STR + q;
+      // only the last three k-quads of the padded rank can be empty (rank 89: 23 quads of 24); a wave-uniform skip
+      // (KB >= 7 is at the register limit: no extra control flow there)
+      auto live = [&](int kq) { return !(KB <= 6 && kq >= NQ - 3 && kq >= nq_live); };
+      if constexpr (KB <= 6) {
+        // Software-pipelined by pairs of k-quads: the A fragments of pair g + 1 are fetched BEFORE the four MFMAs of
+        // pair g are issued, and sched_barrier keeps them there.  Left to itself the scheduler sinks every ds_read to
+        // just in front of its MFMA (ds_read, s_waitcnt lgkmcnt(0), four MFMAs, ds_read, ...): the LDS latency is then
+        // exposed once per 256 MFMA-cycles, and the co-resident workgroup only partly covers it (81 % pipe utilisation).
+        double a0[2][2], a1[2][2];
+        a0[0][0] = a0p[0];
+        a0[0][1] = a0p[4];
+        a1[0][0] = a1p[0];
+        a1[0][1] = a1p[4];
 #pragma unroll
-      for (int kq = 0; kq < NQ; ++kq) {
-        // only the last three k-quads of the padded rank can be empty (rank 89: 23 quads of 24); a wave-uniform skip
-        if (KB <= 6 && kq >= NQ - 3 && kq >= nq_live) continue;  // (KB >= 7 is at the register limit: no extra control flow)
-        const double a0 = a0p[4 * kq], a1 = a1p[4 * kq];
-        f0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, ufrag[kq], f0, 0, 0, 0);
-        f1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, ufrag[kq], f1, 0, 0, 0);
+        for (int g = 0; g < NQ / 2; ++g) {
+          const int cur = g & 1, nxt = cur ^ 1;
+          if (g + 1 < NQ / 2) {
+            a0[nxt][0] = a0p[8 * (g + 1)];
+            a0[nxt][1] = a0p[8 * (g + 1) + 4];
+            a1[nxt][0] = a1p[8 * (g + 1)];
+            a1[nxt][1] = a1p[8 * (g + 1) + 4];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int kq = 2 * g + h;
+            if (!live(kq)) continue;
+            f0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[cur][h], ufrag[kq], f0, 0, 0, 0);
+            f1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[cur][h], ufrag[kq], f1, 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+#pragma unroll
+        for (int kq = 0; kq < NQ; ++kq) {
+          const double a0 = a0p[4 * kq], a1 = a1p[4 * kq];
+          f0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, ufrag[kq], f0, 0, 0, 0);
+          f1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, ufrag[kq], f1, 0, 0, 0);
+        }
       }
     }
     // per-element cost on the accumulator registers: register r <-> tile row q + 4 r (+16 for the second block)
@@ -203,6 +235,8 @@ __global__ __launch_bounds__(256, 2) void small_rank_kernel(SmallRankP p) {
 #pragma unroll
           for (int ta = 0; ta < KB; ++ta) an[(g + 1) & 1][ta] = ap[16 * ta];
         }
+        // (without this fence the scheduler rotates the loop: group g's reads end up right in front of group g's MFMAs)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ta = 0; ta < KB; ++ta) dacc[ta] = __builtin_amdgcn_mfma_f64_16x16x4f64(an[g & 1][ta], gq[r], dacc[ta], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);

@@ -713,7 +713,7 @@ def test_captured_training_matches_the_eager_loop(P, cost_idx, epochs, k, patien
     assert torch.equal(got_u, u)
 
 
-@pytest.mark.parametrize("mk", [129, 150, 192, 200, 257])
+@pytest.mark.parametrize("mk", [129, 144, 150, 165, 192, 200, 224, 241, 257, 300])
 def test_ranks_just_above_a_tile_multiple(P, mk):
     """Ranks a little above a multiple of 128 take the back-projection as full 128-row tiles plus a 64-row-tile
     remainder launch (129 rows would otherwise compute as 256).  Step and energy by-product against plain torch fp64
