@@ -37,7 +37,8 @@ typedef double double2v __attribute__((ext_vector_type(2)));
 constexpr int CH_PB = 64;   // Cholesky panel width
 constexpr int TS_NB = 128;  // block size of the substitution operators
 constexpr int TS_SC = 32;   // particle columns per workgroup
-constexpr int TS_BK = 32;  // k-depth of a strip-solve step
+constexpr int TS_BK = 32;   // k-depth of a strip-solve sub-step (one set of A fragments)
+constexpr int TS_RK = 128;  // rows of the R tile in LDS (one barrier per tile)
 
 // Lc = K (+ jitter on the diagonal); LcT, Sf, Sb = 0
 __global__ __launch_bounds__(256) void chol_init_kernel(const double *__restrict__ K, int64_t ldk, int64_t m, double jitter,
@@ -169,8 +170,6 @@ __global__ __launch_bounds__(TS_NB) void tri_block_inverse_kernel(const double *
   }
 }
 
-// One block row of a strip solve:  acc(128 x 32) = sum_{k in [kbeg, kend)} S[k][i0 + i] * R[k][j0 + j], where R is
-// Rlo for k < ksw and Rhi for k >= ksw (forward: the rows already solved come from V, the block's own rows from U).
 struct StripArgs {
   const double *Sf, *Sb;
   int64_t ldsf, ldsb;
@@ -181,108 +180,175 @@ struct StripArgs {
   int64_t m, j;
 };
 
+// One block row of a substitution:  acc(128 x 32) = sum_{k in [kbeg, kend)} S[k][i0 + i] * R[k][j0 + j], where R is Rlo
+// for k < ksw and Rhi for k >= ksw (forward: the rows already solved come from V, the block's own rows from U).
+struct RowCtx {
+  const double *S;
+  int64_t lds;
+  const double *Rlo;
+  int64_t ldlo;
+  const double *Rhi;
+  int64_t ldhi;
+  int64_t ksw, kbeg, kend, i0;
+};
+
+__device__ __forceinline__ RowCtx fwd_row(const StripArgs &a, int64_t b) {
+  const int64_t i0 = b * TS_NB;
+  return RowCtx{a.Sf, a.ldsf, a.V, a.ldv, a.U, a.ldu, i0, 0, (i0 + TS_NB < a.m) ? i0 + TS_NB : a.m, i0};
+}
+__device__ __forceinline__ RowCtx bwd_row(const StripArgs &a, int64_t b) {
+  const int64_t i0 = b * TS_NB;
+  return RowCtx{a.Sb, a.ldsb, a.V, a.ldv, a.V, a.ldv, 0, i0, a.m, i0};
+}
+
+constexpr int TS_NQ = TS_BK / 4;       // k-quads per sub-step
+constexpr int TS_NSUB = TS_RK / TS_BK;  // sub-steps per R tile
+
+// Operand registers that live across block rows: the A fragments of the next sub-step and the next R tile.
+struct StripRegs {
+  double afr[2][TS_NQ];
+  double2v rreg[TS_NSUB];
+};
+
+// 8 waves: wave w owns rows [16 w, 16 w + 16) x the strip's 32 columns (one A fragment, two B fragments, two MFMAs per
+// k-quad); two waves per SIMD, so one wave's LDS / memory waits sit under the other's MFMAs.
+//   * The A operand (the substitution operator S) is NOT shared between the waves -- each owns different output rows --
+//     so it never touches LDS: lane l fetches S[k0 + 4 kq + (l >> 4)][i0 + 16 w + (l & 15)] straight into the MFMA
+//     operand register (16 consecutive doubles per lane group: four 128-byte segments per wave-instruction), one
+//     32-deep sub-step ahead.  (Staged through LDS it cost 32 KB of ds_write per 32 rows.)
+//   * The B operand (the strip's rows of R) is shared by all eight waves and goes through LDS in tiles of TS_RK = 128
+//     rows (32 KB, double-buffered): ONE barrier per 128 rows of the contraction, 64 MFMAs per wave between barriers.
+//   * Addressing costs no vector instruction in the k-loop (every VALU instruction is paid in matrix-pipe issue slots):
+//     buffer loads with a descriptor whose base is the first row of the piece (two scalar adds), the row inside it as a
+//     scalar offset, and ONE loop-invariant lane offset.  The descriptor's range ends at row kend, so rows past the end
+//     of the contraction (the K tail of a matrix whose size is not a multiple of 128) read as zero without a branch.  A
+//     column past the matrix edge is CLAMPED, not zeroed: column i of S only ever reaches output row i, column j of R
+//     output column j, and the store drops rows >= m and columns >= j.
+//   * `have_first`: the row's first R tile and A fragments are already in `regs` (the previous row fetched them under its
+//     last MFMAs); `next`: the row whose first tile THIS row fetches under its last MFMAs (NULL: none -- the caller
+//     passes it only when that tile does not overlap the rows this row is about to store).
+// VEC (workgroup-uniform, chosen by the caller): a full strip -> one 16-byte load per R pair.
+// next_kind: 0 none, 1 forward row next_b, 2 backward row next_b (its RowCtx is only built where it is used, at the last
+// tile of this row: held across the k-loop the second set of pointers and strides spilled 33 scalar registers)
 template <bool VEC>
-__device__ __forceinline__ void strip_block_row(const double *__restrict__ S, int64_t lds_, const double *Rlo, int64_t ldlo,
-                                                const double *Rhi, int64_t ldhi, int64_t ksw, int64_t kbeg, int64_t kend,
-                                                int64_t i0, int64_t j0, int64_t m, int64_t j, double *lds,
+__device__ __forceinline__ void strip_block_row(const StripArgs &a, const RowCtx c, bool have_first, int next_kind,
+                                                int64_t next_b, int64_t j0, double *lds, StripRegs &regs,
                                                 double4v (&acc)[2]) {
-  // 8 waves: wave w owns rows [16 w, 16 w + 16) x the strip's 32 columns (one A fragment, two B fragments, two MFMAs per
-  // k-quad); two waves per SIMD, so one wave's LDS / memory waits sit under the other's MFMAs.  A k-step is TS_BK = 32
-  // deep: 16 MFMAs per wave between two barriers.
-  //   * The A operand (the substitution operator S) is NOT shared between the waves -- each owns different output rows --
-  //     so it never touches LDS: lane l fetches S[k0 + 4 kq + (l >> 4)][i0 + 16 w + (l & 15)] straight into the MFMA
-  //     operand register (16 consecutive doubles per lane group: four 128-byte segments per wave-instruction), one k-step
-  //     ahead.  (Staged through LDS it cost 32 KB of ds_write per step, ~500 cycles of a 3 600-cycle step.)
-  //   * The B operand (the strip's rows of R) is shared by all eight waves: 8 KB per step through LDS, double-buffered.
+  const int64_t m = a.m, j = a.j;
   constexpr int SR = TS_SC + 16;
-  constexpr int NQ = TS_BK / 4;
-  static_assert(TS_BK == 32, "R tile: 32 rows x 16 threads x 2 doubles = one pass of the 512 threads");
-  double *Rs = lds;  // [2][BK][SR]
+  constexpr int NQ = TS_NQ, NSUB = TS_NSUB;
+  static_assert(TS_BK == 32 && TS_RK == 128 && (NSUB % 2) == 0, "sub-step parity = A-fragment buffer");
+  double *Rs = lds;  // [2][TS_RK][SR]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = lane >> 4, c16 = lane & 15;
-  const int rrow = tid >> 4, lcr = (tid & 15) * 2;
-  double afr[2][NQ];
-  double2v rreg;
+  const int rrow = tid >> 4, lcr = (tid & 15) * 2;  // R tile: 4 passes of 32 rows x 16 threads x 2 doubles
   acc[0] = double4v{0.0, 0.0, 0.0, 0.0};
   acc[1] = double4v{0.0, 0.0, 0.0, 0.0};
-  // Addressing costs no vector instruction in the k-loop (every VALU instruction is paid in matrix-pipe issue slots):
-  // buffer loads with a descriptor whose base is the step's first row (two scalar adds per step), the row inside the step
-  // as a scalar offset, and ONE loop-invariant lane offset.  The descriptor's range ends at row kend, so the rows of a K
-  // tail read as zero without a branch.  A column past the matrix edge is CLAMPED, not zeroed: column i of S only ever
-  // reaches output row i, column j of R output column j, and the store drops rows >= m and columns >= j.
-  // VEC (workgroup-uniform, chosen by the caller): a full strip -> one 16-byte load per R pair.
-  const int64_t ca = (i0 + wave * 16 + c16 < m) ? i0 + wave * 16 + c16 : 0;
   const int64_t cj0 = j0 + lcr;
   const int64_t cr0 = (cj0 < j) ? cj0 : 0, cr1 = (cj0 + 1 < j) ? cj0 + 1 : 0;
-  const int voff_a = (int)((q * lds_ + ca) * 8);
-  const int voff_rlo0 = (int)((rrow * ldlo + cr0) * 8), voff_rlo1 = (int)((rrow * ldlo + cr1) * 8);
-  const int voff_rhi0 = (int)((rrow * ldhi + cr0) * 8), voff_rhi1 = (int)((rrow * ldhi + cr1) * 8);
-  const int row4 = (int)(lds_ * 32);  // bytes per 4 rows of S
-  auto load_tiles = [&](int64_t k0, int nxt) {
+  auto clamp = [](int64_t bytes) { return (int)(bytes < 0 ? 0 : (bytes < 0x7FFFFF00 ? bytes : 0x7FFFFF00)); };
+  auto load_a = [&](const RowCtx &x, int64_t k0, int nxt) {  // A fragments of the 32-deep sub-step that starts at row k0
 #if defined(__HIP_DEVICE_COMPILE__)
-    const int64_t left = kend - k0;  // > 0 rows from k0 on
-    auto clamp = [](int64_t bytes) { return (int)(bytes < 0x7FFFFF00 ? bytes : 0x7FFFFF00); };
-    const __amdgpu_buffer_rsrc_t ra =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(S + k0 * lds_), 0, clamp(left * lds_ * 8), 0x00020000);
+    const int64_t ca = (x.i0 + wave * 16 + c16 < m) ? x.i0 + wave * 16 + c16 : 0;
+    const int voff_a = (int)((q * x.lds + ca) * 8);
+    const int row4 = (int)(x.lds * 32);  // bytes per 4 rows of S
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(x.S + k0 * x.lds), 0,
+                                                                       clamp((x.kend - k0) * x.lds * 8), 0x00020000);
 #pragma unroll
     for (int kq = 0; kq < NQ; ++kq)
-      afr[nxt][kq] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(ra, voff_a, kq * row4, 0));
-    const bool hi = k0 >= ksw;  // (a k-step never straddles ksw: ksw and the step boundaries are multiples of TS_BK)
-    const double *rbase = hi ? Rhi + k0 * ldhi : Rlo + k0 * ldlo;
-    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(rbase), 0,
-                                                                       clamp(left * (hi ? ldhi : ldlo) * 8), 0x00020000);
-    const int v0 = hi ? voff_rhi0 : voff_rlo0, v1 = hi ? voff_rhi1 : voff_rlo1;
-    if constexpr (VEC) {
-      rreg = __builtin_bit_cast(double2v, __builtin_amdgcn_raw_buffer_load_b128(rr, v0, 0, 0));
-    } else {
-      rreg.x = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rr, v0, 0, 0));
-      rreg.y = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rr, v1, 0, 0));
-    }
+      regs.afr[nxt][kq] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(ra, voff_a, kq * row4, 0));
 #else
-    (void)k0, (void)nxt, (void)voff_a, (void)voff_rlo0, (void)voff_rlo1, (void)voff_rhi0, (void)voff_rhi1, (void)row4;
+    (void)x, (void)k0, (void)nxt;
 #endif
   };
-  auto store_tiles = [&](int buf) { *reinterpret_cast<double2v *>(Rs + buf * TS_BK * SR + rrow * SR + lcr) = rreg; };
-  auto compute = [&](int buf) {
-    // ALL B fragments of the step are fetched in one burst (16 ds_read_b64, 32 VGPRs) and the MFMAs wait on them with
-    // counted lgkmcnt: with one k-quad of look-ahead the two MFMAs of a quad (128 cycles) did not cover the LDS latency,
-    // and the two waves of a SIMD run this loop in lockstep -- both stalled at every quad (56 % MFMA-pipe utilisation).
-    const double *r = Rs + buf * TS_BK * SR + q * SR + c16;
+  auto load_r = [&](const RowCtx &x, int64_t k0) {  // the 128-row R tile at row k0 (never straddles ksw: both multiples of 128)
+#if defined(__HIP_DEVICE_COMPILE__)
+    const bool hi = k0 >= x.ksw;
+    const int64_t ldr = hi ? x.ldhi : x.ldlo;
+    const double *rbase = hi ? x.Rhi + k0 * x.ldhi : x.Rlo + k0 * x.ldlo;
+    const __amdgpu_buffer_rsrc_t rr =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(rbase), 0, clamp((x.kend - k0) * ldr * 8), 0x00020000);
+    const int v0 = (int)((rrow * ldr + cr0) * 8), v1 = (int)((rrow * ldr + cr1) * 8);
+    const int pass = (int)(ldr * 8 * TS_BK);  // bytes per 32 rows
+#pragma unroll
+    for (int p = 0; p < NSUB; ++p) {
+      if constexpr (VEC) {
+        regs.rreg[p] = __builtin_bit_cast(double2v, __builtin_amdgcn_raw_buffer_load_b128(rr, v0, p * pass, 0));
+      } else {
+        regs.rreg[p].x = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rr, v0, p * pass, 0));
+        regs.rreg[p].y = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rr, v1, p * pass, 0));
+      }
+    }
+#else
+    (void)x, (void)k0, (void)cr0, (void)cr1;
+#endif
+  };
+  auto store_r = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < NSUB; ++p)
+      *reinterpret_cast<double2v *>(Rs + (buf * TS_RK + p * TS_BK + rrow) * SR + lcr) = regs.rreg[p];
+  };
+  auto compute = [&](int rbuf, int sub, auto abuf_tag) {
+    constexpr int abuf = decltype(abuf_tag)::value;
+    // ALL B fragments of the sub-step are fetched in one burst (16 ds_read_b64, 32 VGPRs) and the MFMAs wait on them with
+    // counted lgkmcnt; the fences keep the scheduler from sinking every read to just before its MFMA pair, and from
+    // hoisting what follows (the next tile's ds_write + barrier) above these MFMAs.
+    const double *r = Rs + (rbuf * TS_RK + sub * TS_BK + q) * SR + c16;
     double b[NQ][2];
 #pragma unroll
     for (int kq = 0; kq < NQ; ++kq) {
       b[kq][0] = r[kq * 4 * SR];
       b[kq][1] = r[kq * 4 * SR + 16];
     }
-    __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise sinks every read to just before its MFMA pair)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kq = 0; kq < NQ; ++kq) {
-      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[buf][kq], b[kq][0], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[buf][kq], b[kq][1], acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(regs.afr[abuf][kq], b[kq][0], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(regs.afr[abuf][kq], b[kq][1], acc[1], 0, 0, 0);
     }
-    // (and it otherwise hoists the next tile's ds_write + barrier -- hence the wait for the loads issued a moment ago --
-    // above these MFMAs, which are what those loads are meant to fly under)
     __builtin_amdgcn_sched_barrier(0);
   };
-  const int64_t nk = (kend - kbeg + TS_BK - 1) / TS_BK;
-  load_tiles(kbeg, 0);
-  store_tiles(0);
-  __syncthreads();
-  // unrolled by two so that the A-fragment register buffers are compile-time indices
-  auto step = [&](int64_t kt, auto buf_tag) {
-    constexpr int buf = decltype(buf_tag)::value;
-    const bool more = kt + 1 < nk;
-    if (more) load_tiles(kbeg + (kt + 1) * TS_BK, buf ^ 1);
-    compute(buf);
-    if (more) store_tiles(buf ^ 1);
-    __syncthreads();
-  };
-  int64_t kt = 0;
-  for (; kt + 1 < nk; kt += 2) {
-    step(kt, std::integral_constant<int, 0>{});
-    step(kt + 1, std::integral_constant<int, 1>{});
+  const int64_t nsup = (c.kend - c.kbeg + TS_RK - 1) / TS_RK;
+  if (!have_first) {
+    load_r(c, c.kbeg);
+    load_a(c, c.kbeg, 0);
   }
-  if (kt < nk) step(kt, std::integral_constant<int, 0>{});
+  store_r(0);
+  __syncthreads();
+  // the steady state (every tile but the row's last) is its own loop: no test for the row's end, no second row context
+  int64_t sup = 0;
+  for (; sup + 1 < nsup; ++sup) {
+    const int rbuf = (int)(sup & 1);
+    const int64_t k0 = c.kbeg + sup * TS_RK;
+    load_r(c, k0 + TS_RK);
+    // four sub-steps, A fragments one sub-step ahead
+    load_a(c, k0 + TS_BK, 1);
+    compute(rbuf, 0, std::integral_constant<int, 0>{});
+    load_a(c, k0 + 2 * TS_BK, 0);
+    compute(rbuf, 1, std::integral_constant<int, 1>{});
+    load_a(c, k0 + 3 * TS_BK, 1);
+    compute(rbuf, 2, std::integral_constant<int, 0>{});
+    load_a(c, k0 + TS_RK, 0);
+    compute(rbuf, 3, std::integral_constant<int, 1>{});
+    store_r(rbuf ^ 1);
+    __syncthreads();
+  }
+  {  // the row's last tile: the next block row's first tile and fragments fly under its 64 MFMAs
+    const int rbuf = (int)(sup & 1);
+    const int64_t k0 = c.kbeg + sup * TS_RK;
+    RowCtx nx = c;
+    if (next_kind) nx = next_kind == 1 ? fwd_row(a, next_b) : bwd_row(a, next_b);
+    if (next_kind) load_r(nx, nx.kbeg);
+    load_a(c, k0 + TS_BK, 1);  // (rows past kend read as zero)
+    compute(rbuf, 0, std::integral_constant<int, 0>{});
+    load_a(c, k0 + 2 * TS_BK, 0);
+    compute(rbuf, 1, std::integral_constant<int, 1>{});
+    load_a(c, k0 + 3 * TS_BK, 1);
+    compute(rbuf, 2, std::integral_constant<int, 0>{});
+    if (next_kind) load_a(nx, nx.kbeg, 0);
+    compute(rbuf, 3, std::integral_constant<int, 1>{});
+    __syncthreads();
+  }
 }
 
 // acc -> V rows [i0, i0 + 128), columns [j0, j0 + 32): register (tb, r) of lane l is row 4 r + (l >> 4) of the wave's 16
@@ -303,39 +369,49 @@ __device__ __forceinline__ void strip_store(const double4v (&acc)[2], double *V,
 
 // V = L^-T L^-1 U for one strip of TS_SC columns: forward block rows 0 .. nb-1 (reads U, writes V), then backward block
 // rows nb-1 .. 0 in place.  The strip is private to the workgroup: its earlier stores are ordered before the later
-// loads by the workgroup barrier (all waves of a workgroup share the CU's L1).
+// loads by a workgroup barrier (all waves of a workgroup share the CU's L1).  A row fetches the next row's first operands
+// under its own last MFMAs whenever they cannot be rows it is about to store: forward from row 1 on (the next row starts
+// at rows 0..127 of V), backward always (the next row starts one block above); not from forward row 0, and not across the
+// forward -> backward turn, whose first tile is exactly the block just solved.
 // fwd_only != 0 stops after the forward solve (V = L^-1 U).
-__global__ __launch_bounds__(512) void tri_solve_strip_kernel(StripArgs a, int fwd_only) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int64_t j0 = (int64_t)blockIdx.x * TS_SC;
+template <bool VEC>
+__device__ __forceinline__ void strip_solve(const StripArgs &a, int fwd_only, int64_t j0, double *lds) {
   const int64_t nb = (a.m + TS_NB - 1) / TS_NB;
-  // 16-byte loads of the R operand: a full strip, even leading dimensions, 16-byte aligned bases (workgroup-uniform)
-  const bool vec = (j0 + TS_SC <= a.j) && (((a.ldu | a.ldv) & 1) == 0) &&
-                   (((reinterpret_cast<uintptr_t>(a.U) | reinterpret_cast<uintptr_t>(a.V)) & 15) == 0);
+  StripRegs regs;
   double4v acc[2];
+  bool have = false;
   for (int64_t b = 0; b < nb; ++b) {
-    const int64_t i0 = b * TS_NB;
-    const int64_t kend = (i0 + TS_NB < a.m) ? i0 + TS_NB : a.m;
-    if (vec)
-      strip_block_row<true>(a.Sf, a.ldsf, a.V, a.ldv, a.U, a.ldu, i0, 0, kend, i0, j0, a.m, a.j, lds, acc);
-    else
-      strip_block_row<false>(a.Sf, a.ldsf, a.V, a.ldv, a.U, a.ldu, i0, 0, kend, i0, j0, a.m, a.j, lds, acc);
-    strip_store(acc, a.V, a.ldv, i0, j0, a.m, a.j);
-    __syncthreads();  // (drains the stores: the next block row reads them)
+    const RowCtx c = fwd_row(a, b);
+    const bool pre = b >= 1 && b + 1 < nb;
+    strip_block_row<VEC>(a, c, have, pre ? 1 : 0, b + 1, j0, lds, regs, acc);
+    strip_store(acc, a.V, a.ldv, c.i0, j0, a.m, a.j);
+    have = pre;
+    if (!pre) __syncthreads();  // (drains the stores: the next row's first loads read them)
   }
   if (fwd_only) return;
   for (int64_t b = nb - 1; b >= 0; --b) {
-    const int64_t i0 = b * TS_NB;
-    if (vec)
-      strip_block_row<true>(a.Sb, a.ldsb, a.V, a.ldv, a.V, a.ldv, 0, i0, a.m, i0, j0, a.m, a.j, lds, acc);
-    else
-      strip_block_row<false>(a.Sb, a.ldsb, a.V, a.ldv, a.V, a.ldv, 0, i0, a.m, i0, j0, a.m, a.j, lds, acc);
-    strip_store(acc, a.V, a.ldv, i0, j0, a.m, a.j);
-    __syncthreads();
+    const RowCtx c = bwd_row(a, b);
+    const bool pre = b >= 1;
+    strip_block_row<VEC>(a, c, have, pre ? 2 : 0, b - 1, j0, lds, regs, acc);
+    strip_store(acc, a.V, a.ldv, c.i0, j0, a.m, a.j);
+    have = pre;
+    if (!pre) __syncthreads();
   }
 }
 
-static size_t strip_lds_bytes() { return (size_t)2 * TS_BK * (TS_SC + 16) * sizeof(double); }
+__global__ __launch_bounds__(512) void tri_solve_strip_kernel(StripArgs a, int fwd_only) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int64_t j0 = (int64_t)blockIdx.x * TS_SC;
+  // 16-byte loads of the R operand: a full strip, even leading dimensions, 16-byte aligned bases (workgroup-uniform)
+  const bool vec = (j0 + TS_SC <= a.j) && (((a.ldu | a.ldv) & 1) == 0) &&
+                   (((reinterpret_cast<uintptr_t>(a.U) | reinterpret_cast<uintptr_t>(a.V)) & 15) == 0);
+  if (vec)
+    strip_solve<true>(a, fwd_only, j0, lds);
+  else
+    strip_solve<false>(a, fwd_only, j0, lds);
+}
+
+static size_t strip_lds_bytes() { return (size_t)2 * TS_RK * (TS_SC + 16) * sizeof(double); }
 
 int chol_solve_launch(const pls_chol_desc *f, const double *U, int64_t ldu, int64_t j, double *V, int64_t ldv,
                       int fwd_only, hipStream_t st) {

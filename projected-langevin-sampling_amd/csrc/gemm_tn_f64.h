@@ -387,15 +387,12 @@ __device__ __forceinline__ void gemm_tn_mainloop(const GemmShape &g, int64_t i0,
 // largest leading dimension (doubles) the direct epilogue addresses with 32-bit byte offsets (67 rows * ld * 8 < 2^31)
 constexpr int64_t kDirectMaxLd = (int64_t)1 << 21;
 
-template <int BI, int BJ, int WI, int WJ, int BK, int MINW, class Epilogue>
-__global__ __launch_bounds__((BI / WI) * (BJ / WJ) * 64, MINW) void gemm_tn_f64_kernel(GemmShape g, Epilogue epi) {
+// One output tile (tile_i, tile_j) of the contraction: k-loop + epilogue.
+template <int BI, int BJ, int WI, int WJ, int BK, class Epilogue>
+__device__ __forceinline__ void gemm_tile(GemmShape g, const Epilogue &epi, int tile_i, int tile_j, double *lds) {
   constexpr int TI = WI / 16, TJ = WJ / 16;
   static_assert((BI / WI) * (BJ / WJ) * 2 * 16 * (WJ + 2) <= 2 * BK * ((BI + 16) + (BJ + 16)),
                 "the epilogue slabs reuse the operand tiles' LDS");
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-
-  int tile_i, tile_j;
-  gemm_tile_coords(blockIdx.x, g.nti, g.ntj, tile_i, tile_j);
   const int64_t i0 = (int64_t)tile_i * BI, j0 = (int64_t)tile_j * BJ;
   const int split = blockIdx.y;
   if (gridDim.y > 1) {  // split-K slab: shift the operands to this block's k-range
@@ -444,6 +441,31 @@ __global__ __launch_bounds__((BI / WI) * (BJ / WJ) * 64, MINW) void gemm_tn_f64_
   }
   epi.template apply<TI, TJ>(acc, i0 + wi, j0 + wj, lane, wave, g.I, g.J, tile_i, split, lds);
   PLS_STAMP_AT(3);
+}
+
+template <int BI, int BJ, int WI, int WJ, int BK, int MINW, class Epilogue>
+__global__ __launch_bounds__((BI / WI) * (BJ / WJ) * 64, MINW) void gemm_tn_f64_kernel(GemmShape g, Epilogue epi) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  int tile_i, tile_j;
+  if constexpr (Epilogue::kTag == 1) {  // (only the plain-store contraction is ever launched with a triangular operand)
+   if (g.tri) {
+    // Triangular operand: tile row t contracts (t + 1) * BI rows, so the rows are far from equal -- and the two workgroups
+    // that share a CU get the SAME row (their block ids differ by a multiple of 8 * nti), i.e. a CU holding two copies of
+    // the last row sets the launch time (0.24 ms for L xi at M = 1024 against 0.26 ms for the full product).  A workgroup
+    // therefore takes tile rows t and nti - 1 - t one after the other: every workgroup contracts nti + 1 row-blocks.
+    const int pairs = (g.nti + 1) >> 1;
+    gemm_tile_coords(blockIdx.x, pairs, g.ntj, tile_i, tile_j);
+    gemm_tile<BI, BJ, WI, WJ, BK>(g, epi, tile_i, tile_j, lds);
+    const int other = g.nti - 1 - tile_i;
+    if (other != tile_i) {
+      __syncthreads();  // (the first tile's epilogue may still be reading its LDS slabs)
+      gemm_tile<BI, BJ, WI, WJ, BK>(g, epi, other, tile_j, lds);
+    }
+    return;
+   }
+  }
+  gemm_tile_coords(blockIdx.x, g.nti, g.ntj, tile_i, tile_j);
+  gemm_tile<BI, BJ, WI, WJ, BK>(g, epi, tile_i, tile_j, lds);
 }
 
 // ---- epilogues ------------------------------------------------------------------------------------------------
