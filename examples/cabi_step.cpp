@@ -1,5 +1,6 @@
 // libplship from plain C++ (no Python, no torch): one fused Langevin step on the orthonormal basis through the C ABI
-// of include/plship.h, checked against a scalar host loop.  This is the boundary a non-Python host would bind.
+// of include/plship.h, checked against a scalar host loop, and the device Cholesky + block-substitution solve of the
+// inducing-point basis checked by its residual.  This is the boundary a non-Python host would bind.
 //   build: hipcc -O2 -std=c++17 -I include examples/cabi_step.cpp -L projected-langevin-sampling_amd -lplship \
 //                -Wl,-rpath,$PWD/projected-langevin-sampling_amd -o /tmp/cabi_step
 // Reference semantics: projected_langevin_sampling.py:107-123 with basis/orthonormal.py:98-108,128-159 and
@@ -125,6 +126,58 @@ int main() {
     return 4;
   }
   std::printf("workspace error reported: %s\n", pls_last_error());
+  // the factorisation behind gpytorch.solve (inducing_point.py:89-93, :130-132) from plain C++: K = Q Q^T + m I (SPD, M = 200:
+  // two 128-blocks, the second one partial), K = Lc Lc^T on the device, V = K^-1 U by block substitution, residual on the host
+  {
+    const int64_t m = 200, jj = 45, ld = 208;  // (even leading dimension, 16-byte aligned rows)
+    std::vector<double> Q(m * m), K(m * ld, 0.0), Uh(m * jj);
+    for (auto &v : Q) v = nd(gen);
+    for (auto &v : Uh) v = nd(gen);
+    for (int64_t a = 0; a < m; ++a)
+      for (int64_t b = 0; b < m; ++b) {
+        double acc = (a == b) ? (double)m : 0.0;
+        for (int64_t k = 0; k < m; ++k) acc += Q[a * m + k] * Q[b * m + k];
+        K[a * ld + b] = acc;
+      }
+    double *dK = to_device(K), *dUh = to_device(Uh), *dLc, *dLcT, *dSf, *dSb, *dV;
+    int32_t *dinfo;
+    HIP_OK(hipMalloc(&dLc, m * ld * sizeof(double)));
+    HIP_OK(hipMalloc(&dLcT, m * ld * sizeof(double)));
+    HIP_OK(hipMalloc(&dSf, m * ld * sizeof(double)));
+    HIP_OK(hipMalloc(&dSb, m * ld * sizeof(double)));
+    HIP_OK(hipMalloc(&dV, m * jj * sizeof(double)));
+    HIP_OK(hipMalloc(&dinfo, sizeof(int32_t)));
+    if (!dK || !dUh) return 2;
+    PLS_OK_(pls_chol_factor(dK, ld, m, /*jitter=*/0.0, dLc, ld, dLcT, ld, dSf, ld, dSb, ld, dinfo, st));
+    pls_chol_desc f{m, dLc, ld, dLcT, ld, dSf, ld, dSb, ld};
+    PLS_OK_(pls_chol_solve(&f, dUh, jj, jj, dV, jj, st));
+    HIP_OK(hipStreamSynchronize(st));
+    int32_t info = -1;
+    std::vector<double> V(m * jj);
+    HIP_OK(hipMemcpy(&info, dinfo, sizeof(info), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(V.data(), dV, V.size() * sizeof(double), hipMemcpyDeviceToHost));
+    double res = 0.0, sc = 0.0;
+    for (int64_t a = 0; a < m; ++a)
+      for (int64_t c = 0; c < jj; ++c) {
+        double acc = 0.0;
+        for (int64_t b = 0; b < m; ++b) acc += K[a * ld + b] * V[b * jj + c];
+        res = std::fmax(res, std::abs(acc - Uh[a * jj + c]));
+        sc = std::fmax(sc, std::abs(Uh[a * jj + c]));
+      }
+    std::printf("cholesky: info %d, solve residual max|K V - U| / max|U| = %.2e\n", (int)info, res / sc);
+    if (info != 0 || !(res / sc < 1e-11)) {
+      std::fprintf(stderr, "cholesky / solve failure\n");
+      return 5;
+    }
+    // a matrix that is not positive definite is reported through `info`, not crashed on
+    K[5 * ld + 5] = -1.0;
+    HIP_OK(hipMemcpy(dK, K.data(), K.size() * sizeof(double), hipMemcpyHostToDevice));
+    PLS_OK_(pls_chol_factor(dK, ld, m, 0.0, dLc, ld, dLcT, ld, dSf, ld, dSb, ld, dinfo, st));
+    HIP_OK(hipStreamSynchronize(st));
+    HIP_OK(hipMemcpy(&info, dinfo, sizeof(info), hipMemcpyDeviceToHost));
+    std::printf("not positive definite: info = %d (first failing pivot, 1-based)\n", (int)info);
+    if (info != 6) return 6;
+  }
   if (!(worst < 1e-9)) {
     std::fprintf(stderr, "parity failure: %.3e\n", worst);
     return 1;

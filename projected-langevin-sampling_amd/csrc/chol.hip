@@ -230,6 +230,15 @@ struct StripRegs {
 // VEC (workgroup-uniform, chosen by the caller): a full strip -> one 16-byte load per R pair.
 // next_kind: 0 none, 1 forward row next_b, 2 backward row next_b (its RowCtx is only built where it is used, at the last
 // tile of this row: held across the k-loop the second set of pointers and strides spilled 33 scalar registers)
+// Workgroup barrier that orders LDS traffic only: s_waitcnt lgkmcnt(0) + s_barrier.  __syncthreads() also drains the
+// wave's global loads and stores (vmcnt(0)) -- right for handing over rows of V, wrong inside the k-loop, where the loads
+// in flight are the NEXT sub-step's operand fragments.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 template <bool VEC>
 __device__ __forceinline__ void strip_block_row(const StripArgs &a, const RowCtx c, bool have_first, int next_kind,
                                                 int64_t next_b, int64_t j0, double *lds, StripRegs &regs,
@@ -331,7 +340,7 @@ __device__ __forceinline__ void strip_block_row(const StripArgs &a, const RowCtx
     load_a(c, k0 + TS_RK, 0);
     compute(rbuf, 3, std::integral_constant<int, 1>{});
     store_r(rbuf ^ 1);
-    __syncthreads();
+    lds_barrier();  // (only the R tile is handed over here: the A fragments just requested keep flying across it)
   }
   {  // the row's last tile: the next block row's first tile and fragments fly under its 64 MFMAs
     const int rbuf = (int)(sup & 1);

@@ -22,3 +22,4 @@ def test_cabi_from_plain_cpp(tmp_path):
     run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert run.returncode == 0, run.stdout + run.stderr
     assert "cabi_step OK" in run.stdout and "workspace error reported" in run.stdout
+    assert "cholesky: info 0" in run.stdout and "not positive definite: info = 6" in run.stdout
