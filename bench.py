@@ -398,10 +398,11 @@ def main():
     # ---- Gaussian algebraic fast path, same run ----
     if cfg["cost"] == "gaussian":
         fsteps = max(args.steps * 10, 50)
-        # every section starts from a settled chip, like the headline run does after the setup: straight after the
-        # 45 ms-per-step phase above the power controller holds the clock ~7 % lower for a few tens of milliseconds
-        # (0.279 ms per launch against 0.261 ms for the same launches one second later, tools/fastpath_probe.py)
-        settle()
+        # every section starts from a settled chip, like the headline run does after the setup: after the 45 ms-per-step
+        # phase above (0.6 s of sustained full-rate MFMA) the power controller holds the clock lower for SECONDS -- these
+        # same launches measured 0.282 ms one second after it and 0.261-0.267 ms from a rested chip
+        # (tools/fastpath_probe.py; the train_pls section further down, later in the same run: 0.267 ms)
+        settle(4.0)
         dtf, tlf = run(force_generic=False, steps=fsteps, warmup=max(args.warmup, 5), timeline=True)
         log(f"gaussian fast path: {dtf / fsteps * 1e3:.3f} ms/step")
         k = tlf.get("gemm_langevin_gaussian", {"total_ms": 0.0, "launches": 0, "avg_ms": 0.0})
