@@ -156,6 +156,9 @@ def cpu_baseline(cfg, x, z, y, ls, lam_all, vec_all):
         t_full = t_s * scale
         rss_gb = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1048576.0
         full = (n_s, j_s) == (n_full, j_full)
+        on_device = None
+        if torch.cuda.is_available() and 40.0 * n_full * j_full < 150e9:
+            on_device = reference_style_on_device(O, ob, oc, x, y, z, ls, mk, j_full)
         how = ("measured at the full configuration, no extrapolation" if full else
                f"sub-sample N={n_s} of {n_full}, J={j_s} of {j_full}; scaled by the step's flop ratio x{scale:.2f} to "
                f"{t_full:.1f} s/step (the full step would take minutes of host time)")
@@ -165,11 +168,69 @@ def cpu_baseline(cfg, x, z, y, ls, lam_all, vec_all):
             "cores": cores,
             "kind": "port",
             "extrapolated": not full,
+            "reference_style_torch_rocm": on_device,
             "sample": f"oracle step (reference op order incl. per-step eigh(I) noise, full N x J F and G) at N={n_s}, J={j_s}: "
                       f"1 warm-up + {reps} timed steps, {t_s:.2f} s/step, peak RSS {rss_gb:.1f} GB; {how}",
         }
     finally:
         torch.set_default_dtype(prev)
+
+
+def reference_style_on_device(O, ob, oc, x, y, z, ls, mk, j, dev=None):
+    """What the reference's own ``.cuda()`` branches would do on this GPU (SURVEY 8d "reference-style torch-on-ROCm"): the
+    oracle's step with its operands resident on the device, i.e. torch's rocBLAS matmuls in the reference's association,
+    the full N x J F and G, the dense diag(1/lam) @ U -- and the noise exactly as samplers.py:27-44 makes it: eigh(I) and
+    torch.normal on the HOST, then copied over.  Reported next to the CPU baseline; never part of ``value``."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if dev is None else dev
+    n = x.shape[0]
+    sync = torch.cuda.synchronize if dev.type == "cuda" else (lambda: None)
+    try:
+        kern = O.RBFARDKernel(ls.to(dev), 1.0)
+        ob.base_gram_induce_train = torch.empty(z.shape[0], n, device=dev)
+        zd, xd = z.to(dev), x.to(dev)
+        for r0 in range(0, n, 16384):
+            ob.base_gram_induce_train[:, r0:r0 + 16384] = kern(zd, xd[r0:r0 + 16384])
+        ob.eigenvalues, ob.eigenvectors = ob.eigenvalues.to(dev), ob.eigenvectors.to(dev)
+        ob.scaled_eigenvectors = ob.scaled_eigenvectors.to(dev)
+        oc.y_train = y[:n].to(dev)
+        pls = O.PLS(ob, oc)
+        u = torch.randn(mk, j, generator=torch.Generator().manual_seed(3)).to(dev)
+
+        def noise():  # samplers.py:27-44 under torch.cuda.is_available(): host eigh + host normals, products on the device
+            lam, q = torch.linalg.eigh(torch.eye(mk))
+            xi = torch.normal(mean=0.0, std=1.0, size=(mk, j))
+            lam, q, xi = torch.clip(lam, 0, None).to(dev), q.to(dev), xi.to(dev)
+            return torch.real(q @ torch.diag(torch.sqrt(lam)) @ xi)
+
+        def one(with_noise: bool):
+            e = noise() if with_noise else torch.zeros(mk, j, device=dev)
+            u.add_(pls.calculate_particle_update(u, 1e-12, noise=e))
+
+        one(True)
+        sync()
+        reps = 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            one(True)
+        sync()
+        t_step = (time.perf_counter() - t0) / reps
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            one(False)
+        sync()
+        t_dev = (time.perf_counter() - t0) / reps
+        log(f"reference-style torch-on-ROCm step: {t_step * 1e3:.1f} ms ({t_dev * 1e3:.1f} ms without the host-side noise)")
+        return {"value": 1.0 / t_step, "unit": "steps/s", "ms_per_step": t_step * 1e3,
+                "ms_per_step_device_part": t_dev * 1e3,
+                "note": "oracle step with operands on the GPU (torch matmuls = rocBLAS, reference association, full N x J F "
+                        "and G) + the reference's sampler (host eigh(I), host torch.normal, H2D copy); "
+                        f"{reps} timed steps after 1 warm-up"}
+    except Exception as exc:  # a comparator only: never fail the bench line over it
+        log(f"reference-style torch-on-ROCm variant failed: {exc!r}")
+        return {"value": None, "error": repr(exc)}
+    finally:
+        if dev.type == "cuda":
+            torch.cuda.empty_cache()
 
 
 def self_launch(n_ranks: int) -> int:
@@ -575,6 +636,9 @@ def main():
         lam_all, vec_all = basis.eigenvalues.cpu(), basis.eigenvectors.cpu()
         out["cpu_baseline"] = cpu_baseline(cfg, x, z, y, ls, lam_all, vec_all)
         out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        ref_dev = out["cpu_baseline"].get("reference_style_torch_rocm")
+        if ref_dev and ref_dev.get("value"):
+            out["gpu_over_reference_style_torch_rocm"] = value / ref_dev["value"]
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist.is_initialized():

@@ -125,9 +125,7 @@ __global__ __launch_bounds__(256, 2) void small_rank_kernel(SmallRankP p) {
         const_cast<double *>(p.y + n0), 0, (int)(left * 8 < 0x7FFFFF00 ? left * 8 : 0x7FFFFF00), 0x00020000);
 #pragma unroll
     for (int i = 0; i < NLOAD; ++i) {
-      sr_double2_t v = __builtin_bit_cast(sr_double2_t, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[i], 0, 0));
-      v.y = half[i] ? 0.0 : v.y;
-      stage[i] = v;
+      stage[i] = __builtin_bit_cast(sr_double2_t, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[i], 0, 0));
     }
     ystage = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(ry, yoff, 0, 0));
 #else
@@ -139,7 +137,11 @@ __global__ __launch_bounds__(256, 2) void small_rank_kernel(SmallRankP p) {
     for (int i = 0; i < NLOAD; ++i) {
       const int e = tid + 256 * i;
       const int row = e / (KP / 2), m = 2 * (e % (KP / 2));
-      *reinterpret_cast<sr_double2_t *>(tile_of(buf) + row * STR + m) = stage[i];
+      // (the padding fix-up lives HERE, behind the second contraction: next to the load it made the wave wait for the
+      // tile it had just requested before it could issue that contraction's MFMAs)
+      sr_double2_t v = stage[i];
+      v.y = half[i] ? 0.0 : v.y;
+      *reinterpret_cast<sr_double2_t *>(tile_of(buf) + row * STR + m) = v;
     }
     if (tid < SR_ROWS) ys_of(buf)[tid] = ystage;
   };
@@ -152,6 +154,15 @@ __global__ __launch_bounds__(256, 2) void small_rank_kernel(SmallRankP p) {
     const double *Y = ys_of(buf);
     // first contraction: both 16-row blocks interleaved (two independent accumulator chains)
     sr_double4_t f0{0.0, 0.0, 0.0, 0.0}, f1{0.0, 0.0, 0.0, 0.0};
+    // the tile's targets for this lane's 8 rows, fetched ahead of the first contraction (KB <= 6: registers allow it);
+    // read next to their use, each pair cost a full LDS round trip in front of the per-element code
+    double yv[2][4];
+    if constexpr (KB <= 6) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) yv[b][r] = Y[16 * b + q + 4 * r];
+    }
     {
       const double *a0p = T + c * STR + q, *a1p = T + (16 + c) * STR + q;
       // only the last three k-quads of the padded rank can be empty (rank 89: 23 quads of 24); a wave-uniform skip
@@ -202,14 +213,14 @@ __global__ __launch_bounds__(256, 2) void small_rank_kernel(SmallRankP p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = 16 * b + q + 4 * r;
-        const double yv = Y[row];
+        const double yr = (KB <= 6) ? yv[b][r] : Y[row];
         const bool valid = !LAST || (n0 + row < nend);
         if (MODE != SR_MODE_DRIFT) {
-          const double cval = cost_value(cp, yv, f[r]);
+          const double cval = cost_value(cp, yr, f[r]);
           vsum += valid ? cval : 0.0;
         }
         if (MODE != SR_MODE_VALUE) {
-          const double gval = cost_deriv(cp, yv, f[r]);
+          const double gval = cost_deriv(cp, yr, f[r]);
           f[r] = valid ? gval : 0.0;
         }
       }
