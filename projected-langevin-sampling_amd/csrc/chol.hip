@@ -180,232 +180,303 @@ struct StripArgs {
   int64_t m, j;
 };
 
-// One block row of a substitution:  acc(128 x 32) = sum_{k in [kbeg, kend)} S[k][i0 + i] * R[k][j0 + j], where R is Rlo
-// for k < ksw and Rhi for k >= ksw (forward: the rows already solved come from V, the block's own rows from U).
-struct RowCtx {
-  const double *S;
+// ---- the strip solve as ONE pipeline of tiles ------------------------------------------------------------------------
+// A block row of a substitution is  acc(128 x 32) = sum_k S[k][i0 + i] R[k][j0 + j]  over 128-row tiles of the strip's
+// rows R.  Every tile but one holds rows that were final long ago (the right-hand side U, or blocks of V solved at least
+// one block row earlier); the exception is the block the PREVIOUS block row has just produced.  The order of the sum is
+// free, so every row takes that newest block LAST, and takes it from LDS: a row that finishes writes its 128 x 32 result
+// to global memory (output, and operand of the rows after the next) and into a hand-over tile in LDS in the R-tile
+// layout.  The rows then chain without a bubble: while the hand-over of row s travels, row s + 1 is already contracting
+// its old tiles; nobody waits for a global store to complete (the round-1/early-round-2 kernel drained its stores and
+// re-read them through L1 at every block row: 5.4 us x 16 rows of a 0.41 ms solve at M = 1024).  The only true
+// dependency left is the forward -> backward turn, where the first backward row needs the last forward block at once.
+//
+//   forward  row b:  [U block b]  [V blocks 0 .. b-2]        [hand-over: y_(b-1)]
+//   backward row b:  [V block b (y_b; the hand-over itself for the first backward row)]  [V blocks b+2 ..]  [hand-over: v_(b+1)]
+//
+// One tile = four 32-deep sub-steps.  All operands of a sub-step are requested one sub-step ahead: the A fragments (the
+// operator S, not shared between the waves: straight from global memory / L2 into the MFMA operand registers) and the B
+// fragments (LDS -> registers, double-buffered: 64 VGPRs); the next tile's rows are requested at sub-step 0, written to
+// LDS after sub-step 1 and handed over by the tile's only barrier after sub-step 2, so that sub-step 3 can already fetch
+// the next tile's first fragments.  The tile body has no branch: a tile without a global source (hand-over, end of the
+// solve) loads through a descriptor of range 0 (zeros, no traffic) into an R buffer nobody reads.
+// LDS: 2 R tiles + 2 hand-over tiles of 128 x 32 doubles = 128 KB; element (r, c) of a tile sits at
+// r * 32 + (c ^ ((r & 1) << 4)) -- odd rows swap their 16-column halves, which makes the B-fragment reads (4 rows x 16
+// columns per wave-instruction) conflict-free without row padding.
+[[maybe_unused]] constexpr int TS_NQ = TS_BK / 4;        // k-quads per sub-step
+[[maybe_unused]] constexpr int TS_NSUB = TS_RK / TS_BK;  // sub-steps per R tile
+constexpr int TS_TILE = TS_RK * TS_SC;  // doubles per LDS tile
+#ifndef PLS_STRIP_AD
+#define PLS_STRIP_AD 1
+#endif
+[[maybe_unused]] constexpr int TS_AD = PLS_STRIP_AD;     // sub-steps between the request of an A fragment and its MFMAs (1 or 2)
+
+struct TileDesc {  // wave-uniform
+  const double *S;  // first operator row of the tile (S + k0 * lds); range 0 = no tile
   int64_t lds;
-  const double *Rlo;
-  int64_t ldlo;
-  const double *Rhi;
-  int64_t ldhi;
-  int64_t ksw, kbeg, kend, i0;
+  int s_bytes;      // descriptor range of S from that row (0: every load returns zero)
+  int64_t i0;       // first output row of the block row
+  const double *R;  // first row of the tile in global memory, NULL = hand-over tile (or no tile)
+  int64_t ldr;
+  int r_bytes;
+  int r_is_u;       // R points into U (its leading dimension selects the lane offsets)
+  int hbuf;         // hand-over buffer (R == NULL)
+  int s, t;         // block-row sequence number (0 .. 2 nb - 1) and tile index inside it
+  int first, last, valid;
 };
 
-__device__ __forceinline__ RowCtx fwd_row(const StripArgs &a, int64_t b) {
-  const int64_t i0 = b * TS_NB;
-  return RowCtx{a.Sf, a.ldsf, a.V, a.ldv, a.U, a.ldu, i0, 0, (i0 + TS_NB < a.m) ? i0 + TS_NB : a.m, i0};
-}
-__device__ __forceinline__ RowCtx bwd_row(const StripArgs &a, int64_t b) {
-  const int64_t i0 = b * TS_NB;
-  return RowCtx{a.Sb, a.ldsb, a.V, a.ldv, a.V, a.ldv, 0, i0, a.m, i0};
+__device__ __forceinline__ int clamp_range(int64_t bytes) {
+  return (int)(bytes < 0 ? 0 : (bytes < 0x7FFFFF00 ? bytes : 0x7FFFFF00));
 }
 
-constexpr int TS_NQ = TS_BK / 4;       // k-quads per sub-step
-constexpr int TS_NSUB = TS_RK / TS_BK;  // sub-steps per R tile
+__device__ __forceinline__ TileDesc make_tile(const StripArgs &a, int nb, int nrows, int s, int t) {
+  TileDesc d;
+  d.s = s;
+  d.t = t;
+  d.valid = s < nrows;
+  d.R = nullptr;
+  d.ldr = a.ldv;
+  d.r_bytes = 0;
+  d.r_is_u = 0;
+  d.hbuf = (s + 1) & 1;
+  d.S = a.Sf;
+  d.lds = a.ldsf;
+  d.s_bytes = 0;
+  d.i0 = 0;
+  d.first = (t == 0);
+  d.last = 1;
+  if (!d.valid) return d;
+  int64_t k0, kend;
+  bool handover;
+  int nt;
+  if (s < nb) {  // forward row b = s
+    const int b = s;
+    d.i0 = (int64_t)b * TS_NB;
+    nt = b + 1;
+    kend = (d.i0 + TS_NB < a.m) ? d.i0 + TS_NB : a.m;
+    handover = (t >= 1 && t == nt - 1);
+    if (t == 0) {
+      k0 = d.i0;
+      d.r_is_u = 1;
+    } else {
+      k0 = (int64_t)(handover ? b - 1 : t - 1) * TS_NB;
+    }
+  } else {  // backward row b
+    const int b = 2 * nb - 1 - s;
+    d.i0 = (int64_t)b * TS_NB;
+    nt = nb - b;
+    kend = a.m;
+    d.S = a.Sb;
+    d.lds = a.ldsb;
+    handover = (t == nt - 1);  // (the first backward row's only tile is the hand-over of the last forward row)
+    k0 = (int64_t)(t == 0 ? b : (handover ? b + 1 : b + 1 + t)) * TS_NB;
+  }
+  d.last = (t == nt - 1);
+  d.S = d.S + k0 * d.lds;
+  d.s_bytes = clamp_range((kend - k0) * d.lds * 8);
+  if (!handover) {
+    d.ldr = d.r_is_u ? a.ldu : a.ldv;
+    d.R = (d.r_is_u ? a.U : a.V) + k0 * d.ldr;
+    d.r_bytes = clamp_range((kend - k0) * d.ldr * 8);
+  }
+  return d;
+}
 
-// Operand registers that live across block rows: the A fragments of the next sub-step and the next R tile.
-struct StripRegs {
-  double afr[2][TS_NQ];
-  double2v rreg[TS_NSUB];
-};
-
-// 8 waves: wave w owns rows [16 w, 16 w + 16) x the strip's 32 columns (one A fragment, two B fragments, two MFMAs per
-// k-quad); two waves per SIMD, so one wave's LDS / memory waits sit under the other's MFMAs.
-//   * The A operand (the substitution operator S) is NOT shared between the waves -- each owns different output rows --
-//     so it never touches LDS: lane l fetches S[k0 + 4 kq + (l >> 4)][i0 + 16 w + (l & 15)] straight into the MFMA
-//     operand register (16 consecutive doubles per lane group: four 128-byte segments per wave-instruction), one
-//     32-deep sub-step ahead.  (Staged through LDS it cost 32 KB of ds_write per 32 rows.)
-//   * The B operand (the strip's rows of R) is shared by all eight waves and goes through LDS in tiles of TS_RK = 128
-//     rows (32 KB, double-buffered): ONE barrier per 128 rows of the contraction, 64 MFMAs per wave between barriers.
-//   * Addressing costs no vector instruction in the k-loop (every VALU instruction is paid in matrix-pipe issue slots):
-//     buffer loads with a descriptor whose base is the first row of the piece (two scalar adds), the row inside it as a
-//     scalar offset, and ONE loop-invariant lane offset.  The descriptor's range ends at row kend, so rows past the end
-//     of the contraction (the K tail of a matrix whose size is not a multiple of 128) read as zero without a branch.  A
-//     column past the matrix edge is CLAMPED, not zeroed: column i of S only ever reaches output row i, column j of R
-//     output column j, and the store drops rows >= m and columns >= j.
-//   * `have_first`: the row's first R tile and A fragments are already in `regs` (the previous row fetched them under its
-//     last MFMAs); `next`: the row whose first tile THIS row fetches under its last MFMAs (NULL: none -- the caller
-//     passes it only when that tile does not overlap the rows this row is about to store).
-// VEC (workgroup-uniform, chosen by the caller): a full strip -> one 16-byte load per R pair.
-// next_kind: 0 none, 1 forward row next_b, 2 backward row next_b (its RowCtx is only built where it is used, at the last
-// tile of this row: held across the k-loop the second set of pointers and strides spilled 33 scalar registers)
 // Workgroup barrier that orders LDS traffic only: s_waitcnt lgkmcnt(0) + s_barrier.  __syncthreads() also drains the
-// wave's global loads and stores (vmcnt(0)) -- right for handing over rows of V, wrong inside the k-loop, where the loads
-// in flight are the NEXT sub-step's operand fragments.
+// wave's global loads and stores (vmcnt(0)): used once per block row, at its first tile, where it makes the previous
+// row's stores to V visible to the whole workgroup long before anyone loads them.
 __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// V = L^-T L^-1 U for one strip of TS_SC columns (fwd_only: V = L^-1 U).  8 waves; wave w owns rows [16 w, 16 w + 16) of
+// every block row x the strip's 32 columns (one A fragment, two B fragments, two MFMAs per k-quad).
+// VEC (workgroup-uniform, chosen by the caller): a full strip -> one 16-byte load per R pair.
 template <bool VEC>
-__device__ __forceinline__ void strip_block_row(const StripArgs &a, const RowCtx c, bool have_first, int next_kind,
-                                                int64_t next_b, int64_t j0, double *lds, StripRegs &regs,
-                                                double4v (&acc)[2]) {
-  const int64_t m = a.m, j = a.j;
-  constexpr int SR = TS_SC + 16;
+__device__ __forceinline__ void strip_solve(const StripArgs &a, int fwd_only, int64_t j0, double *lds) {
+#if defined(__HIP_DEVICE_COMPILE__)
   constexpr int NQ = TS_NQ, NSUB = TS_NSUB;
-  static_assert(TS_BK == 32 && TS_RK == 128 && (NSUB % 2) == 0, "sub-step parity = A-fragment buffer");
-  double *Rs = lds;  // [2][TS_RK][SR]
+  static_assert(TS_BK == 32 && TS_RK == 128 && NSUB == 4 && TS_SC == 32, "tile geometry is wired into the pipeline below");
+  const int64_t m = a.m, j = a.j;
+  const int nb = (int)((m + TS_NB - 1) / TS_NB);
+  const int nrows = fwd_only ? nb : 2 * nb;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = lane >> 4, c16 = lane & 15;
-  const int rrow = tid >> 4, lcr = (tid & 15) * 2;  // R tile: 4 passes of 32 rows x 16 threads x 2 doubles
+  double *const Rs = lds;                 // [2][TS_TILE]
+  double *const Hs = lds + 2 * TS_TILE;   // [2][TS_TILE]
+  // R tile staging: 4 passes of 32 rows x 16 threads x 2 doubles
+  const int rrow = tid >> 4, lcr = (tid & 15) * 2;
+  const int64_t cj0 = j0 + lcr;
+  const int64_t cr0 = (cj0 < j) ? cj0 : 0, cr1 = (cj0 + 1 < j) ? cj0 + 1 : 0;  // (a column past the edge is clamped, its results dropped)
+  const int v0u = (int)((rrow * a.ldu + cr0) * 8), v1u = (int)((rrow * a.ldu + cr1) * 8);
+  const int v0v = (int)((rrow * a.ldv + cr0) * 8), v1v = (int)((rrow * a.ldv + cr1) * 8);
+  const int st_off = rrow * TS_SC + (lcr ^ ((rrow & 1) << 4));  // + p * 32 rows: the row parity does not change
+  // B fragments: rows 4 kq + q of a sub-step, columns c16 and 16 + c16 (swapped in odd rows)
+  const int bo0 = q * TS_SC + ((q & 1) << 4) + c16, bo1 = q * TS_SC + (16 ^ ((q & 1) << 4)) + c16;
+
+  double afr[NSUB][NQ];  // A fragments of sub-step s of the tile in flight (requested TS_AD sub-steps ahead)
+  double bq[2][NQ][2];
+  double2v rreg[NSUB];
+  double4v acc[2];
   acc[0] = double4v{0.0, 0.0, 0.0, 0.0};
   acc[1] = double4v{0.0, 0.0, 0.0, 0.0};
-  const int64_t cj0 = j0 + lcr;
-  const int64_t cr0 = (cj0 < j) ? cj0 : 0, cr1 = (cj0 + 1 < j) ? cj0 + 1 : 0;
-  auto clamp = [](int64_t bytes) { return (int)(bytes < 0 ? 0 : (bytes < 0x7FFFFF00 ? bytes : 0x7FFFFF00)); };
-  auto load_a = [&](const RowCtx &x, int64_t k0, int nxt) {  // A fragments of the 32-deep sub-step that starts at row k0
-#if defined(__HIP_DEVICE_COMPILE__)
-    const int64_t ca = (x.i0 + wave * 16 + c16 < m) ? x.i0 + wave * 16 + c16 : 0;
-    const int voff_a = (int)((q * x.lds + ca) * 8);
-    const int row4 = (int)(x.lds * 32);  // bytes per 4 rows of S
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(x.S + k0 * x.lds), 0,
-                                                                       clamp((x.kend - k0) * x.lds * 8), 0x00020000);
+
+  auto a_voff = [&](const TileDesc &d) {  // lane offset of the A fragments of a block row: S[.. + q][i0 + 16 w + c16]
+    const int64_t ca = (d.i0 + wave * 16 + c16 < m) ? d.i0 + wave * 16 + c16 : 0;
+    return (int)((q * d.lds + ca) * 8);
+  };
+  auto load_a = [&](const TileDesc &d, int voff, auto sub_tag) {  // sub-step `sub` of tile d -> afr[sub]
+    constexpr int sub = decltype(sub_tag)::value;
+#if !defined(PLS_STRIP_ABL_NOA)
+    const __amdgpu_buffer_rsrc_t ra =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(d.S), 0, d.s_bytes, 0x00020000);
+    const int row4 = (int)(d.lds * 32);  // bytes per 4 rows of S
+    const int sub_off = sub * TS_BK * (int)(d.lds * 8);
 #pragma unroll
     for (int kq = 0; kq < NQ; ++kq)
-      regs.afr[nxt][kq] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(ra, voff_a, kq * row4, 0));
+      afr[sub][kq] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(ra, voff, sub_off + kq * row4, 0));
 #else
-    (void)x, (void)k0, (void)nxt;
+    (void)d, (void)voff;
 #endif
   };
-  auto load_r = [&](const RowCtx &x, int64_t k0) {  // the 128-row R tile at row k0 (never straddles ksw: both multiples of 128)
-#if defined(__HIP_DEVICE_COMPILE__)
-    const bool hi = k0 >= x.ksw;
-    const int64_t ldr = hi ? x.ldhi : x.ldlo;
-    const double *rbase = hi ? x.Rhi + k0 * x.ldhi : x.Rlo + k0 * x.ldlo;
+  auto load_r = [&](const TileDesc &d) {
+#if defined(PLS_STRIP_ABL_NOR)
+    return;
+#endif
     const __amdgpu_buffer_rsrc_t rr =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(rbase), 0, clamp((x.kend - k0) * ldr * 8), 0x00020000);
-    const int v0 = (int)((rrow * ldr + cr0) * 8), v1 = (int)((rrow * ldr + cr1) * 8);
-    const int pass = (int)(ldr * 8 * TS_BK);  // bytes per 32 rows
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(d.R ? d.R : a.V), 0, d.r_bytes, 0x00020000);
+    const int v0 = d.r_is_u ? v0u : v0v, v1 = d.r_is_u ? v1u : v1v;
+    const int pass = (int)(d.ldr * 8 * TS_BK);  // bytes per 32 rows
 #pragma unroll
     for (int p = 0; p < NSUB; ++p) {
       if constexpr (VEC) {
-        regs.rreg[p] = __builtin_bit_cast(double2v, __builtin_amdgcn_raw_buffer_load_b128(rr, v0, p * pass, 0));
+        rreg[p] = __builtin_bit_cast(double2v, __builtin_amdgcn_raw_buffer_load_b128(rr, v0, p * pass, 0));
       } else {
-        regs.rreg[p].x = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rr, v0, p * pass, 0));
-        regs.rreg[p].y = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rr, v1, p * pass, 0));
+        rreg[p].x = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rr, v0, p * pass, 0));
+        rreg[p].y = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rr, v1, p * pass, 0));
       }
     }
-#else
-    (void)x, (void)k0, (void)cr0, (void)cr1;
+    (void)v1;
+  };
+  auto store_r = [&](double *tile) {
+#if defined(PLS_STRIP_ABL_NOR)
+    return;
 #endif
-  };
-  auto store_r = [&](int buf) {
 #pragma unroll
-    for (int p = 0; p < NSUB; ++p)
-      *reinterpret_cast<double2v *>(Rs + (buf * TS_RK + p * TS_BK + rrow) * SR + lcr) = regs.rreg[p];
+    for (int p = 0; p < NSUB; ++p) *reinterpret_cast<double2v *>(tile + p * TS_BK * TS_SC + st_off) = rreg[p];
   };
-  auto compute = [&](int rbuf, int sub, auto abuf_tag) {
-    constexpr int abuf = decltype(abuf_tag)::value;
-    // ALL B fragments of the sub-step are fetched in one burst (16 ds_read_b64, 32 VGPRs) and the MFMAs wait on them with
-    // counted lgkmcnt; the fences keep the scheduler from sinking every read to just before its MFMA pair, and from
-    // hoisting what follows (the next tile's ds_write + barrier) above these MFMAs.
-    const double *r = Rs + (rbuf * TS_RK + sub * TS_BK + q) * SR + c16;
-    double b[NQ][2];
+  auto read_b = [&](const double *tile, int sub, auto buf_tag) {
+    constexpr int buf = decltype(buf_tag)::value;
+#if defined(PLS_STRIP_ABL_NOB)
+    return;
+#endif
+    const double *r0 = tile + sub * TS_BK * TS_SC + bo0, *r1 = tile + sub * TS_BK * TS_SC + bo1;
 #pragma unroll
     for (int kq = 0; kq < NQ; ++kq) {
-      b[kq][0] = r[kq * 4 * SR];
-      b[kq][1] = r[kq * 4 * SR + 16];
+      bq[buf][kq][0] = r0[kq * 4 * TS_SC];
+      bq[buf][kq][1] = r1[kq * 4 * TS_SC];
     }
-    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto mfmas = [&](auto sub_tag) {  // sub-step `sub`: A fragments afr[sub], B fragments bq[sub & 1]
+    constexpr int sub = decltype(sub_tag)::value, buf = sub & 1;
+    __builtin_amdgcn_sched_barrier(0);  // (operand requests stay in front of the MFMAs, what follows stays behind them)
 #pragma unroll
     for (int kq = 0; kq < NQ; ++kq) {
-      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(regs.afr[abuf][kq], b[kq][0], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(regs.afr[abuf][kq], b[kq][1], acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[sub][kq], bq[buf][kq][0], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[sub][kq], bq[buf][kq][1], acc[1], 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
   };
-  const int64_t nsup = (c.kend - c.kbeg + TS_RK - 1) / TS_RK;
-  if (!have_first) {
-    load_r(c, c.kbeg);
-    load_a(c, c.kbeg, 0);
-  }
-  store_r(0);
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+  using S3 = std::integral_constant<int, 3>;
+  constexpr bool AD2 = (TS_AD == 2);  // A fragments requested two sub-steps ahead (one otherwise)
+
+  // ---- prime: the first tile of the solve (forward row 0: rows 0 .. 127 of U) ----
+  TileDesc cur = make_tile(a, nb, nrows, 0, 0);
+  int voff_cur = a_voff(cur);
+  load_r(cur);
+  load_a(cur, voff_cur, S0{});
+#if defined(PLS_STRIP_ABL_NOA)
+  for (int sb = 0; sb < NSUB; ++sb)
+    for (int kq = 0; kq < NQ; ++kq) afr[sb][kq] = 1e-3 * (lane + kq + sb);
+#endif
+  if constexpr (AD2) load_a(cur, voff_cur, S1{});
+  store_r(Rs);
   __syncthreads();
-  // the steady state (every tile but the row's last) is its own loop: no test for the row's end, no second row context
-  int64_t sup = 0;
-  for (; sup + 1 < nsup; ++sup) {
-    const int rbuf = (int)(sup & 1);
-    const int64_t k0 = c.kbeg + sup * TS_RK;
-    load_r(c, k0 + TS_RK);
-    // four sub-steps, A fragments one sub-step ahead
-    load_a(c, k0 + TS_BK, 1);
-    compute(rbuf, 0, std::integral_constant<int, 0>{});
-    load_a(c, k0 + 2 * TS_BK, 0);
-    compute(rbuf, 1, std::integral_constant<int, 1>{});
-    load_a(c, k0 + 3 * TS_BK, 1);
-    compute(rbuf, 2, std::integral_constant<int, 0>{});
-    load_a(c, k0 + TS_RK, 0);
-    compute(rbuf, 3, std::integral_constant<int, 1>{});
-    store_r(rbuf ^ 1);
-    lds_barrier();  // (only the R tile is handed over here: the A fragments just requested keep flying across it)
-  }
-  {  // the row's last tile: the next block row's first tile and fragments fly under its 64 MFMAs
-    const int rbuf = (int)(sup & 1);
-    const int64_t k0 = c.kbeg + sup * TS_RK;
-    RowCtx nx = c;
-    if (next_kind) nx = next_kind == 1 ? fwd_row(a, next_b) : bwd_row(a, next_b);
-    if (next_kind) load_r(nx, nx.kbeg);
-    load_a(c, k0 + TS_BK, 1);  // (rows past kend read as zero)
-    compute(rbuf, 0, std::integral_constant<int, 0>{});
-    load_a(c, k0 + 2 * TS_BK, 0);
-    compute(rbuf, 1, std::integral_constant<int, 1>{});
-    load_a(c, k0 + 3 * TS_BK, 1);
-    compute(rbuf, 2, std::integral_constant<int, 0>{});
-    if (next_kind) load_a(nx, nx.kbeg, 0);
-    compute(rbuf, 3, std::integral_constant<int, 1>{});
-    __syncthreads();
-  }
-}
+  const double *curbuf = Rs;
+  read_b(curbuf, 0, B0{});
+#if defined(PLS_STRIP_ABL_NOB)
+  for (int bb = 0; bb < 2; ++bb)
+    for (int kq = 0; kq < NQ; ++kq) bq[bb][kq][0] = bq[bb][kq][1] = 1e-3 * (lane + kq);
+#endif
+  int gcount = 1;  // global tiles staged so far: the next one goes to Rs[gcount & 1]
 
-// acc -> V rows [i0, i0 + 128), columns [j0, j0 + 32): register (tb, r) of lane l is row 4 r + (l >> 4) of the wave's 16
-// rows, column 16 tb + (l & 15)
-__device__ __forceinline__ void strip_store(const double4v (&acc)[2], double *V, int64_t ldv, int64_t i0, int64_t j0,
-                                            int64_t m, int64_t j) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int q = lane >> 4, c16 = lane & 15;
+  for (;;) {
+    const TileDesc nxt = cur.last ? make_tile(a, nb, nrows, cur.s + 1, 0) : make_tile(a, nb, nrows, cur.s, cur.t + 1);
+    const int voff_nxt = cur.last ? a_voff(nxt) : voff_cur;
+    double *const nxt_rs = Rs + (gcount & 1) * TS_TILE;
+    const double *nxtbuf = nxt.R ? nxt_rs : Hs + nxt.hbuf * TS_TILE;
+    // sub-step 0: also request the next tile's rows (range 0 if it has none)
+    // (after the A fragments: the memory counter is in order, so rows requested BEFORE them would have to land before
+    // sub-step 1 may use its fragments -- one sub-step of latency budget instead of the two they have until store_r)
+    if constexpr (AD2) load_a(cur, voff_cur, S2{}); else load_a(cur, voff_cur, S1{});
+    load_r(nxt);
+    read_b(curbuf, 1, B1{});
+    mfmas(S0{});
+    // sub-step 1
+    if constexpr (AD2) load_a(cur, voff_cur, S3{}); else load_a(cur, voff_cur, S2{});
+    read_b(curbuf, 2, B0{});
+    mfmas(S1{});
+    store_r(nxt_rs);
+    // sub-step 2
+    if constexpr (AD2) load_a(nxt, voff_nxt, S0{}); else load_a(cur, voff_cur, S3{});
+    read_b(curbuf, 3, B1{});
+    mfmas(S2{});
+#if !defined(PLS_STRIP_ABL_NOBAR)
+    if (cur.first)
+      __syncthreads();  // once per block row: also completes this wave's stores of the previous row's block
+    else
+      lds_barrier();
+#endif
+    // sub-step 3: the next tile's first operands (a hand-over tile that this row is about to write is read again below)
+    if constexpr (AD2) load_a(nxt, voff_nxt, S1{}); else load_a(nxt, voff_nxt, S0{});
+    read_b(nxtbuf, 0, B0{});
+    mfmas(S3{});
+    if (cur.last) {  // the block row is complete: result -> global V and the hand-over tile
+      double *const hand = Hs + (cur.s & 1) * TS_TILE;
 #pragma unroll
-  for (int tb = 0; tb < 2; ++tb)
+      for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int64_t row = i0 + wave * 16 + 4 * r + q;
-      const int64_t col = j0 + tb * 16 + c16;
-      if (row < m && col < j) V[row * ldv + col] = acc[tb][r];
+        for (int r = 0; r < 4; ++r) {
+          const int lrow = wave * 16 + 4 * r + q;
+          const int64_t row = cur.i0 + lrow, col = j0 + tb * 16 + c16;
+          const bool rin = row < m;
+          const double v = rin ? acc[tb][r] : 0.0;  // (rows past the matrix must be ZERO in the hand-over: 0 * garbage)
+          hand[lrow * TS_SC + ((tb * 16) ^ ((q & 1) << 4)) + c16] = v;
+          if (rin && col < j) a.V[row * a.ldv + col] = v;
+        }
+      acc[0] = double4v{0.0, 0.0, 0.0, 0.0};
+      acc[1] = double4v{0.0, 0.0, 0.0, 0.0};
+      if (nxt.valid && nxt.R == nullptr) {  // the turn: the next row starts with the block just written
+        lds_barrier();
+        read_b(nxtbuf, 0, B0{});
+      }
     }
-}
-
-// V = L^-T L^-1 U for one strip of TS_SC columns: forward block rows 0 .. nb-1 (reads U, writes V), then backward block
-// rows nb-1 .. 0 in place.  The strip is private to the workgroup: its earlier stores are ordered before the later
-// loads by a workgroup barrier (all waves of a workgroup share the CU's L1).  A row fetches the next row's first operands
-// under its own last MFMAs whenever they cannot be rows it is about to store: forward from row 1 on (the next row starts
-// at rows 0..127 of V), backward always (the next row starts one block above); not from forward row 0, and not across the
-// forward -> backward turn, whose first tile is exactly the block just solved.
-// fwd_only != 0 stops after the forward solve (V = L^-1 U).
-template <bool VEC>
-__device__ __forceinline__ void strip_solve(const StripArgs &a, int fwd_only, int64_t j0, double *lds) {
-  const int64_t nb = (a.m + TS_NB - 1) / TS_NB;
-  StripRegs regs;
-  double4v acc[2];
-  bool have = false;
-  for (int64_t b = 0; b < nb; ++b) {
-    const RowCtx c = fwd_row(a, b);
-    const bool pre = b >= 1 && b + 1 < nb;
-    strip_block_row<VEC>(a, c, have, pre ? 1 : 0, b + 1, j0, lds, regs, acc);
-    strip_store(acc, a.V, a.ldv, c.i0, j0, a.m, a.j);
-    have = pre;
-    if (!pre) __syncthreads();  // (drains the stores: the next row's first loads read them)
+    if (!nxt.valid) break;
+    if (nxt.R) ++gcount;
+    cur = nxt;
+    voff_cur = voff_nxt;
+    curbuf = nxtbuf;
   }
-  if (fwd_only) return;
-  for (int64_t b = nb - 1; b >= 0; --b) {
-    const RowCtx c = bwd_row(a, b);
-    const bool pre = b >= 1;
-    strip_block_row<VEC>(a, c, have, pre ? 2 : 0, b - 1, j0, lds, regs, acc);
-    strip_store(acc, a.V, a.ldv, c.i0, j0, a.m, a.j);
-    have = pre;
-    if (!pre) __syncthreads();
-  }
+#else
+  (void)a, (void)fwd_only, (void)j0, (void)lds;
+#endif
 }
 
 __global__ __launch_bounds__(512) void tri_solve_strip_kernel(StripArgs a, int fwd_only) {
@@ -420,7 +491,7 @@ __global__ __launch_bounds__(512) void tri_solve_strip_kernel(StripArgs a, int f
     strip_solve<false>(a, fwd_only, j0, lds);
 }
 
-static size_t strip_lds_bytes() { return (size_t)2 * TS_RK * (TS_SC + 16) * sizeof(double); }
+static size_t strip_lds_bytes() { return (size_t)4 * TS_TILE * sizeof(double); }
 
 int chol_solve_launch(const pls_chol_desc *f, const double *U, int64_t ldu, int64_t j, double *V, int64_t ldv,
                       int fwd_only, hipStream_t st) {

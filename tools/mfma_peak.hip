@@ -47,6 +47,6 @@ void run(int blocks_per_cu, int threads) {
 int main() {
   run<16>(1, 256); run<16>(2, 256); run<16>(4, 256);
   run<4>(1, 256); run<4>(2, 256);
-  run<1>(1, 256); run<1>(2, 256); run<2>(1, 256);
+  run<1>(1, 256); run<1>(2, 256); run<2>(1, 256); run<2>(2, 256); run<2>(4, 256); run<8>(1, 256); run<8>(2, 256);
   return 0;
 }
