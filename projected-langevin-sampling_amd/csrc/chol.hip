@@ -341,31 +341,48 @@ __device__ __forceinline__ void strip_solve(const StripArgs &a, int fwd_only, in
     (void)d, (void)voff;
 #endif
   };
-  auto load_r = [&](const TileDesc &d) {
+  // The next tile's rows.  Full strips (VEC) go global -> LDS directly (LDS-DMA, `buffer_load_dwordx4 ... lds`): one
+  // wave-instruction deposits 1 KiB = 4 rows of the tile, lane l the 16 bytes at position l -- so the lane picks the
+  // global columns that BELONG at that position (the swizzle lives in its loop-invariant offset); no staging registers,
+  // no ds_write.  Completion needs no wait of its own: loads complete in order, and the A fragments of sub-step 2 are
+  // requested after these, so the MFMAs of sub-step 2 (which precede the tile's barrier) cannot start before the rows
+  // have landed.  Ragged strips go through registers.
+  typedef __attribute__((address_space(3))) void *lds_ptr_t;
+  const int dma_col = (2 * (lane & 15)) ^ (((lane >> 4) & 1) << 4);
+  const int dma_u = (int)(((lane >> 4) * a.ldu + j0 + dma_col) * 8), dma_v = (int)(((lane >> 4) * a.ldv + j0 + dma_col) * 8);
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  auto load_r = [&](const TileDesc &d, double *tile) {
 #if defined(PLS_STRIP_ABL_NOR)
     return;
 #endif
     const __amdgpu_buffer_rsrc_t rr =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(d.R ? d.R : a.V), 0, d.r_bytes, 0x00020000);
-    const int v0 = d.r_is_u ? v0u : v0v, v1 = d.r_is_u ? v1u : v1v;
-    const int pass = (int)(d.ldr * 8 * TS_BK);  // bytes per 32 rows
+    if constexpr (VEC) {
+      const int dv = d.r_is_u ? dma_u : dma_v;
+      const int grp = (int)(d.ldr * 32);  // bytes per 4 rows
 #pragma unroll
-    for (int p = 0; p < NSUB; ++p) {
-      if constexpr (VEC) {
-        rreg[p] = __builtin_bit_cast(double2v, __builtin_amdgcn_raw_buffer_load_b128(rr, v0, p * pass, 0));
-      } else {
+      for (int p = 0; p < NSUB; ++p) {
+        const int g = wave_u + 8 * p;  // 4-row group of the tile
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rr, (lds_ptr_t)(tile + g * 4 * TS_SC), 16, dv, g * grp, 0, 0);
+      }
+    } else {
+      const int v0 = d.r_is_u ? v0u : v0v, v1 = d.r_is_u ? v1u : v1v;
+      const int pass = (int)(d.ldr * 8 * TS_BK);  // bytes per 32 rows
+#pragma unroll
+      for (int p = 0; p < NSUB; ++p) {
         rreg[p].x = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rr, v0, p * pass, 0));
         rreg[p].y = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rr, v1, p * pass, 0));
       }
     }
-    (void)v1;
   };
   auto store_r = [&](double *tile) {
 #if defined(PLS_STRIP_ABL_NOR)
     return;
 #endif
+    if constexpr (!VEC) {
 #pragma unroll
-    for (int p = 0; p < NSUB; ++p) *reinterpret_cast<double2v *>(tile + p * TS_BK * TS_SC + st_off) = rreg[p];
+      for (int p = 0; p < NSUB; ++p) *reinterpret_cast<double2v *>(tile + p * TS_BK * TS_SC + st_off) = rreg[p];
+    }
   };
   auto read_b = [&](const double *tile, int sub, auto buf_tag) {
     constexpr int buf = decltype(buf_tag)::value;
@@ -400,7 +417,11 @@ __device__ __forceinline__ void strip_solve(const StripArgs &a, int fwd_only, in
   // ---- prime: the first tile of the solve (forward row 0: rows 0 .. 127 of U) ----
   TileDesc cur = make_tile(a, nb, nrows, 0, 0);
   int voff_cur = a_voff(cur);
-  load_r(cur);
+  // every tile starts from finite content: rows past the end of a contraction are never written by a range-checked
+  // load, and what they hold is multiplied by operator rows that read as zero
+  for (int e = tid; e < 4 * TS_TILE / 2; e += 512) reinterpret_cast<double2v *>(lds)[e] = double2v{0.0, 0.0};
+  __syncthreads();
+  load_r(cur, Rs);
   load_a(cur, voff_cur, S0{});
 #if defined(PLS_STRIP_ABL_NOA)
   for (int sb = 0; sb < NSUB; ++sb)
@@ -426,7 +447,7 @@ __device__ __forceinline__ void strip_solve(const StripArgs &a, int fwd_only, in
     // (after the A fragments: the memory counter is in order, so rows requested BEFORE them would have to land before
     // sub-step 1 may use its fragments -- one sub-step of latency budget instead of the two they have until store_r)
     if constexpr (AD2) load_a(cur, voff_cur, S2{}); else load_a(cur, voff_cur, S1{});
-    load_r(nxt);
+    load_r(nxt, nxt_rs);
     read_b(curbuf, 1, B1{});
     mfmas(S0{});
     // sub-step 1
