@@ -516,13 +516,8 @@ static size_t strip_lds_bytes() { return (size_t)4 * TS_TILE * sizeof(double); }
 
 int chol_solve_launch(const pls_chol_desc *f, const double *U, int64_t ldu, int64_t j, double *V, int64_t ldv,
                       int fwd_only, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tri_solve_strip_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)strip_lds_bytes());
-    if (e != hipSuccess) return fail(PLS_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> lds_ready{0};
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(tri_solve_strip_kernel), strip_lds_bytes(), lds_ready)) return rc;
   StripArgs a{f->Sf, f->Sb, f->ldsf, f->ldsb, U, ldu, V, ldv, f->m, j};
   {
     LaunchScope scope(PLS_TAG_TRI_SOLVE, st);
@@ -580,14 +575,9 @@ int pls_chol_build_operators(const double *Lc, int64_t ldlc, const double *LcT, 
   PLS_REQUIRE(m > 0 && ldlc >= m && ldlct >= m && ldsf >= m && ldsb >= m, "chol_build_operators: bad sizes");
   hipStream_t st = S(stream);
   int rc;
-  static bool attr_set = false;
   const size_t inv_lds = (size_t)(TS_NB * TS_NB + TS_NB) * sizeof(double);
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tri_block_inverse_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)inv_lds);
-    if (e != hipSuccess) return fail(PLS_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> lds_ready{0};
+  if (int rc2 = ensure_dynamic_lds(reinterpret_cast<const void *>(tri_block_inverse_kernel), inv_lds, lds_ready)) return rc2;
   const int64_t nbk = cdiv(m, TS_NB);
   hipLaunchKernelGGL(tri_block_inverse_kernel, dim3((unsigned)nbk), dim3(TS_NB), inv_lds, st, Lc, ldlc, m, Sf, ldsf, Sb, ldsb);
   rc = check_launch("tri_block_inverse");

@@ -2,7 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
+#include <cstdint>
 #include <cstdio>
 #include <string>
 #include <vector>
@@ -65,6 +67,20 @@ struct LaunchScope {  // records the bracketing events of one launch when the ti
     if (slot >= 0) (void)hipEventRecord(g_tl.ev[2 * slot + 1], st);
   }
 };
+
+// Kernels that need more than 64 KB of dynamic LDS must be told so once PER DEVICE (the attribute lives in the device's
+// copy of the code object); `done` is the per-kernel bit mask of devices already served.  One process per GPU is the
+// deployment model, but a process that drives several devices must not find the second one unprepared.
+inline int ensure_dynamic_lds(const void *kernel, size_t bytes, std::atomic<uint64_t> &done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  const uint64_t bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_relaxed) & bit) return PLS_OK;
+  hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return fail(PLS_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+  done.fetch_or(bit, std::memory_order_relaxed);
+  return PLS_OK;
+}
 
 static inline hipStream_t S(void *stream) { return reinterpret_cast<hipStream_t>(stream); }
 __host__ __device__ static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

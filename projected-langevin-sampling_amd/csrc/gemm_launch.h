@@ -18,13 +18,8 @@ static int launch_gemm_cfg(GemmShape g, const Epi &epi, hipStream_t st) {
   constexpr int NT = (BI / WI) * (BJ / WJ) * 64;
   constexpr size_t lds_bytes = (size_t)2 * BK * ((BI + 16) + (BJ + 16)) * sizeof(double);
   auto kern = gemm_tn_f64_kernel<BI, BJ, WI, WJ, BK, MINW, Epi>;
-  static bool attr_set = false;  // benign race: idempotent
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return fail(PLS_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> lds_ready{0};
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds_bytes, lds_ready)) return rc;
 #ifdef PLS_STAMP
   g.stamps = g_stamp_buffer;
 #endif

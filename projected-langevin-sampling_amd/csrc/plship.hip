@@ -1312,13 +1312,8 @@ int pls_row_quantiles(const double *samples, int64_t lds, int64_t rows, int64_t 
   int npad = 2;
   while (npad < cols) npad <<= 1;
   const size_t bytes = (size_t)npad * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(row_quantiles_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * (int)sizeof(double));
-    if (e != hipSuccess) return fail(PLS_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> lds_ready{0};
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(row_quantiles_kernel), 16384 * sizeof(double), lds_ready)) return rc;
   hipLaunchKernelGGL(row_quantiles_kernel, dim3((unsigned)rows), dim3(256), bytes, S(stream), samples, lds, cols, npad, q, (int)nq,
                      out, ldout);
   return check_launch("row_quantiles");
