@@ -1,7 +1,6 @@
 """Orthonormal basis (drop-in for src/projected_langevin_sampling/basis/orthonormal.py:10-244)."""
 from __future__ import annotations
 
-import math
 
 import torch
 

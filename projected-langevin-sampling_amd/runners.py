@@ -26,7 +26,7 @@ import numpy as np
 import torch
 
 from . import _ops
-from .basis.base import BlockSpec, NoiseSpec
+from .basis.base import BlockSpec
 from .metrics import calculate_mae, calculate_mse, calculate_nll
 from .projected_langevin_sampling import PLS
 from .trainers import EarlyStopper, train_pls
