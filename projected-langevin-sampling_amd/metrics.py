@@ -7,7 +7,6 @@ import math
 import torch
 
 from .conformalise import ConformalPrediction
-from .kernel import _dev
 
 
 def _point(prediction) -> torch.Tensor:
