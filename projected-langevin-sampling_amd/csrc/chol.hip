@@ -206,10 +206,9 @@ struct StripArgs {
 [[maybe_unused]] constexpr int TS_NQ = TS_BK / 4;        // k-quads per sub-step
 [[maybe_unused]] constexpr int TS_NSUB = TS_RK / TS_BK;  // sub-steps per R tile
 constexpr int TS_TILE = TS_RK * TS_SC;  // doubles per LDS tile
-#ifndef PLS_STRIP_AD
-#define PLS_STRIP_AD 1
+#ifndef PLS_STRIP_INTERLEAVE
+#define PLS_STRIP_INTERLEAVE 1  // 0: all operand requests of a sub-step in one burst ahead of its MFMAs (A/B builds)
 #endif
-[[maybe_unused]] constexpr int TS_AD = PLS_STRIP_AD;     // sub-steps between the request of an A fragment and its MFMAs (1 or 2)
 
 struct TileDesc {  // wave-uniform
   const double *S;  // first operator row of the tile (S + k0 * lds); range 0 = no tile
@@ -229,56 +228,53 @@ __device__ __forceinline__ int clamp_range(int64_t bytes) {
   return (int)(bytes < 0 ? 0 : (bytes < 0x7FFFFF00 ? bytes : 0x7FFFFF00));
 }
 
-__device__ __forceinline__ TileDesc make_tile(const StripArgs &a, int nb, int nrows, int s, int t) {
+struct RowState {  // wave-uniform; what the tiles of one block row share (computed once per row, not once per tile:
+  const double *S;   // the eight waves of a workgroup run this bookkeeping at the same moment on the CU's one scalar unit)
+  int64_t lds, kend, i0;
+  int nt, b, fwd, s, valid;
+};
+
+__device__ __forceinline__ RowState make_row(const StripArgs &a, int nb, int nrows, int s) {
+  RowState r;
+  r.s = s;
+  r.valid = s < nrows;
+  r.fwd = s < nb;
+  r.b = r.fwd ? s : 2 * nb - 1 - s;
+  if (!r.valid) r.b = 0;  // (past the last row: a well-formed descriptor of range 0, never a negative row offset)
+  r.i0 = (int64_t)r.b * TS_NB;
+  r.nt = r.fwd ? r.b + 1 : nb - r.b;
+  r.S = r.fwd ? a.Sf : a.Sb;
+  r.lds = r.fwd ? a.ldsf : a.ldsb;
+  const int64_t kf = (r.i0 + TS_NB < a.m) ? r.i0 + TS_NB : a.m;
+  r.kend = r.valid ? (r.fwd ? kf : a.m) : 0;
+  if (!r.valid) r.nt = 1;
+  return r;
+}
+
+// tile t of block row r:
+//   forward  row b:  t = 0 the block's rows of U;  1 .. nt-2 blocks 0 .. b-2 of V;  nt-1 (>= 1) the hand-over y_(b-1)
+//   backward row b:  t = 0 block b of V (the hand-over itself in the first backward row);  1 .. nt-2 blocks b+2 ..;  nt-1 the
+//                    hand-over v_(b+1)
+__device__ __forceinline__ TileDesc make_tile(const StripArgs &a, const RowState &r, int t) {
   TileDesc d;
-  d.s = s;
+  d.s = r.s;
   d.t = t;
-  d.valid = s < nrows;
-  d.R = nullptr;
-  d.ldr = a.ldv;
-  d.r_bytes = 0;
-  d.r_is_u = 0;
-  d.hbuf = (s + 1) & 1;
-  d.S = a.Sf;
-  d.lds = a.ldsf;
-  d.s_bytes = 0;
-  d.i0 = 0;
+  d.valid = r.valid;
   d.first = (t == 0);
-  d.last = 1;
-  if (!d.valid) return d;
-  int64_t k0, kend;
-  bool handover;
-  int nt;
-  if (s < nb) {  // forward row b = s
-    const int b = s;
-    d.i0 = (int64_t)b * TS_NB;
-    nt = b + 1;
-    kend = (d.i0 + TS_NB < a.m) ? d.i0 + TS_NB : a.m;
-    handover = (t >= 1 && t == nt - 1);
-    if (t == 0) {
-      k0 = d.i0;
-      d.r_is_u = 1;
-    } else {
-      k0 = (int64_t)(handover ? b - 1 : t - 1) * TS_NB;
-    }
-  } else {  // backward row b
-    const int b = 2 * nb - 1 - s;
-    d.i0 = (int64_t)b * TS_NB;
-    nt = nb - b;
-    kend = a.m;
-    d.S = a.Sb;
-    d.lds = a.ldsb;
-    handover = (t == nt - 1);  // (the first backward row's only tile is the hand-over of the last forward row)
-    k0 = (int64_t)(t == 0 ? b : (handover ? b + 1 : b + 1 + t)) * TS_NB;
-  }
-  d.last = (t == nt - 1);
-  d.S = d.S + k0 * d.lds;
-  d.s_bytes = clamp_range((kend - k0) * d.lds * 8);
-  if (!handover) {
-    d.ldr = d.r_is_u ? a.ldu : a.ldv;
-    d.R = (d.r_is_u ? a.U : a.V) + k0 * d.ldr;
-    d.r_bytes = clamp_range((kend - k0) * d.ldr * 8);
-  }
+  d.last = (t == r.nt - 1);
+  d.i0 = r.i0;
+  d.lds = r.lds;
+  d.hbuf = (r.s + 1) & 1;
+  const bool handover = r.fwd ? (t >= 1 && t == r.nt - 1) : (t == r.nt - 1);
+  const int kb = (t == 0) ? r.b : (r.fwd ? (handover ? r.b - 1 : t - 1) : (handover ? r.b + 1 : r.b + 1 + t));
+  const int64_t k0 = (int64_t)kb * TS_NB;
+  d.r_is_u = r.fwd && t == 0;
+  d.ldr = d.r_is_u ? a.ldu : a.ldv;
+  d.S = r.S + k0 * r.lds;
+  d.s_bytes = r.valid ? clamp_range((r.kend - k0) * r.lds * 8) : 0;
+  const bool global_rows = r.valid && !handover;
+  d.R = global_rows ? (d.r_is_u ? a.U : a.V) + k0 * d.ldr : nullptr;
+  d.r_bytes = global_rows ? clamp_range((r.kend - k0) * d.ldr * 8) : 0;
   return d;
 }
 
@@ -316,7 +312,7 @@ __device__ __forceinline__ void strip_solve(const StripArgs &a, int fwd_only, in
   // B fragments: rows 4 kq + q of a sub-step, columns c16 and 16 + c16 (swapped in odd rows)
   const int bo0 = q * TS_SC + ((q & 1) << 4) + c16, bo1 = q * TS_SC + (16 ^ ((q & 1) << 4)) + c16;
 
-  double afr[NSUB][NQ];  // A fragments of sub-step s of the tile in flight (requested TS_AD sub-steps ahead)
+  double afr[NSUB][NQ];  // A fragments of sub-step s of the tile in flight (requested one sub-step ahead)
   double bq[2][NQ][2];
   double2v rreg[NSUB];
   double4v acc[2];
@@ -327,7 +323,13 @@ __device__ __forceinline__ void strip_solve(const StripArgs &a, int fwd_only, in
     const int64_t ca = (d.i0 + wave * 16 + c16 < m) ? d.i0 + wave * 16 + c16 : 0;
     return (int)((q * d.lds + ca) * 8);
   };
-  auto load_a = [&](const TileDesc &d, int voff, auto sub_tag) {  // sub-step `sub` of tile d -> afr[sub]
+  // ---- operand requests, one PAIR of k-quads at a time (the sub-step interleaves them with its MFMAs) ----
+  typedef __attribute__((address_space(3))) void *lds_ptr_t;
+  const int dma_col = (2 * (lane & 15)) ^ (((lane >> 4) & 1) << 4);
+  const int dma_u = (int)(((lane >> 4) * a.ldu + j0 + dma_col) * 8), dma_v = (int)(((lane >> 4) * a.ldv + j0 + dma_col) * 8);
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  // A fragments of k-quads 2 p, 2 p + 1 of sub-step `sub` of tile d -> afr[sub]
+  auto load_a_pair = [&](const TileDesc &d, int voff, auto sub_tag, int p) {
     constexpr int sub = decltype(sub_tag)::value;
 #if !defined(PLS_STRIP_ABL_NOA)
     const __amdgpu_buffer_rsrc_t ra =
@@ -335,23 +337,32 @@ __device__ __forceinline__ void strip_solve(const StripArgs &a, int fwd_only, in
     const int row4 = (int)(d.lds * 32);  // bytes per 4 rows of S
     const int sub_off = sub * TS_BK * (int)(d.lds * 8);
 #pragma unroll
-    for (int kq = 0; kq < NQ; ++kq)
+    for (int kq = 2 * p; kq < 2 * p + 2; ++kq)
       afr[sub][kq] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(ra, voff, sub_off + kq * row4, 0));
 #else
-    (void)d, (void)voff;
+    (void)d, (void)voff, (void)p;
 #endif
   };
-  // The next tile's rows.  Full strips (VEC) go global -> LDS directly (LDS-DMA, `buffer_load_dwordx4 ... lds`): one
-  // wave-instruction deposits 1 KiB = 4 rows of the tile, lane l the 16 bytes at position l -- so the lane picks the
-  // global columns that BELONG at that position (the swizzle lives in its loop-invariant offset); no staging registers,
-  // no ds_write.  Completion needs no wait of its own: loads complete in order, and the A fragments of sub-step 2 are
-  // requested after these, so the MFMAs of sub-step 2 (which precede the tile's barrier) cannot start before the rows
-  // have landed.  Ragged strips go through registers.
-  typedef __attribute__((address_space(3))) void *lds_ptr_t;
-  const int dma_col = (2 * (lane & 15)) ^ (((lane >> 4) & 1) << 4);
-  const int dma_u = (int)(((lane >> 4) * a.ldu + j0 + dma_col) * 8), dma_v = (int)(((lane >> 4) * a.ldv + j0 + dma_col) * 8);
-  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  auto load_r = [&](const TileDesc &d, double *tile) {
+  // B fragments of the same pair of k-quads of sub-step `sub` of an LDS tile -> bq[buf]
+  auto read_b_pair = [&](const double *tile, int sub, auto buf_tag, int p) {
+    constexpr int buf = decltype(buf_tag)::value;
+#if defined(PLS_STRIP_ABL_NOB)
+    return;
+#endif
+    const double *r0 = tile + sub * TS_BK * TS_SC + bo0, *r1 = tile + sub * TS_BK * TS_SC + bo1;
+#pragma unroll
+    for (int kq = 2 * p; kq < 2 * p + 2; ++kq) {
+      bq[buf][kq][0] = r0[kq * 4 * TS_SC];
+      bq[buf][kq][1] = r1[kq * 4 * TS_SC];
+    }
+  };
+  // Quarter p of the next tile's rows.  Full strips (VEC) go global -> LDS directly (LDS-DMA, `buffer_load_dwordx4 ...
+  // lds`): one wave-instruction deposits 1 KiB = 4 rows of the tile, lane l the 16 bytes at position l -- so the lane
+  // picks the global columns that BELONG at that position (the swizzle lives in its loop-invariant offset); no staging
+  // registers, no ds_write.  Completion needs no wait of its own: loads complete in order, and the A fragments of
+  // sub-step 2 are requested after these, so the MFMAs of sub-step 2 (which precede the tile's barrier) cannot start
+  // before the rows have landed.  Ragged strips go through registers (store_r after sub-step 1).
+  auto load_r_part = [&](const TileDesc &d, double *tile, int p) {
 #if defined(PLS_STRIP_ABL_NOR)
     return;
 #endif
@@ -360,19 +371,13 @@ __device__ __forceinline__ void strip_solve(const StripArgs &a, int fwd_only, in
     if constexpr (VEC) {
       const int dv = d.r_is_u ? dma_u : dma_v;
       const int grp = (int)(d.ldr * 32);  // bytes per 4 rows
-#pragma unroll
-      for (int p = 0; p < NSUB; ++p) {
-        const int g = wave_u + 8 * p;  // 4-row group of the tile
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rr, (lds_ptr_t)(tile + g * 4 * TS_SC), 16, dv, g * grp, 0, 0);
-      }
+      const int g = wave_u + 8 * p;       // 4-row group of the tile
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rr, (lds_ptr_t)(tile + g * 4 * TS_SC), 16, dv, g * grp, 0, 0);
     } else {
       const int v0 = d.r_is_u ? v0u : v0v, v1 = d.r_is_u ? v1u : v1v;
       const int pass = (int)(d.ldr * 8 * TS_BK);  // bytes per 32 rows
-#pragma unroll
-      for (int p = 0; p < NSUB; ++p) {
-        rreg[p].x = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rr, v0, p * pass, 0));
-        rreg[p].y = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rr, v1, p * pass, 0));
-      }
+      rreg[p].x = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rr, v0, p * pass, 0));
+      rreg[p].y = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rr, v1, p * pass, 0));
     }
   };
   auto store_r = [&](double *tile) {
@@ -384,27 +389,43 @@ __device__ __forceinline__ void strip_solve(const StripArgs &a, int fwd_only, in
       for (int p = 0; p < NSUB; ++p) *reinterpret_cast<double2v *>(tile + p * TS_BK * TS_SC + st_off) = rreg[p];
     }
   };
-  auto read_b = [&](const double *tile, int sub, auto buf_tag) {
-    constexpr int buf = decltype(buf_tag)::value;
-#if defined(PLS_STRIP_ABL_NOB)
-    return;
-#endif
-    const double *r0 = tile + sub * TS_BK * TS_SC + bo0, *r1 = tile + sub * TS_BK * TS_SC + bo1;
-#pragma unroll
-    for (int kq = 0; kq < NQ; ++kq) {
-      bq[buf][kq][0] = r0[kq * 4 * TS_SC];
-      bq[buf][kq][1] = r1[kq * 4 * TS_SC];
-    }
-  };
-  auto mfmas = [&](auto sub_tag) {  // sub-step `sub`: A fragments afr[sub], B fragments bq[sub & 1]
+  auto mfma_pair = [&](auto sub_tag, int p) {  // sub-step `sub`: A fragments afr[sub], B fragments bq[sub & 1]
     constexpr int sub = decltype(sub_tag)::value, buf = sub & 1;
-    __builtin_amdgcn_sched_barrier(0);  // (operand requests stay in front of the MFMAs, what follows stays behind them)
 #pragma unroll
-    for (int kq = 0; kq < NQ; ++kq) {
+    for (int kq = 2 * p; kq < 2 * p + 2; ++kq) {
       acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[sub][kq], bq[buf][kq][0], acc[0], 0, 0, 0);
       acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[sub][kq], bq[buf][kq][1], acc[1], 0, 0, 0);
     }
+  };
+  // One sub-step: the 16 MFMAs of sub-step SUB of the tile in flight, and the operand requests for what comes a
+  // sub-step later, INTERLEAVED pair by pair (2 A loads, 1 DMA at most, 4 B reads, then 4 MFMAs).  Issued as one burst
+  // in front of the MFMAs (all eight waves at once, right after the same barrier) the 64 + 8 memory instructions of a
+  // sub-step queue up behind each other at the CU's one address unit while the waves that issued them cannot reach their
+  // MFMAs (measured: burst 0.405 / 4.80 ms, pairs 0.389 / 4.57 ms at M = 1024 / 4096; one k-quad at a time was twice as
+  // slow); `sched_barrier` pins the interleaving.
+  auto substep = [&](auto sub_tag, const TileDesc &da, int voffa, auto asub_tag, const double *tileb, int bsub, auto bbuf_tag,
+                     const TileDesc *dr, double *rtile) {
+#pragma unroll
+    for (int p = 0; p < NQ / 2; ++p) {
+#if PLS_STRIP_INTERLEAVE
+      load_a_pair(da, voffa, asub_tag, p);
+      if (dr) load_r_part(*dr, rtile, p);
+      read_b_pair(tileb, bsub, bbuf_tag, p);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_pair(sub_tag, p);
+      __builtin_amdgcn_sched_barrier(0);
+#else
+      load_a_pair(da, voffa, asub_tag, p);
+      if (dr) load_r_part(*dr, rtile, p);
+      read_b_pair(tileb, bsub, bbuf_tag, p);
+#endif
+    }
+#if !PLS_STRIP_INTERLEAVE
     __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int p = 0; p < NQ / 2; ++p) mfma_pair(sub_tag, p);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
   };
   using B0 = std::integral_constant<int, 0>;
   using B1 = std::integral_constant<int, 1>;
@@ -412,26 +433,29 @@ __device__ __forceinline__ void strip_solve(const StripArgs &a, int fwd_only, in
   using S1 = std::integral_constant<int, 1>;
   using S2 = std::integral_constant<int, 2>;
   using S3 = std::integral_constant<int, 3>;
-  constexpr bool AD2 = (TS_AD == 2);  // A fragments requested two sub-steps ahead (one otherwise)
 
   // ---- prime: the first tile of the solve (forward row 0: rows 0 .. 127 of U) ----
-  TileDesc cur = make_tile(a, nb, nrows, 0, 0);
+  RowState row = make_row(a, nb, nrows, 0);
+  TileDesc cur = make_tile(a, row, 0);
   int voff_cur = a_voff(cur);
   // every tile starts from finite content: rows past the end of a contraction are never written by a range-checked
   // load, and what they hold is multiplied by operator rows that read as zero
   for (int e = tid; e < 4 * TS_TILE / 2; e += 512) reinterpret_cast<double2v *>(lds)[e] = double2v{0.0, 0.0};
   __syncthreads();
-  load_r(cur, Rs);
-  load_a(cur, voff_cur, S0{});
+#pragma unroll
+  for (int p = 0; p < NQ / 2; ++p) {
+    load_r_part(cur, Rs, p);
+    load_a_pair(cur, voff_cur, S0{}, p);
+  }
 #if defined(PLS_STRIP_ABL_NOA)
   for (int sb = 0; sb < NSUB; ++sb)
     for (int kq = 0; kq < NQ; ++kq) afr[sb][kq] = 1e-3 * (lane + kq + sb);
 #endif
-  if constexpr (AD2) load_a(cur, voff_cur, S1{});
   store_r(Rs);
   __syncthreads();
   const double *curbuf = Rs;
-  read_b(curbuf, 0, B0{});
+#pragma unroll
+  for (int p = 0; p < NQ / 2; ++p) read_b_pair(curbuf, 0, B0{}, p);
 #if defined(PLS_STRIP_ABL_NOB)
   for (int bb = 0; bb < 2; ++bb)
     for (int kq = 0; kq < NQ; ++kq) bq[bb][kq][0] = bq[bb][kq][1] = 1e-3 * (lane + kq);
@@ -439,36 +463,25 @@ __device__ __forceinline__ void strip_solve(const StripArgs &a, int fwd_only, in
   int gcount = 1;  // global tiles staged so far: the next one goes to Rs[gcount & 1]
 
   for (;;) {
-    const TileDesc nxt = cur.last ? make_tile(a, nb, nrows, cur.s + 1, 0) : make_tile(a, nb, nrows, cur.s, cur.t + 1);
+    RowState nrow = row;
+    if (cur.last) nrow = make_row(a, nb, nrows, cur.s + 1);
+    const TileDesc nxt = make_tile(a, nrow, cur.last ? 0 : cur.t + 1);
     const int voff_nxt = cur.last ? a_voff(nxt) : voff_cur;
     double *const nxt_rs = Rs + (gcount & 1) * TS_TILE;
     const double *nxtbuf = nxt.R ? nxt_rs : Hs + nxt.hbuf * TS_TILE;
-    // sub-step 0: also request the next tile's rows (range 0 if it has none)
-    // (after the A fragments: the memory counter is in order, so rows requested BEFORE them would have to land before
-    // sub-step 1 may use its fragments -- one sub-step of latency budget instead of the two they have until store_r)
-    if constexpr (AD2) load_a(cur, voff_cur, S2{}); else load_a(cur, voff_cur, S1{});
-    load_r(nxt, nxt_rs);
-    read_b(curbuf, 1, B1{});
-    mfmas(S0{});
-    // sub-step 1
-    if constexpr (AD2) load_a(cur, voff_cur, S3{}); else load_a(cur, voff_cur, S2{});
-    read_b(curbuf, 2, B0{});
-    mfmas(S1{});
+    // sub-step 0: also requests the next tile's rows (range 0 if it has none)
+    substep(S0{}, cur, voff_cur, S1{}, curbuf, 1, B1{}, &nxt, nxt_rs);
+    substep(S1{}, cur, voff_cur, S2{}, curbuf, 2, B0{}, nullptr, nullptr);
     store_r(nxt_rs);
-    // sub-step 2
-    if constexpr (AD2) load_a(nxt, voff_nxt, S0{}); else load_a(cur, voff_cur, S3{});
-    read_b(curbuf, 3, B1{});
-    mfmas(S2{});
+    substep(S2{}, cur, voff_cur, S3{}, curbuf, 3, B1{}, nullptr, nullptr);
 #if !defined(PLS_STRIP_ABL_NOBAR)
     if (cur.first)
       __syncthreads();  // once per block row: also completes this wave's stores of the previous row's block
     else
       lds_barrier();
 #endif
-    // sub-step 3: the next tile's first operands (a hand-over tile that this row is about to write is read again below)
-    if constexpr (AD2) load_a(nxt, voff_nxt, S1{}); else load_a(nxt, voff_nxt, S0{});
-    read_b(nxtbuf, 0, B0{});
-    mfmas(S3{});
+    // sub-step 3 fetches the next tile's first operands (a hand-over tile that this row is about to write is read again below)
+    substep(S3{}, nxt, voff_nxt, S0{}, nxtbuf, 0, B0{}, nullptr, nullptr);
     if (cur.last) {  // the block row is complete: result -> global V and the hand-over tile
       double *const hand = Hs + (cur.s & 1) * TS_TILE;
 #pragma unroll
@@ -486,12 +499,14 @@ __device__ __forceinline__ void strip_solve(const StripArgs &a, int fwd_only, in
       acc[1] = double4v{0.0, 0.0, 0.0, 0.0};
       if (nxt.valid && nxt.R == nullptr) {  // the turn: the next row starts with the block just written
         lds_barrier();
-        read_b(nxtbuf, 0, B0{});
+#pragma unroll
+        for (int p = 0; p < NQ / 2; ++p) read_b_pair(nxtbuf, 0, B0{}, p);
       }
     }
     if (!nxt.valid) break;
     if (nxt.R) ++gcount;
     cur = nxt;
+    row = nrow;
     voff_cur = voff_nxt;
     curbuf = nxtbuf;
   }
