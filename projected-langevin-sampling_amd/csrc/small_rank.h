@@ -115,22 +115,31 @@ __global__ __launch_bounds__(256, 2) void small_rank_kernel(SmallRankP p) {
   }
   const int yoff = (tid < SR_ROWS) ? tid * 8 : 0x7FFFFF00;
   const int64_t row_bytes = p.ldlb * 8;
-  auto load_tile = [&](int64_t n0) {
+  // part i of the next tile's loads: i < NLOAD one 16-byte pair per thread, i == NLOAD the tile's targets.  The parts are
+  // issued one per MFMA group of the second contraction, not as one burst in front of it: eight waves per CU reach this
+  // point together, and a wave queued behind the CU's address unit cannot issue its MFMAs (5 % on the strip solve; here,
+  // with 7 loads per 94 MFMAs, it measures as nothing -- 4.788 vs 4.784 ms at configs[2] -- but costs nothing either and
+  // frees 16 registers).
+  auto load_tile_part = [&](int64_t n0, int i) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const int64_t left = nend - n0;  // > 0
-    const int64_t lb = left * row_bytes;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<double *>(p.Lb + n0 * p.ldlb), 0, (int)(lb < 0x7FFFFF00 ? lb : 0x7FFFFF00), 0x00020000);
-    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<double *>(p.y + n0), 0, (int)(left * 8 < 0x7FFFFF00 ? left * 8 : 0x7FFFFF00), 0x00020000);
-#pragma unroll
-    for (int i = 0; i < NLOAD; ++i) {
+    if (i < NLOAD) {
+      const int64_t lb = left * row_bytes;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<double *>(p.Lb + n0 * p.ldlb), 0, (int)(lb < 0x7FFFFF00 ? lb : 0x7FFFFF00), 0x00020000);
       stage[i] = __builtin_bit_cast(sr_double2_t, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[i], 0, 0));
+    } else {
+      const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<double *>(p.y + n0), 0, (int)(left * 8 < 0x7FFFFF00 ? left * 8 : 0x7FFFFF00), 0x00020000);
+      ystage = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(ry, yoff, 0, 0));
     }
-    ystage = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(ry, yoff, 0, 0));
 #else
-    (void)n0, (void)yoff, (void)row_bytes;
+    (void)n0, (void)i, (void)yoff, (void)row_bytes;
 #endif
+  };
+  auto load_tile = [&](int64_t n0) {
+#pragma unroll
+    for (int i = 0; i <= NLOAD; ++i) load_tile_part(n0, i);
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
@@ -226,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void small_rank_kernel(SmallRankP p) {
       }
     }
     // the next tile's global loads fly during the second contraction (their staging registers are not live before)
-    if (more) load_tile(n0 + SR_ROWS);
+    if (more && (MODE == SR_MODE_VALUE || NLOAD + 1 > 8)) load_tile(n0 + SR_ROWS);
     if (MODE != SR_MODE_VALUE) {
       // second contraction: D[16 ta + c][jcol] += sum_rows Lb[row][16 ta + c] * G[row][jcol]; the A-operands of row
       // group r + 1 are fetched before the MFMAs of group r are issued (and no earlier: registers)
@@ -246,6 +255,7 @@ __global__ __launch_bounds__(256, 2) void small_rank_kernel(SmallRankP p) {
 #pragma unroll
           for (int ta = 0; ta < KB; ++ta) an[(g + 1) & 1][ta] = ap[16 * ta];
         }
+        if (NLOAD + 1 <= 8 && more && g <= NLOAD) load_tile_part(n0 + SR_ROWS, g);  // one part per group (see load_tile_part)
         // (without this fence the scheduler rotates the loop: group g's reads end up right in front of group g's MFMAs)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
