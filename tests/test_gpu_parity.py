@@ -1642,7 +1642,8 @@ def _spd(m, d, seed, scale=0.35):
 
 
 @pytest.mark.parametrize("m,d,j", [(1, 1, 3), (2, 1, 1), (63, 2, 5), (64, 2, 33), (65, 3, 64), (128, 3, 31), (129, 3, 100),
-                                   (200, 3, 257), (300, 4, 64), (640, 6, 96), (1024, 8, 512), (1024, 8, 4100)])
+                                   (200, 3, 257), (300, 4, 64), (520, 5, 40), (640, 6, 96), (897, 7, 70), (1024, 8, 512),
+                                   (1024, 8, 4100), (1153, 8, 33)])
 def test_device_cholesky_and_solves_against_lapack(P, m, d, j):
     from projected_langevin_sampling_amd import _chol
 
