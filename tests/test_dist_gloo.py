@@ -62,3 +62,13 @@ def test_two_ranks_even_shards(tmp_path):
 
 def test_two_ranks_ragged_shards(tmp_path):
     _run(2, 37, tmp_path)
+
+
+def test_four_ranks_ragged_shards(tmp_path):
+    """the shape of the 4-GPU configuration (configs[3]) in miniature: J not divisible by the world size"""
+    _run(4, 37, tmp_path)
+
+
+def test_three_ranks_fewer_particles_than_some_shards_expect(tmp_path):
+    """a shard may be a single column (J = 4 over 3 ranks: 2, 1, 1)"""
+    _run(3, 4, tmp_path)
