@@ -6,7 +6,7 @@
 //
 // Factorisation (once per basis, everything stays on the device, nothing synchronises):
 //   right-looking blocked Cholesky, panels of CH_PB = 64 columns:
-//     chol_diag_kernel   the 64 x 64 diagonal block, one workgroup, in LDS
+//     chol_diag_kernel   the 64 x 64 diagonal block, one wave, in registers
 //     chol_panel_kernel  the rows below it: x L11^T = a, one row per thread, L11 broadcast from LDS; writes L (lower,
 //                        row-major) AND L^T (upper) so that both are k-major operands of the MFMA contraction
 //     trailing update    A22 -= L21 L21^T through gemm_tn_f64_kernel (gemm_tn_ex)
@@ -58,43 +58,61 @@ __global__ __launch_bounds__(256) void chol_init_kernel(const double *__restrict
   }
 }
 
-// Factor the nb x nb diagonal block at (k0, k0) in LDS.  info (device int): 1-based index of the first pivot that is not
-// positive (the factor is then garbage and the caller escalates the jitter), 0 otherwise.
-__global__ __launch_bounds__(256) void chol_diag_kernel(double *Lc, int64_t ldl, double *LcT, int64_t ldlt, int64_t k0,
-                                                         int nb, int *info) {
-  __shared__ double S[CH_PB][CH_PB + 1];
-  __shared__ double colv[CH_PB];
-  const int tid = threadIdx.x;
-  for (int e = tid; e < CH_PB * CH_PB; e += 256) {
-    const int r = e / CH_PB, c = e % CH_PB;
-    S[r][c] = (r < nb && c < nb) ? Lc[(k0 + r) * ldl + k0 + c] : (r == c ? 1.0 : 0.0);
-  }
-  __syncthreads();
-  for (int c = 0; c < nb; ++c) {
-    const double d = S[c][c];
-    if (!(d > 0.0) && tid == 0 && info && *info == 0) *info = (int)(k0 + c) + 1;
-    const double sd = sqrt(d);
-    if (tid < CH_PB) colv[tid] = (tid > c) ? S[tid][c] / sd : 0.0;
-    __syncthreads();
-    for (int e = tid; e < CH_PB * CH_PB; e += 256) {
-      const int r = e / CH_PB, k = e % CH_PB;
-      if (k > c && r >= k) S[r][k] = fma(-colv[r], colv[k], S[r][k]);
+// Factor the nb x nb diagonal block at (k0, k0): ONE wave, lane r holds row r in registers, no LDS and no barrier.
+// Column c: the pivot and the column below it are broadcast with v_readlane (the lane index is a compile-time constant:
+// the loops are fully unrolled), the rank-1 update of the trailing columns is one fma per (row, column) with the
+// broadcast value as a scalar operand.  ~8.5 k straight-line instructions = ~17 us; the round-2 first version (256
+// threads, the block in LDS, two workgroup barriers per column) took 104 us per panel -- 1.7 of the 2.8 ms of a
+// factorisation at M = 1024.
+// info (device int): 1-based index of the first pivot that is not positive (the factor is then garbage and the caller
+// escalates the jitter), 0 otherwise.
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+#else
+  (void)lane;
+  return v;
+#endif
+}
+
+__global__ __launch_bounds__(64) void chol_diag_kernel(double *Lc, int64_t ldl, double *LcT, int64_t ldlt, int64_t k0,
+                                                        int nb, int *info) {
+  static_assert(CH_PB == 64, "one lane per row of the panel");
+  const int r = threadIdx.x;
+  double x[CH_PB];
+  if (nb == CH_PB) {  // (k0 is a multiple of 64 and ldl even: 16-byte aligned rows)
+    const double2v *src = reinterpret_cast<const double2v *>(Lc + (k0 + r) * ldl + k0);
+#pragma unroll
+    for (int c = 0; c < CH_PB / 2; ++c) {
+      const double2v v = src[c];
+      x[2 * c] = v.x;
+      x[2 * c + 1] = v.y;
     }
-    if (tid < CH_PB) {
-      if (tid > c) S[tid][c] = colv[tid];
-      if (tid == c) S[c][c] = sd;
-    }
-    __syncthreads();
+  } else {  // the last, partial block: identity beyond nb
+#pragma unroll
+    for (int c = 0; c < CH_PB; ++c) x[c] = (r < nb && c < nb) ? Lc[(k0 + r) * ldl + k0 + c] : (r == c ? 1.0 : 0.0);
   }
-  for (int e = tid; e < CH_PB * CH_PB; e += 256) {
-    const int r = e / CH_PB, c = e % CH_PB;
-    if (r < nb && c < nb) {
-      const double lo = (r >= c) ? S[r][c] : 0.0;  // L[r][c]
-      const double up = (c >= r) ? S[c][r] : 0.0;  // L^T[r][c] = L[c][r]
-      Lc[(k0 + r) * ldl + k0 + c] = lo;
-      LcT[(k0 + r) * ldlt + k0 + c] = up;
-    }
+  int bad = 0;
+#pragma unroll
+  for (int c = 0; c < CH_PB; ++c) {
+    const double d = readlane_f64(x[c], c);
+    if (!(d > 0.0) && bad == 0) bad = c + 1;  // (wave-uniform)
+    const double sd = sqrt(d), inv = 1.0 / sd;
+    const double l = (r > c) ? x[c] * inv : (r == c ? sd : 0.0);
+    x[c] = l;
+#pragma unroll
+    for (int k = c + 1; k < CH_PB; ++k) x[k] = fma(-l, readlane_f64(l, k), x[k]);
   }
+  if (bad && r == 0 && info && *info == 0) *info = (int)k0 + bad;
+  if (r < nb) {
+#pragma unroll
+    for (int c = 0; c < CH_PB; ++c)
+      if (c < nb) Lc[(k0 + r) * ldl + k0 + c] = (c <= r) ? x[c] : 0.0;  // L[r][c]
+  }
+#pragma unroll
+  for (int c = 0; c < CH_PB; ++c)
+    if (c < nb && r < nb) LcT[(k0 + c) * ldlt + k0 + r] = (r >= c) ? x[c] : 0.0;  // L^T[c][r] = L[r][c]: coalesced over the lanes
 }
 
 // Rows below a full 64-column panel: row r of A21 -> x with x L11^T = a (forward substitution along the row).
@@ -607,7 +625,7 @@ int pls_chol_factor(const double *K, int64_t ldk, int64_t m, double jitter, doub
   }
   for (int64_t k0 = 0; k0 < m; k0 += CH_PB) {
     const int nb = (int)((m - k0 < CH_PB) ? (m - k0) : CH_PB);
-    hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, st, Lc, ldlc, LcT, ldlct, k0, nb, info);
+    hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(64), 0, st, Lc, ldlc, LcT, ldlct, k0, nb, info);
     const int64_t rem = m - k0 - nb;
     if (rem > 0) {  // (then nb == CH_PB)
       hipLaunchKernelGGL(chol_panel_kernel, dim3((unsigned)cdiv(rem, 64)), dim3(64), 0, st, Lc, ldlc, LcT, ldlct, k0, m);
