@@ -256,9 +256,10 @@ int pls_row_power_sums(const double *S, int64_t lds, int64_t rows, int64_t cols,
                        double *out, void *stream);
 
 /* out[r][k] = q[k]-quantile of row r of S (rows x cols), linear interpolation between order statistics at position
- * q * (cols - 1): the value torch.quantile(S, q, dim=1) returns (conformalise/pls.py:36-45, :57-62).  One workgroup
- * sorts one row in LDS (bitonic), so cols <= 16384; q: nq values in [0, 1] (device).  A row that contains a NaN yields
- * NaN, like torch. */
+ * q * (cols - 1): the value torch.quantile(S, q, dim=1) returns (conformalise/pls.py:36-45, :57-62).  Up to 16384
+ * samples per row one workgroup sorts the row in LDS (bitonic); longer rows (a large calibration split, the gathered
+ * samples of a J-sharded run) take a radix selection of the two order statistics instead (nine passes over the row, no
+ * workspace).  q: nq values in [0, 1] (device).  A row that contains a NaN yields NaN, like torch. */
 int pls_row_quantiles(const double *S, int64_t lds, int64_t rows, int64_t cols, const double *q, int32_t nq, double *out,
                       int64_t ldout, void *stream);
 

@@ -41,19 +41,14 @@ def row_power_sums(s: torch.Tensor, power: int, shift: torch.Tensor | None = Non
     return out
 
 
-ROW_QUANTILES_MAX_COLS = 16384
-
-
 def row_quantiles(s: torch.Tensor, qs) -> torch.Tensor:
-    """(rows, len(qs)) quantiles over dim 1 with torch.quantile's linear interpolation (pls_row_quantiles)."""
+    """(rows, len(qs)) quantiles over dim 1 with torch.quantile's linear interpolation (pls_row_quantiles: one LDS sort per
+    row up to 16384 samples, radix selection of the two order statistics beyond -- a calibration split above 16384 points,
+    the gathered samples of a J-sharded run)."""
     L.require_gpu_tensor(s, "samples")
     s = s if s.stride(1) == 1 else s.contiguous()
     rows, cols = s.shape
     q = torch.as_tensor(list(qs), dtype=torch.float64).to(s.device)
-    if cols > ROW_QUANTILES_MAX_COLS:
-        # pls_row_quantiles sorts one row per workgroup in LDS (<= 16384 samples).  Longer rows -- a calibration split above
-        # 16384 points, or the gathered samples of a J-sharded run -- go through torch's device sort: same interpolation rule
-        return torch.quantile(s, q, dim=1).T.contiguous()
     out = torch.empty((rows, q.numel()), dtype=torch.float64, device=s.device)
     L.check(
         L.load().pls_row_quantiles(s.data_ptr(), L.ld(s), rows, cols, q.data_ptr(), q.numel(), out.data_ptr(), q.numel(),

@@ -708,6 +708,123 @@ __global__ __launch_bounds__(256) void row_quantiles_kernel(const double *__rest
   }
 }
 
+// per-row quantiles of LONG rows (more samples than one LDS sort holds: a calibration split above 16384 points, the
+// gathered samples of a J-sharded run): no sort at all, the two order statistics a quantile interpolates between are
+// SELECTED.  A double maps to a 64-bit key with the same order; eight passes over the row, most significant byte first,
+// each a 256-bin histogram of the next byte among the samples that still match the key prefix found so far, fix one
+// byte of the k-th smallest key.  The upper neighbour is the same value (ties) or the smallest larger key: one more
+// pass.  A workgroup serves up to SEL_NQ quantiles of one row at once (one histogram each); nothing is written but the
+// results, no workspace.  Histogram updates are aggregated per wave (the leading bytes -- sign, exponent -- are the same
+// for nearly every sample: 64 lanes would otherwise serialise on one LDS counter).
+constexpr int SEL_NQ = 4;
+
+__device__ __forceinline__ uint64_t order_key(double v) {  // monotone: v < w  <=>  key(v) < key(w)  (no NaN)
+  const uint64_t b = (uint64_t)__double_as_longlong(v);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double key_value(uint64_t k) {
+  const uint64_t b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+  return __longlong_as_double((long long)b);
+}
+
+__global__ __launch_bounds__(256) void row_quantiles_select_kernel(const double *__restrict__ samples, int64_t lds_, int64_t cols,
+                                                                    const double *__restrict__ q, int nq, int q0,
+                                                                    double *__restrict__ out, int64_t ldout) {
+  __shared__ unsigned int hist[SEL_NQ][256];
+  __shared__ uint64_t prefix[SEL_NQ], minabove[SEL_NQ];
+  __shared__ long long rank[SEL_NQ];
+  __shared__ unsigned int tie[SEL_NQ];
+  __shared__ int has_nan;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const double *row = samples + (int64_t)blockIdx.x * lds_;
+  const int nloc = (nq - q0 < SEL_NQ) ? nq - q0 : SEL_NQ;  // quantiles of this workgroup: q0 .. q0 + nloc - 1
+  if (tid < SEL_NQ) {
+    prefix[tid] = 0;
+    minabove[tid] = ~0ull;
+    tie[tid] = 0;
+    if (tid < nloc) rank[tid] = (long long)floor(q[q0 + tid] * (double)(cols - 1));  // lower order statistic, 0-based
+  }
+  if (tid == 0) has_nan = 0;
+  for (int pass = 7; pass >= 0; --pass) {
+    for (int e = tid; e < SEL_NQ * 256; e += 256) (&hist[0][0])[e] = 0;
+    __syncthreads();
+    const int shift = 8 * pass;
+    uint64_t pf[SEL_NQ];
+#pragma unroll
+    for (int i = 0; i < SEL_NQ; ++i) pf[i] = prefix[i];
+    bool nan_seen = false;
+    for (int64_t k0 = 0; k0 < cols; k0 += 256) {
+      const int64_t k = k0 + tid;
+      const bool in = k < cols;
+      const double v = in ? row[k] : 0.0;
+      nan_seen |= (v != v);
+      const uint64_t key = order_key(v);
+      const unsigned byte = (unsigned)(key >> shift) & 255u;
+#pragma unroll
+      for (int i = 0; i < SEL_NQ; ++i) {
+        if (i >= nloc) break;
+        const bool match = in && (pass == 7 || ((key ^ pf[i]) >> (shift + 8)) == 0);
+        unsigned long long todo = __ballot(match);
+        while (todo) {  // one LDS update per distinct byte value in the wave
+          const int leader = __ffsll((long long)todo) - 1;
+          const unsigned lb = (unsigned)__shfl((int)byte, leader);
+          const unsigned long long same = __ballot(match && byte == lb) & todo;
+          if (lane == leader) atomicAdd(&hist[i][lb], (unsigned)__popcll(same));
+          todo &= ~same;
+        }
+      }
+    }
+    if (pass == 7 && nan_seen) has_nan = 1;
+    __syncthreads();
+    if (tid < nloc) {  // the bin that holds the rank: serial scan of 256 counters (once per pass)
+      long long r = rank[tid];
+      unsigned b = 0;
+      for (; b < 255; ++b) {
+        const unsigned c = hist[tid][b];
+        if (r < (long long)c) break;
+        r -= c;
+      }
+      rank[tid] = r;
+      prefix[tid] |= (uint64_t)b << shift;
+      if (pass == 0) tie[tid] = hist[tid][b];  // samples equal to the selected value; r = position among them
+    }
+    __syncthreads();
+  }
+  // upper neighbour: the selected value again if the ties reach past it, otherwise the smallest larger key
+  {
+    uint64_t pf[SEL_NQ], best[SEL_NQ];
+#pragma unroll
+    for (int i = 0; i < SEL_NQ; ++i) {
+      pf[i] = prefix[i];
+      best[i] = ~0ull;
+    }
+    for (int64_t k = tid; k < cols; k += 256) {
+      const uint64_t key = order_key(row[k]);
+#pragma unroll
+      for (int i = 0; i < SEL_NQ; ++i)
+        if (key > pf[i] && key < best[i]) best[i] = key;
+    }
+#pragma unroll
+    for (int i = 0; i < SEL_NQ; ++i)
+      if (i < nloc) atomicMin(reinterpret_cast<unsigned long long *>(&minabove[i]), (unsigned long long)best[i]);
+    __syncthreads();
+  }
+  if (tid < nloc) {
+    double r;
+    if (has_nan) {
+      r = __builtin_nan("");
+    } else {
+      const double pos = q[q0 + tid] * (double)(cols - 1);
+      const double lo_f = floor(pos), w = pos - lo_f;
+      const double a = key_value(prefix[tid]);
+      const bool last = (int64_t)lo_f + 1 >= cols;
+      const double b = (last || rank[tid] + 1 < (long long)tie[tid]) ? a : key_value(minabove[tid]);
+      r = (w < 0.5) ? a + w * (b - a) : b - (b - a) * (1.0 - w);  // torch.lerp's two-sided form
+    }
+    out[(int64_t)blockIdx.x * ldout + q0 + tid] = r;
+  }
+}
+
 __global__ __launch_bounds__(256) void counter_add_kernel(uint64_t *counter, uint64_t increment) { *counter += increment; }
 
 __global__ __launch_bounds__(256) void normal_fill_kernel(double *__restrict__ out, int64_t ldo, int64_t rows,
@@ -1307,8 +1424,16 @@ int pls_row_quantiles(const double *samples, int64_t lds, int64_t rows, int64_t 
   PLS_REQUIRE(samples && q && out, "row_quantiles: NULL pointer");
   PLS_REQUIRE(rows >= 0 && cols >= 1 && lds >= cols && nq >= 1 && ldout >= nq, "row_quantiles: bad sizes");
   PLS_REQUIRE(rows <= 0x7fffffff, "row_quantiles: too many rows");
-  if (cols > 16384) return fail(PLS_ERR_UNSUPPORTED, "row_quantiles: %lld samples per row > 16384 (one LDS sort per row)", (long long)cols);
   if (rows == 0) return PLS_OK;
+  if (cols > 16384) {  // longer than one LDS sort: radix selection, SEL_NQ quantiles per launch
+    for (int q0 = 0; q0 < nq; q0 += SEL_NQ) {
+      hipLaunchKernelGGL(row_quantiles_select_kernel, dim3((unsigned)rows), dim3(256), 0, S(stream), samples, lds, cols, q,
+                         (int)nq, q0, out, ldout);
+      int rc = check_launch("row_quantiles_select");
+      if (rc) return rc;
+    }
+    return PLS_OK;
+  }
   int npad = 2;
   while (npad < cols) npad <<= 1;
   const size_t bytes = (size_t)npad * sizeof(double);

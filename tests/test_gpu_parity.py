@@ -1851,12 +1851,28 @@ def test_user_defined_basis_with_the_reference_signature(P):
 
 
 def test_quantiles_beyond_one_lds_sort(P):
-    """More than 16 384 samples per row (a large calibration split, or the gathered samples of a J-sharded run): the
-    quantile falls back to the device sort instead of raising PLS_ERR_UNSUPPORTED (advisor finding, round 1)."""
+    """More than 16 384 samples per row (a large calibration split, or the gathered samples of a J-sharded run):
+    pls_row_quantiles selects the two order statistics by radix passes instead of sorting in LDS (round 1 raised
+    PLS_ERR_UNSUPPORTED here; the first fix fell back to torch's sort).  Against torch.quantile on the host: plain
+    normals, heavy ties, mixed signs and magnitudes, the extreme quantiles, more quantiles than one launch serves, a
+    padded (strided) view, and NaN propagation."""
     from projected_langevin_sampling_amd import _ops
 
     g = torch.Generator().manual_seed(0)
+    qs = [0.0, 0.05, 0.3333, 0.5, 0.95, 1.0]  # (6 > SEL_NQ = 4: two launches)
+    want = lambda s: torch.quantile(s, torch.tensor(qs, dtype=s.dtype), dim=1).T
     s = torch.randn(2, 20000, generator=g)
-    got = _ops.row_quantiles(cu(s), [0.05, 0.5, 0.95])
-    assert relerr(got, torch.quantile(s, torch.tensor([0.05, 0.5, 0.95]), dim=1).T) < 1e-14
+    assert relerr(_ops.row_quantiles(cu(s), qs), want(s)) < 1e-14
+    ties = torch.randint(-3, 4, (3, 40001), generator=g).double()  # 7 distinct values: the neighbour is almost always a tie
+    assert torch.equal(_ops.row_quantiles(cu(ties), qs).cpu(), want(ties))
+    wide = torch.randn(2, 65536, generator=g) * torch.exp(8.0 * torch.randn(2, 65536, generator=g))  # 1e-15 .. 1e15, both signs
+    wide[0, :100] = 0.0
+    wide[1, 5] = -0.0
+    assert relerr(_ops.row_quantiles(cu(wide), qs), want(wide)) < 1e-14
+    padded = torch.randn(2, 17001 + 7, generator=g)
+    assert relerr(_ops.row_quantiles(cu(padded)[:, 3:3 + 17001], qs), want(padded[:, 3:3 + 17001].contiguous())) < 1e-14
+    bad = s.clone()
+    bad[1, 12345] = float("nan")
+    got = _ops.row_quantiles(cu(bad), [0.5, 0.9]).cpu()
+    assert torch.isnan(got[1]).all() and relerr(got[0], torch.quantile(s[0], torch.tensor([0.5, 0.9], dtype=s.dtype))) < 1e-14
     assert _ops.row_quantiles(cu(s[:, :16384].contiguous()), [0.5]).shape == (2, 1)
