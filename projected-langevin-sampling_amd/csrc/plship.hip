@@ -727,7 +727,7 @@ __device__ __forceinline__ double key_value(uint64_t k) {
   return __longlong_as_double((long long)b);
 }
 
-__global__ __launch_bounds__(256) void row_quantiles_select_kernel(const double *__restrict__ samples, int64_t lds_, int64_t cols,
+__global__ __launch_bounds__(1024) void row_quantiles_select_kernel(const double *__restrict__ samples, int64_t lds_, int64_t cols,
                                                                     const double *__restrict__ q, int nq, int q0,
                                                                     double *__restrict__ out, int64_t ldout) {
   __shared__ unsigned int hist[SEL_NQ][256];
@@ -735,7 +735,7 @@ __global__ __launch_bounds__(256) void row_quantiles_select_kernel(const double 
   __shared__ long long rank[SEL_NQ];
   __shared__ unsigned int tie[SEL_NQ];
   __shared__ int has_nan;
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63, nt = blockDim.x;  // 256 threads, 1024 when there are only a few rows
   const double *row = samples + (int64_t)blockIdx.x * lds_;
   const int nloc = (nq - q0 < SEL_NQ) ? nq - q0 : SEL_NQ;  // quantiles of this workgroup: q0 .. q0 + nloc - 1
   if (tid < SEL_NQ) {
@@ -746,14 +746,14 @@ __global__ __launch_bounds__(256) void row_quantiles_select_kernel(const double 
   }
   if (tid == 0) has_nan = 0;
   for (int pass = 7; pass >= 0; --pass) {
-    for (int e = tid; e < SEL_NQ * 256; e += 256) (&hist[0][0])[e] = 0;
+    for (int e = tid; e < SEL_NQ * 256; e += nt) (&hist[0][0])[e] = 0;
     __syncthreads();
     const int shift = 8 * pass;
     uint64_t pf[SEL_NQ];
 #pragma unroll
     for (int i = 0; i < SEL_NQ; ++i) pf[i] = prefix[i];
     bool nan_seen = false;
-    for (int64_t k0 = 0; k0 < cols; k0 += 256) {
+    for (int64_t k0 = 0; k0 < cols; k0 += nt) {
       const int64_t k = k0 + tid;
       const bool in = k < cols;
       const double v = in ? row[k] : 0.0;
@@ -798,7 +798,7 @@ __global__ __launch_bounds__(256) void row_quantiles_select_kernel(const double 
       pf[i] = prefix[i];
       best[i] = ~0ull;
     }
-    for (int64_t k = tid; k < cols; k += 256) {
+    for (int64_t k = tid; k < cols; k += nt) {
       const uint64_t key = order_key(row[k]);
 #pragma unroll
       for (int i = 0; i < SEL_NQ; ++i)
@@ -1427,7 +1427,7 @@ int pls_row_quantiles(const double *samples, int64_t lds, int64_t rows, int64_t 
   if (rows == 0) return PLS_OK;
   if (cols > 16384) {  // longer than one LDS sort: radix selection, SEL_NQ quantiles per launch
     for (int q0 = 0; q0 < nq; q0 += SEL_NQ) {
-      hipLaunchKernelGGL(row_quantiles_select_kernel, dim3((unsigned)rows), dim3(256), 0, S(stream), samples, lds, cols, q,
+      hipLaunchKernelGGL(row_quantiles_select_kernel, dim3((unsigned)rows), dim3(rows < 256 ? 1024 : 256), 0, S(stream), samples, lds, cols, q,
                          (int)nq, q0, out, ldout);
       int rc = check_launch("row_quantiles_select");
       if (rc) return rc;

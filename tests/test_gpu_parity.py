@@ -1871,6 +1871,8 @@ def test_quantiles_beyond_one_lds_sort(P):
     assert relerr(_ops.row_quantiles(cu(wide), qs), want(wide)) < 1e-14
     padded = torch.randn(2, 17001 + 7, generator=g)
     assert relerr(_ops.row_quantiles(cu(padded)[:, 3:3 + 17001], qs), want(padded[:, 3:3 + 17001].contiguous())) < 1e-14
+    many = torch.randn(300, 17000, generator=g)  # >= 256 rows: the 256-thread launch (few rows get 1024 threads each)
+    assert relerr(_ops.row_quantiles(cu(many), qs), want(many)) < 1e-14
     bad = s.clone()
     bad[1, 12345] = float("nan")
     got = _ops.row_quantiles(cu(bad), [0.5, 0.9]).cpu()
