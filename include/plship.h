@@ -188,7 +188,14 @@ typedef enum pls_option {
   PLS_OPT_SMALL_RANK_MAX = 1,
   /* 1: V = k(Z,Z)^-1 U of the inducing-point basis as the contraction W U with the explicit inverse (needs
    * pls_ipb_desc.W); 0 (default): two blocked triangular solves with the Cholesky factor (pls_chol_solve). */
-  PLS_OPT_IPB_EXPLICIT_INVERSE = 2
+  PLS_OPT_IPB_EXPLICIT_INVERSE = 2,
+  /* Contractions with few output tiles (a narrow J-shard of an 8-GPU run: Mk x Mk x J/8) take 64 x 64 tiles whose k range
+   * is split over two wave groups INSIDE the workgroup (csrc/gemm_tn_f64_kg.h), so that 256..1023 tiles still put 2..4
+   * waves on every SIMD; the epilogue runs once on the fixed-order sum.  MODE: 0 off, 1 automatic (default), 2 / 3 force the
+   * two- / one-group kernel wherever the operands are 16-byte aligned (A/B runs, tests).  MAX_TILES: the number of
+   * 128 x 128 output tiles below which the automatic mode takes it (default 256: one workgroup per CU). */
+  PLS_OPT_KSPLIT_MODE = 3,
+  PLS_OPT_KSPLIT_MAX_TILES = 4
 } pls_option;
 /* Diagnostic: out[i] = op(x[i]) with the device exp (op 0) / log (op 1) the per-element kernels use (csrc/fmath.h),
  * so that their accuracy can be pinned against libm.  Not on the step path. */

@@ -18,6 +18,7 @@
 #include "gemm_api.h"
 #include "gemm_tn_f64.h"
 #include "gemm_launch.h"
+#include "gemm_tn_f64_kg.h"
 #include "cost_epilogues.h"
 #include "philox.h"
 #include "small_rank.h"
@@ -362,6 +363,59 @@ static int64_t plan_split_k(int64_t I, int64_t J, int64_t K, int64_t *kchunk) {
   s = cdiv(K, kc);
   *kchunk = (s > 1) ? kc : 0;
   return s;
+}
+
+// ---- few output tiles: 64 x 64 tiles with the k range split over wave groups inside the workgroup (gemm_tn_f64_kg.h) ----
+static std::atomic<int64_t> g_ksplit_mode{1};          // pls_set_option(PLS_OPT_KSPLIT_MODE): 0 off, 1 auto, 2 / 3 force 2 / 1 k-groups
+static std::atomic<int64_t> g_ksplit_max_tiles{256};   // pls_set_option(PLS_OPT_KSPLIT_MAX_TILES): 128 x 128 tiles below which it is taken
+
+enum GemmCfg { CFG_BIG = 0, CFG_SMALL = 1, CFG_KG1 = 2, CFG_KG2 = 3 };
+
+// Which configuration a contraction of this shape runs in (the energy partial layout of the fast path follows from it)
+static GemmCfg pick_gemm_cfg(const double *L, int64_t ldl, const double *R, int64_t ldr, int64_t I, int64_t J, int64_t K,
+                             int64_t nsplit = 1) {
+  const int64_t mode = g_ksplit_mode.load();
+  const int64_t tiles128 = cdiv(I, 128) * cdiv(J, 128) * nsplit;
+  const bool aligned = ((ldl | ldr) & 1) == 0 && ((reinterpret_cast<uintptr_t>(L) | reinterpret_cast<uintptr_t>(R)) & 15) == 0 &&
+                       ldl < ((int64_t)1 << 22) && ldr < ((int64_t)1 << 22);
+  if (mode != 0 && aligned && nsplit == 1 && K >= 1) {
+    if (mode == 2) return CFG_KG2;
+    if (mode == 3) return CFG_KG1;
+    if (tiles128 < g_ksplit_max_tiles.load() && K >= 32) return CFG_KG2;
+  }
+  return tiles128 >= 256 ? CFG_BIG : CFG_SMALL;
+}
+
+template <int KG, class Epi>
+static int launch_gemm_kg(GemmShape g, const Epi &epi, hipStream_t st) {
+  using G = KgGeom<KG>;
+  constexpr size_t lds_bytes = (size_t)G::LDS_DOUBLES * sizeof(double);
+  auto kern = gemm_tn_f64_kg_kernel<KG, Epi>;
+  static std::atomic<uint64_t> lds_ready{0};
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds_bytes, lds_ready)) return rc;
+  g.nti = (int)cdiv(g.I, 64);
+  g.ntj = (int)cdiv(g.J, 64);
+  const int64_t nwg = (int64_t)g.nti * g.ntj;
+  if (nwg <= 0) return PLS_OK;
+  if (nwg > 0x7fffffff) return fail(PLS_ERR_INVALID_ARGUMENT, "gemm: too many tiles");
+  {
+    LaunchScope scope(Epi::kTag, st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg, 1), dim3(G::NT), lds_bytes, st, g, epi);
+  }
+  return check_launch("gemm_tn_f64_kg");
+}
+
+// launch_gemm of gemm_launch.h plus the k-split configurations (this translation unit's epilogues only)
+template <class Epi>
+static int launch_gemm_any(const double *L, int64_t ldl, const double *R, int64_t ldr, int64_t I, int64_t J, int64_t K,
+                           const Epi &epi, hipStream_t st, int64_t kchunk = 0, int tri = 0) {
+  const int64_t nsplit = (kchunk > 0 && kchunk < K) ? cdiv(K, kchunk) : 1;
+  const GemmCfg cfg = pick_gemm_cfg(L, ldl, R, ldr, I, J, K, nsplit);
+  if (cfg == CFG_KG2 || cfg == CFG_KG1) {
+    GemmShape g{L, ldl, R, ldr, I, J, K, 0, 0, 0, tri};
+    return cfg == CFG_KG2 ? launch_gemm_kg<2>(g, epi, st) : launch_gemm_kg<1>(g, epi, st);
+  }
+  return launch_gemm(L, ldl, R, ldr, I, J, K, epi, st, kchunk, tri);
 }
 
 // cost-value GEMM (tile geometry is part of the epilogue type); returns the number of partial rows written
@@ -1215,7 +1269,7 @@ int gemm_tn_ex(const double *L, int64_t ldl, const double *R, int64_t ldr, doubl
               (long long)ldl, (long long)I, (long long)ldr, (long long)J, (long long)ldc);
   if (I == 0 || J == 0) return PLS_OK;
   EpiStore e{C, ldc, alpha, beta, 0};
-  return launch_gemm(L, ldl, R, ldr, I, J, K, e, st, 0, tri);
+  return launch_gemm_any(L, ldl, R, ldr, I, J, K, e, st, 0, tri);
 }
 
 // out[b] = mean of e[b * bc, min(j, (b + 1) * bc)): one block per column block, fixed-order tree
@@ -1256,6 +1310,14 @@ int pls_set_option(int32_t option, int64_t value) {
       PLS_REQUIRE(value == 0 || value == 1, "set_option: ipb explicit inverse must be 0 or 1");
       g_ipb_explicit_inverse.store(value);
       return PLS_OK;
+    case PLS_OPT_KSPLIT_MODE:
+      PLS_REQUIRE(value >= 0 && value <= 3, "set_option: k-split mode must be 0..3");
+      g_ksplit_mode.store(value);
+      return PLS_OK;
+    case PLS_OPT_KSPLIT_MAX_TILES:
+      PLS_REQUIRE(value >= 0, "set_option: k-split tile limit must be >= 0");
+      g_ksplit_max_tiles.store(value);
+      return PLS_OK;
     default: return fail(PLS_ERR_INVALID_ARGUMENT, "set_option: unknown option %d", (int)option);
   }
 }
@@ -1272,6 +1334,8 @@ int64_t pls_get_option(int32_t option) {
   switch (option) {
     case PLS_OPT_SMALL_RANK_MAX: return g_small_rank_max.load();
     case PLS_OPT_IPB_EXPLICIT_INVERSE: return g_ipb_explicit_inverse.load();
+    case PLS_OPT_KSPLIT_MODE: return g_ksplit_mode.load();
+    case PLS_OPT_KSPLIT_MAX_TILES: return g_ksplit_max_tiles.load();
     default: return -1;
   }
 }
@@ -1597,7 +1661,7 @@ static int onb_step_impl(const pls_onb_desc *basis, const pls_cost_desc *cost, c
   const EtaP etap = make_etap(eta, blocks);
   hipStream_t st = S(stream);
   if (onb_fast_path(basis, cost, force_generic)) {
-    const bool big = use_big_tiles(basis->mk, j);
+    const bool big = pick_gemm_cfg(basis->B, basis->ldb, U, ldu, basis->mk, j, basis->mk) == CFG_BIG;
     double *epart = nullptr;
     if (energy_in) {
       const int64_t parts = big ? 2 * cdiv(basis->mk, 128) : cdiv(basis->mk, 64);
@@ -1608,7 +1672,7 @@ static int onb_step_impl(const pls_onb_desc *basis, const pls_cost_desc *cost, c
     }
     EpiLangevinGaussian e{out, ldo, U, ldu, basis->c, basis->lam, etap, 1.0 / cost->p[0], out_mode, nz,
                           epart, j, 2, big ? 128 : 64};
-    rc = launch_gemm(basis->B, basis->ldb, U, ldu, basis->mk, j, basis->mk, e, st);
+    rc = launch_gemm_any(basis->B, basis->ldb, U, ldu, basis->mk, j, basis->mk, e, st);
     if (rc || !energy_in) return rc;
     const int64_t parts = big ? 2 * cdiv(basis->mk, 128) : cdiv(basis->mk, 64);
     hipLaunchKernelGGL(gaussian_energy_finish_kernel, dim3((unsigned)cdiv(j, 256)), dim3(256), 0, st, epart, j, parts, j,
@@ -1687,14 +1751,21 @@ int pls_onb_energy(const pls_onb_desc *basis, const pls_cost_desc *cost, const d
   if (j == 0) return PLS_OK;
   if (onb_fast_path(basis, cost, force_generic)) {
     // cost_j = (u^T B u - 2 c^T u + y^T y) / (2 sigma2): one Mk x Mk x J contraction, reduced per tile then per column
-    const int64_t parts = use_big_tiles(basis->mk, j) ? cdiv(basis->mk, 128) : cdiv(basis->mk, 64);
+    const GemmCfg cfg = pick_gemm_cfg(basis->B, basis->ldb, U, ldu, basis->mk, j, basis->mk);
+    const int64_t parts = cfg == CFG_BIG ? cdiv(basis->mk, 128) : cdiv(basis->mk, 64);
     if (!workspace || workspace_bytes < (size_t)parts * j * sizeof(double))
       return fail(PLS_ERR_WORKSPACE_TOO_SMALL, "onb_energy: workspace %zu bytes too small", workspace_bytes);
     double *partial = static_cast<double *>(workspace);
     GemmShape g{basis->B, basis->ldb, U, ldu, basis->mk, j, basis->mk, 0, 0, 0};
-    if (use_big_tiles(basis->mk, j)) {
+    if (cfg == CFG_BIG) {
       EpiGaussianQuad<128, 128, 64, 64> ep{partial, j, U, ldu, basis->c, basis->lam, 0.5 / cost->p[0]};
       rc = launch_gemm_cfg<128, 128, 64, 64>(g, ep, S(stream));
+    } else if (cfg == CFG_KG2) {
+      EpiGaussianQuad<64, 64, 16, 32> ep{partial, j, U, ldu, basis->c, basis->lam, 0.5 / cost->p[0]};
+      rc = launch_gemm_kg<2>(g, ep, S(stream));
+    } else if (cfg == CFG_KG1) {
+      EpiGaussianQuad<64, 64, 32, 32> ep{partial, j, U, ldu, basis->c, basis->lam, 0.5 / cost->p[0]};
+      rc = launch_gemm_kg<1>(g, ep, S(stream));
     } else {
       EpiGaussianQuad<64, 64, 32, 32> ep{partial, j, U, ldu, basis->c, basis->lam, 0.5 / cost->p[0]};
       rc = launch_gemm_cfg<64, 64, 32, 32>(g, ep, S(stream));
