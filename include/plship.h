@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PLSHIP_ABI_VERSION 2
+#define PLSHIP_ABI_VERSION 3
 
 typedef enum {
   PLS_OK = 0,
@@ -139,6 +139,15 @@ typedef struct {
   int64_t ldsf;
   const double *Sb;
   int64_t ldsb;
+  /* Optional (ABI 3): the inverse factor Linv = Lc^-1 (M x M, lower, row-major) and its transpose LinvT, as
+   * pls_chol_build_inverse leaves them (column c of Lc^-1 by forward substitution of e_c).  With them a solve is one
+   * (forward) or two (forward + backward) TRIANGULAR PRODUCTS on the MFMA contraction instead of a block substitution:
+   * any number of right-hand sides fills the chip, which the substitution -- a workgroup per 32 columns, serial over the
+   * block rows -- does not on the narrow J-shard of an 8-GPU run.  NULL: block substitution only. */
+  const double *Linv;
+  int64_t ldlinv;
+  const double *LinvT;
+  int64_t ldlinvt;
 } pls_chol_desc;
 
 /* Inducing-point basis state (reference: basis/inducing_point.py:23-50).
@@ -165,6 +174,19 @@ typedef struct {
   int64_t ldsf;
   const double *Sb;
   int64_t ldsb;
+  /* Optional (ABI 3): the inverse factor of k(Z,Z) (see pls_chol_desc) ... */
+  const double *Linv;
+  int64_t ldlinv;
+  const double *LinvT;
+  int64_t ldlinvt;
+  /* ... and the Gaussian/identity operator in WHITENED coordinates S = Lc^-1 U (pls_ipb_build_whitened, built for ONE
+   * observation noise: q_inv_noise = 1 / sigma2):  Q = Lc^-1 (B / sigma2 + M I) Lc^-T (M x M), ct = Lc^-1 c / sigma2 (M entries,
+   * then y^T y).  With them pls_ipb_step's Gaussian path is forward solve + Q S (fused update kernel) + Lc dS, and
+   * pls_ipb_whitened_step advances S itself with ONE M x M x J contraction per step. */
+  const double *Q;
+  int64_t ldq;
+  const double *ct;
+  double q_inv_noise;
 } pls_ipb_desc;
 
 /* Step-size search (experiments/runners.py:331-446): the S candidate step sizes run as S column blocks of ONE particle
@@ -195,7 +217,10 @@ typedef enum pls_option {
    * two- / one-group kernel wherever the operands are 16-byte aligned (A/B runs, tests).  MAX_TILES: the number of
    * 128 x 128 output tiles below which the automatic mode takes it (default 256: one workgroup per CU). */
   PLS_OPT_KSPLIT_MODE = 3,
-  PLS_OPT_KSPLIT_MAX_TILES = 4
+  PLS_OPT_KSPLIT_MAX_TILES = 4,
+  /* Solves with the Cholesky factor of k(Z,Z): 1 (default) = triangular products with the inverse factor wherever the
+   * descriptor carries Linv / LinvT, 0 = block substitution (tri_solve_strip_kernel) always. */
+  PLS_OPT_SOLVE_MODE = 5
 } pls_option;
 /* Diagnostic: out[i] = op(x[i]) with the device exp (op 0) / log (op 1) the per-element kernels use (csrc/fmath.h),
  * so that their accuracy can be pinned against libm.  Not on the step path. */
@@ -307,6 +332,23 @@ int pls_chol_build_operators(const double *Lc, int64_t ldlc, const double *LcT, 
 int pls_chol_solve(const pls_chol_desc *factor, const double *U, int64_t ldu, int64_t j, double *V, int64_t ldv,
                    void *stream);
 
+/* Linv = Lc^-1 and LinvT = Lc^-T (M x M each, 16-byte aligned, even leading dimensions): the identity pushed through the
+ * block forward substitution of pls_chol_solve, column by column the backward-stable solve Lc x = e_c.  Needs Sf / Sb. */
+int pls_chol_build_inverse(const pls_chol_desc *factor, double *Linv, int64_t ldlinv, double *LinvT, int64_t ldlinvt,
+                           void *stream);
+
+/* Y (M x J) = Lc^-1 U: the forward half of pls_chol_solve (one triangular product with LinvT when the descriptor has it
+ * and PLS_OPT_SOLVE_MODE is 1, block forward substitution otherwise).  Y must not alias U. */
+int pls_chol_forward_solve(const pls_chol_desc *factor, const double *U, int64_t ldu, int64_t j, double *Y, int64_t ldy,
+                           void *stream);
+
+/* pls_chol_solve with a workspace of pls_chol_solve_workspace_bytes(M, J): with Linv / LinvT in the descriptor (and
+ * PLS_OPT_SOLVE_MODE 1) the solve is two triangular products, Lc^-1 U into the workspace and Lc^-T of that into V; a
+ * narrow J-shard then uses every CU (M = 1024, J = 1024: 32 workgroups of the substitution kernel on 256 CUs). */
+size_t pls_chol_solve_workspace_bytes(int64_t m, int64_t j);
+int pls_chol_solve_ws(const pls_chol_desc *factor, const double *U, int64_t ldu, int64_t j, double *V, int64_t ldv,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
 /* out (M x J) = Lc X with the TRANSPOSED factor LcT (upper) as the k-major operand; only k <= row is contracted.
  * Colours standard normals: e = Lc xi ~ N(0, k(Z,Z)) (replaces sample_multivariate_normal's Q sqrt(Lambda) xi,
  * samplers.py:37-44, same law). */
@@ -416,6 +458,34 @@ int pls_ipb_build_gaussian(const pls_ipb_desc *basis, const double *y, double *B
 size_t pls_ipb_energy_workspace_bytes(const pls_ipb_desc *basis, int64_t j, int64_t n_chunk);
 int pls_ipb_energy(const pls_ipb_desc *basis, const pls_cost_desc *cost, const double *y, const double *U,
                    int64_t ldu, int64_t j, double *e, int32_t force_generic, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Whitened coordinates S = Lc^-1 U of the inducing-point basis, Gaussian cost with the identity link.
+ * With V = k(Z,Z)^-1 U = Lc^-T S the update of inducing_point.py:117-150 under gaussian.py:86-88,
+ *     dU = -eta ((B V - c) / sigma2 + M V) + sqrt(2 eta) Lc xi,
+ * is  dU = Lc dS,  dS = -eta (Q S - ct) + sqrt(2 eta) xi,  and the energy of inducing_point.py:95-115 is
+ * S^T Q S / 2 - ct^T S + y^T y / (2 sigma2): the same law, the same noise xi, one M x M x J contraction per step.
+ * pls_ipb_build_whitened: Q (M x M, 16-byte aligned, ldq even) and ct (M + 1 doubles) from the descriptor's B, c and
+ * Cholesky operators for inv_noise = 1 / sigma2; the caller then stores Q, ldq, ct and q_inv_noise = inv_noise in the
+ * descriptor.  workspace: pls_ipb_build_whitened_workspace_bytes(M). */
+size_t pls_ipb_build_whitened_workspace_bytes(int64_t m);
+int pls_ipb_build_whitened(const pls_ipb_desc *basis, double inv_noise, double *Q, int64_t ldq, double *ct, void *workspace,
+                           size_t workspace_bytes, void *stream);
+/* S = Lc^-1 U and back, U = Lc S (neither may alias its input). */
+int pls_ipb_whiten(const pls_ipb_desc *basis, const double *U, int64_t ldu, int64_t j, double *S, int64_t lds, void *stream);
+int pls_ipb_unwhiten(const pls_ipb_desc *basis, const double *S, int64_t lds, int64_t j, double *U, int64_t ldu, void *stream);
+/* One Langevin step of the whitened particles: out = dS (out_mode 0) or S + dS (out_mode 1); Philox noise draws the xi
+ * of the reference's e = Lc xi (same counters as pls_ipb_step), injected noise is used as xi (NOT coloured).  energy_in
+ * (optional): energy of the INPUT particles; it needs pls_ipb_whitened_workspace_bytes(basis, J) workspace bytes. */
+size_t pls_ipb_whitened_workspace_bytes(const pls_ipb_desc *basis, int64_t j);
+int pls_ipb_whitened_step(const pls_ipb_desc *basis, const pls_cost_desc *cost, const double *S, int64_t lds, int64_t j,
+                          double eta, const pls_noise_desc *noise, double *out, int64_t ldo, int32_t out_mode, double *energy_in,
+                          void *workspace, size_t workspace_bytes, void *stream);
+int pls_ipb_whitened_step_blocks(const pls_ipb_desc *basis, const pls_cost_desc *cost, const double *S, int64_t lds, int64_t j,
+                                 const pls_block_desc *blocks, const pls_noise_desc *noise, double *out, int64_t ldo,
+                                 int32_t out_mode, double *energy_in, void *workspace, size_t workspace_bytes, void *stream);
+/* e(J) of whitened particles; workspace: pls_ipb_whitened_workspace_bytes(basis, J). */
+int pls_ipb_whitened_energy(const pls_ipb_desc *basis, const pls_cost_desc *cost, const double *S, int64_t lds, int64_t j,
+                            double *e, void *workspace, size_t workspace_bytes, void *stream);
 
 /* e(J) = cost_j + (M/2) * ||k(Z,Z)^-1 U_j||^2 with the cost vector handed in (inducing_point.py:95-115).
  * workspace: m*j doubles. */

@@ -325,16 +325,20 @@ def _chol_solve(k: torch.Tensor, rhs: torch.Tensor) -> torch.Tensor:
 class OrthonormalBasis:
     """basis/orthonormal.py:22-159."""
 
-    def __init__(self, base_kernel, x_induce, x_train, eigenvalue_threshold: float = 0.0, r_kernel=None):
+    def __init__(self, base_kernel, x_induce, x_train, eigenvalue_threshold: float = 0.0, r_kernel=None, spectrum=None):
         self.base_kernel = base_kernel
         self.x_induce = x_induce
         # r(x1, x2, extra approximation samples): kernel.py:31-76 unless a test double is handed in
         self.r_kernel = r_kernel or (lambda x1, x2, extra: pls_kernel_r(base_kernel, x_induce, x1, x2, extra))
         self.base_gram_induce = base_kernel(x_induce, x_induce)  # :36-38
         self.base_gram_induce_train = base_kernel(x_induce, x_train)  # :39-41
-        self.eigenvalues, self.eigenvectors = torch.linalg.eigh(
-            (1 / self.x_induce.shape[0]) * self.base_gram_induce
-        )  # :46-48
+        if spectrum is None:
+            self.eigenvalues, self.eigenvectors = torch.linalg.eigh(
+                (1 / self.x_induce.shape[0]) * self.base_gram_induce
+            )  # :46-48
+        else:  # (not in the reference) a frozen eigendecomposition of k(Z,Z)/M: tests/golden/oracle_step_vectors.npz pins the
+            # eigenvector gauge (signs, rotations inside clusters), which LAPACK is free to choose differently per version
+            self.eigenvalues, self.eigenvectors = (torch.as_tensor(t, dtype=torch.float64) for t in spectrum)
         idx = torch.where(self.eigenvalues > eigenvalue_threshold)[0]  # :52
         self.eigenvalues = self.eigenvalues[idx].real
         self.eigenvectors = self.eigenvectors[:, idx].real

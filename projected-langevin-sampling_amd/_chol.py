@@ -28,6 +28,20 @@ class CholeskyFactor:
     def __init__(self, lc: torch.Tensor, lct: torch.Tensor, sf: torch.Tensor, sb: torch.Tensor, jitter: float):
         self.Lc, self.LcT, self.Sf, self.Sb, self.jitter = lc, lct, sf, sb, jitter
         self.m = lc.shape[0]
+        self.Linv = self.LinvT = None
+
+    def build_inverse(self) -> "CholeskyFactor":
+        """Linv = Lc^-1 and its transpose (pls_chol_build_inverse: the identity through the block forward substitution).
+        With them a solve is one or two triangular PRODUCTS on the MFMA contraction -- what fills the chip when the
+        right-hand side is a narrow J-shard -- instead of a substitution that is serial over the block rows."""
+        if self.Linv is None:
+            from .basis.base import alloc_matrix
+
+            linv, linvt = alloc_matrix(self.m, self.m, self.Lc.device), alloc_matrix(self.m, self.m, self.Lc.device)
+            L.check(L.load().pls_chol_build_inverse(self.desc(), linv.data_ptr(), L.ld(linv), linvt.data_ptr(), L.ld(linvt),
+                                                    L.stream_ptr()), "pls_chol_build_inverse")
+            self.Linv, self.LinvT = linv, linvt
+        return self
 
     def desc(self) -> L.CholDesc:
         d = L.CholDesc()
@@ -36,18 +50,34 @@ class CholeskyFactor:
         d.LcT, d.ldlct = self.LcT.data_ptr(), L.ld(self.LcT)
         d.Sf, d.ldsf = self.Sf.data_ptr(), L.ld(self.Sf)
         d.Sb, d.ldsb = self.Sb.data_ptr(), L.ld(self.Sb)
+        if self.Linv is not None:
+            d.Linv, d.ldlinv = self.Linv.data_ptr(), L.ld(self.Linv)
+            d.LinvT, d.ldlinvt = self.LinvT.data_ptr(), L.ld(self.LinvT)
         return d
 
     def solve(self, rhs: torch.Tensor) -> torch.Tensor:
-        """K^-1 rhs for a (M, J) device matrix: block forward + backward substitution, one launch."""
+        """K^-1 rhs for a (M, J) device matrix: two triangular products with the inverse factor if build_inverse() has
+        run (and PLS_OPT_SOLVE_MODE is 1), block forward + backward substitution in one launch otherwise."""
         u = L.require_gpu_tensor(rhs, "rhs")
         u = u if u.dim() == 2 and u.stride(1) == 1 else u.reshape(self.m, -1).contiguous()
         j = u.shape[1]
         v = torch.empty((self.m, j), dtype=torch.float64, device=u.device)
         if j:
-            L.check(L.load().pls_chol_solve(self.desc(), u.data_ptr(), L.ld(u), j, v.data_ptr(), max(j, 1), L.stream_ptr()),
-                    "pls_chol_solve")
+            ws = torch.empty((self.m, j), dtype=torch.float64, device=u.device) if self.Linv is not None else None
+            L.check(L.load().pls_chol_solve_ws(self.desc(), u.data_ptr(), L.ld(u), j, v.data_ptr(), max(j, 1), L.ptr(ws),
+                                               0 if ws is None else ws.numel() * 8, L.stream_ptr()), "pls_chol_solve_ws")
         return v
+
+    def forward_solve(self, rhs: torch.Tensor) -> torch.Tensor:
+        """Lc^-1 rhs (pls_chol_forward_solve)."""
+        u = L.require_gpu_tensor(rhs, "rhs")
+        u = u if u.dim() == 2 and u.stride(1) == 1 else u.reshape(self.m, -1).contiguous()
+        j = u.shape[1]
+        y = torch.empty((self.m, j), dtype=torch.float64, device=u.device)
+        if j:
+            L.check(L.load().pls_chol_forward_solve(self.desc(), u.data_ptr(), L.ld(u), j, y.data_ptr(), max(j, 1),
+                                                    L.stream_ptr()), "pls_chol_forward_solve")
+        return y
 
     def colour(self, xi: torch.Tensor) -> torch.Tensor:
         """Lc xi: standard normals (M, J) -> N(0, K) samples (triangular product)."""

@@ -82,6 +82,14 @@ class IpbDesc(C.Structure):
         ("ldsf", C.c_int64),
         ("Sb", C.c_void_p),
         ("ldsb", C.c_int64),
+        ("Linv", C.c_void_p),
+        ("ldlinv", C.c_int64),
+        ("LinvT", C.c_void_p),
+        ("ldlinvt", C.c_int64),
+        ("Q", C.c_void_p),
+        ("ldq", C.c_int64),
+        ("ct", C.c_void_p),
+        ("q_inv_noise", C.c_double),
     ]
 
 
@@ -96,6 +104,10 @@ class CholDesc(C.Structure):
         ("ldsf", C.c_int64),
         ("Sb", C.c_void_p),
         ("ldsb", C.c_int64),
+        ("Linv", C.c_void_p),
+        ("ldlinv", C.c_int64),
+        ("LinvT", C.c_void_p),
+        ("ldlinvt", C.c_int64),
     ]
 
 
@@ -150,11 +162,23 @@ SIGNATURES = {
     "pls_chol_build_operators": (C.c_int, [_P, _I64, _P, _I64, _I64, _P, _I64, _P, _I64, _P]),
     "pls_chol_solve": (C.c_int, [_CHD, _P, _I64, _I64, _P, _I64, _P]),
     "pls_tri_multiply": (C.c_int, [_P, _I64, _I64, _P, _I64, _I64, _P, _I64, _P]),
+    "pls_chol_build_inverse": (C.c_int, [_CHD, _P, _I64, _P, _I64, _P]),
+    "pls_chol_forward_solve": (C.c_int, [_CHD, _P, _I64, _I64, _P, _I64, _P]),
+    "pls_chol_solve_workspace_bytes": (_SZ, [_I64, _I64]),
+    "pls_chol_solve_ws": (C.c_int, [_CHD, _P, _I64, _I64, _P, _I64, _P, _SZ, _P]),
+    "pls_ipb_build_whitened_workspace_bytes": (_SZ, [_I64]),
+    "pls_ipb_build_whitened": (C.c_int, [_ID, _D, _P, _I64, _P, _P, _SZ, _P]),
+    "pls_ipb_whiten": (C.c_int, [_ID, _P, _I64, _I64, _P, _I64, _P]),
+    "pls_ipb_unwhiten": (C.c_int, [_ID, _P, _I64, _I64, _P, _I64, _P]),
+    "pls_ipb_whitened_workspace_bytes": (_SZ, [_ID, _I64]),
+    "pls_ipb_whitened_step": (C.c_int, [_ID, _CD, _P, _I64, _I64, _D, _ND, _P, _I64, _I32, _P, _P, _SZ, _P]),
+    "pls_ipb_whitened_step_blocks": (C.c_int, [_ID, _CD, _P, _I64, _I64, _BD, _ND, _P, _I64, _I32, _P, _P, _SZ, _P]),
+    "pls_ipb_whitened_energy": (C.c_int, [_ID, _CD, _P, _I64, _I64, _P, _P, _SZ, _P]),
     "pls_onb_step_blocks": (C.c_int, [_OD, _CD, _P, _P, _I64, _I64, _BD, _ND, _P, _I64, _I32, _I32, _P, _P, _SZ, _P]),
     "pls_ipb_step_blocks": (C.c_int, [_ID, _CD, _P, _P, _I64, _I64, _BD, _ND, _P, _I64, _I32, _I32, _P, _P, _SZ, _P]),
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib = None
 
@@ -184,6 +208,7 @@ OPT_SMALL_RANK_MAX = 1
 OPT_IPB_EXPLICIT_INVERSE = 2
 OPT_KSPLIT_MODE = 3
 OPT_KSPLIT_MAX_TILES = 4
+OPT_SOLVE_MODE = 5
 TAG_NAMES = {1: "gemm_store", 2: "gemm_cost_deriv", 3: "gemm_cost_value", 4: "gemm_langevin_gaussian",
              5: "langevin_update", 6: "kernel_gram", 7: "other", 8: "small_rank_drift", 9: "small_rank_value",
              10: "tri_solve"}

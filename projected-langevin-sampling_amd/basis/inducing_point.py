@@ -50,6 +50,9 @@ class InducingPointBasis(PLSBasis):
             self._chol = _chol.cholesky_factor(self.base_gram_induce)  # what gpytorch.solve does, on the device
         else:
             self._chol = _chol.factor_from_host(cholesky_factor)
+        # the inverse factor Lc^-1: every solve with k(Z,Z) becomes triangular products on the MFMA contraction, which
+        # fill the chip for any number of particle columns (a rank of an 8-GPU run holds J / 8 of them)
+        self._chol.build_inverse()
         self._W = None
         if explicit_inverse:  # A/B only: the contraction W U instead of the two triangular solves
             self._W = _dev(torch.cholesky_inverse(self._chol.Lc.cpu()))
@@ -59,6 +62,10 @@ class InducingPointBasis(PLSBasis):
         self._B = None  # Gaussian fast path constants, keyed by the y they were built from
         self._c = None
         self._gauss_key = None
+        self._Q = None  # ... and the same operator in whitened coordinates, keyed by (y, observation noise)
+        self._ct = None
+        self._q_inv_noise = 0.0
+        self._white_key = None
 
     @property
     def approximation_dimension(self) -> int:
@@ -75,24 +82,123 @@ class InducingPointBasis(PLSBasis):
         d.LcT, d.ldlct = f.LcT.data_ptr(), L.ld(f.LcT)
         d.Sf, d.ldsf = f.Sf.data_ptr(), L.ld(f.Sf)
         d.Sb, d.ldsb = f.Sb.data_ptr(), L.ld(f.Sb)
+        if f.Linv is not None:
+            d.Linv, d.ldlinv = f.Linv.data_ptr(), L.ld(f.Linv)
+            d.LinvT, d.ldlinvt = f.LinvT.data_ptr(), L.ld(f.LinvT)
         if with_gaussian and self._B is not None:
             d.B, d.ldb, d.c = self._B.data_ptr(), L.ld(self._B), self._c.data_ptr()
+            if self._Q is not None and self.whitened:
+                d.Q, d.ldq, d.ct, d.q_inv_noise = self._Q.data_ptr(), L.ld(self._Q), self._ct.data_ptr(), self._q_inv_noise
         return d
 
-    def prepare_gaussian(self, y_dev: torch.Tensor) -> None:
-        """B = k(Z,X) k(X,Z), c = k(Z,X) y: the Gaussian/identity step becomes two M x M x J products (pls_ipb_build_gaussian)."""
+    #: take the Gaussian/identity step in whitened coordinates (pls_ipb_build_whitened); False: the round-2 route
+    #: (solve, B V, Lc xi, update) -- kept for A/B runs and tests
+    whitened = True
+
+    def prepare_gaussian(self, y_dev: torch.Tensor, observation_noise: float | None = None) -> None:
+        """B = k(Z,X) k(X,Z), c = k(Z,X) y (pls_ipb_build_gaussian) and, for the cost's observation noise, the same
+        operator in whitened coordinates: Q = Lc^-1 (B / sigma2 + M I) Lc^-T, c~ = Lc^-1 c / sigma2 (pls_ipb_build_whitened)."""
         key = (y_dev.data_ptr(), y_dev._version)
-        if self._gauss_key == key:
-            return
+        lib = L.load()
         m = self.approximation_dimension
-        self._B = alloc_matrix(m, m, y_dev.device)
-        self._c = torch.empty(m + 1, dtype=torch.float64, device=y_dev.device)
+        if self._gauss_key != key:
+            self._B = alloc_matrix(m, m, y_dev.device)
+            self._c = torch.empty(m + 1, dtype=torch.float64, device=y_dev.device)
+            L.check(
+                lib.pls_ipb_build_gaussian(self._desc(), y_dev.data_ptr(), self._B.data_ptr(), L.ld(self._B), self._c.data_ptr(),
+                                           L.stream_ptr()),
+                "pls_ipb_build_gaussian",
+            )
+            self._gauss_key = key
+            self._white_key = None
+        if observation_noise is None or not self.whitened:
+            return
+        inv_noise = 1.0 / float(observation_noise)
+        wkey = (key, inv_noise)
+        if self._white_key == wkey:
+            return
+        q = alloc_matrix(m, m, y_dev.device)
+        ct = torch.empty(m + 1, dtype=torch.float64, device=y_dev.device)
+        ws_bytes = lib.pls_ipb_build_whitened_workspace_bytes(m)
+        ws = torch.empty(ws_bytes // 8 + 1, dtype=torch.float64, device=y_dev.device)
+        self._Q = None  # (the descriptor of the build call must not carry a stale operator)
         L.check(
-            L.load().pls_ipb_build_gaussian(self._desc(), y_dev.data_ptr(), self._B.data_ptr(), L.ld(self._B), self._c.data_ptr(),
-                                            L.stream_ptr()),
-            "pls_ipb_build_gaussian",
+            lib.pls_ipb_build_whitened(self._desc(with_gaussian=True), inv_noise, q.data_ptr(), L.ld(q), ct.data_ptr(),
+                                       ws.data_ptr(), ws_bytes, L.stream_ptr()),
+            "pls_ipb_build_whitened",
         )
-        self._gauss_key = key
+        self._Q, self._ct, self._q_inv_noise, self._white_key = q, ct, inv_noise, wkey
+
+    def _prepare_for(self, cost) -> None:
+        self.prepare_gaussian(cost.y_device(), float(cost.desc().p[0]))
+
+    # ---- whitened coordinates S = Lc^-1 U (Gaussian cost, identity link) ------------------------------------------------
+    def whiten(self, particles: torch.Tensor) -> torch.Tensor:
+        """S = Lc^-1 U (pls_ipb_whiten)."""
+        u = _rows_contiguous(L.require_gpu_tensor(particles, "particles"))
+        s = torch.empty_like(u, memory_format=torch.contiguous_format)
+        if u.shape[1]:
+            L.check(L.load().pls_ipb_whiten(self._desc(), u.data_ptr(), L.ld(u), u.shape[1], s.data_ptr(), L.ld(s), L.stream_ptr()),
+                    "pls_ipb_whiten")
+        return s
+
+    def unwhiten(self, whitened: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+        """U = Lc S (pls_ipb_unwhiten)."""
+        s = _rows_contiguous(L.require_gpu_tensor(whitened, "whitened particles"))
+        u = torch.empty_like(s, memory_format=torch.contiguous_format) if out is None else out
+        if s.shape[1]:
+            L.check(L.load().pls_ipb_unwhiten(self._desc(), s.data_ptr(), L.ld(s), s.shape[1], u.data_ptr(), L.ld(u), L.stream_ptr()),
+                    "pls_ipb_unwhiten")
+        return u
+
+    def whitened_step(self, cost, whitened: torch.Tensor, step_size: float, out: torch.Tensor | None = None,
+                      new_state: bool = False, noise: NoiseSpec | None = None, input_energy: torch.Tensor | None = None,
+                      blocks: BlockSpec | None = None, workspace: torch.Tensor | None = None) -> torch.Tensor:
+        """One Langevin step of whitened particles (pls_ipb_whitened_step): ONE M x M x J contraction with the update,
+        the noise and -- optionally -- the energy of the input particles in its epilogue.  ``noise`` injected = xi itself
+        (standard normal, not coloured); Philox noise draws the xi of fused_step's e = Lc xi."""
+        assert self._is_gaussian(cost, False), "whitened steps exist for the Gaussian cost with the identity link"
+        s = _rows_contiguous(L.require_gpu_tensor(whitened, "whitened particles"))
+        j = s.shape[1]
+        if out is None:
+            out = torch.empty_like(s, memory_format=torch.contiguous_format)
+        if j == 0:
+            return out
+        assert out.data_ptr() != s.data_ptr(), "whitened_step: out must not alias its input"
+        assert self.whitened, "whitened coordinates are switched off on this basis"
+        self._prepare_for(cost)
+        lib = L.load()
+        desc = self._desc(with_gaussian=True)
+        ws, ws_bytes = None, 0
+        if input_energy is not None:
+            ws_bytes = lib.pls_ipb_whitened_workspace_bytes(desc, j)
+            ws = self._pick_workspace(workspace, ws_bytes, s.device)
+        nd = (noise if noise is not None else self._draw_noise_spec(None)).desc()
+        mode = L.OUT_NEW_STATE if new_state else L.OUT_DELTA
+        if blocks is None:
+            L.check(lib.pls_ipb_whitened_step(desc, cost.desc(), s.data_ptr(), L.ld(s), j, float(step_size), nd, out.data_ptr(),
+                                              L.ld(out), mode, L.ptr(input_energy), L.ptr(ws), ws_bytes, L.stream_ptr()),
+                    "pls_ipb_whitened_step")
+        else:
+            L.check(lib.pls_ipb_whitened_step_blocks(desc, cost.desc(), s.data_ptr(), L.ld(s), j, blocks.desc(), nd,
+                                                     out.data_ptr(), L.ld(out), mode, L.ptr(input_energy), L.ptr(ws), ws_bytes,
+                                                     L.stream_ptr()), "pls_ipb_whitened_step_blocks")
+        return out
+
+    def whitened_particle_energy(self, cost, whitened: torch.Tensor) -> torch.Tensor:
+        """e_j of whitened particles: S^T Q S / 2 - c~^T S + y^T y / (2 sigma2) (pls_ipb_whitened_energy)."""
+        s = _rows_contiguous(L.require_gpu_tensor(whitened, "whitened particles"))
+        j = s.shape[1]
+        self._prepare_for(cost)
+        lib = L.load()
+        desc = self._desc(with_gaussian=True)
+        ws_bytes = lib.pls_ipb_whitened_workspace_bytes(desc, j)
+        ws = self._workspace(ws_bytes, s.device)
+        e = torch.empty(j, dtype=torch.float64, device=s.device)
+        if j:
+            L.check(lib.pls_ipb_whitened_energy(desc, cost.desc(), s.data_ptr(), L.ld(s), j, e.data_ptr(), ws.data_ptr(), ws_bytes,
+                                                L.stream_ptr()), "pls_ipb_whitened_energy")
+        return e
 
     @staticmethod
     def _is_gaussian(cost, force_generic: bool) -> bool:
@@ -173,7 +279,7 @@ class InducingPointBasis(PLSBasis):
         lib = L.load()
         gaussian = self._is_gaussian(cost, force_generic)
         if gaussian:
-            self.prepare_gaussian(cost.y_device())
+            self._prepare_for(cost)
         desc = self._desc(with_gaussian=gaussian)
         need_min = lib.pls_ipb_step_workspace_bytes(desc, j, 128)
         need_full = lib.pls_ipb_step_workspace_bytes(desc, j, self._n)
@@ -214,7 +320,7 @@ class InducingPointBasis(PLSBasis):
         lib = L.load()
         gaussian = self._is_gaussian(cost, force_generic)
         if gaussian:
-            self.prepare_gaussian(cost.y_device())
+            self._prepare_for(cost)
         desc = self._desc(with_gaussian=gaussian)
         ws_bytes = lib.pls_ipb_energy_workspace_bytes(desc, j, self._n)
         ws = self._workspace(ws_bytes, u.device)

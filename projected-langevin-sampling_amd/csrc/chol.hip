@@ -585,6 +585,45 @@ __global__ __launch_bounds__(512) void tri_solve_strip_kernel(StripArgs a, int f
     strip_solve<false>(a, fwd_only, j0, lds);
 }
 
+// out (cols x rows) = in^T, 32 x 32 tiles through LDS (both sides coalesced)
+__global__ __launch_bounds__(256) void transpose_kernel(const double *__restrict__ in, int64_t ldi, double *__restrict__ out,
+                                                        int64_t ldo, int64_t rows, int64_t cols) {
+  __shared__ double t[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int64_t r0 = (int64_t)blockIdx.y * 32, c0 = (int64_t)blockIdx.x * 32;
+  for (int k = ty; k < 32; k += 8)
+    if (r0 + k < rows && c0 + tx < cols) t[k][tx] = in[(r0 + k) * ldi + c0 + tx];
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8)
+    if (c0 + k < cols && r0 + tx < rows) out[(c0 + k) * ldo + r0 + tx] = t[tx][k];
+}
+
+// out = alpha * in + diag * I  (m x m); in may be NULL (out = diag * I)
+__global__ __launch_bounds__(256) void scale_add_diag_kernel(const double *__restrict__ in, int64_t ldi, double alpha, double diag,
+                                                             double *__restrict__ out, int64_t ldo, int64_t m) {
+  const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (col >= m) return;
+  for (int64_t row = blockIdx.y; row < m; row += gridDim.y) {
+    const double v = in ? alpha * in[row * ldi + col] : 0.0;
+    out[row * ldo + col] = (row == col) ? v + diag : v;
+  }
+}
+
+int launch_transpose(const double *in, int64_t ldi, double *out, int64_t ldo, int64_t rows, int64_t cols, hipStream_t st) {
+  if (rows <= 0 || cols <= 0) return PLS_OK;
+  hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)cdiv(cols, 32), (unsigned)cdiv(rows, 32)), dim3(256), 0, st, in, ldi, out,
+                     ldo, rows, cols);
+  return check_launch("transpose");
+}
+
+int launch_scale_add_diag(const double *in, int64_t ldi, double alpha, double diag, double *out, int64_t ldo, int64_t m,
+                          hipStream_t st) {
+  if (m <= 0) return PLS_OK;
+  const unsigned gy = (unsigned)(m < 1024 ? m : 1024);
+  hipLaunchKernelGGL(scale_add_diag_kernel, dim3((unsigned)cdiv(m, 256), gy), dim3(256), 0, st, in, ldi, alpha, diag, out, ldo, m);
+  return check_launch("scale_add_diag");
+}
+
 static size_t strip_lds_bytes() { return (size_t)4 * TS_TILE * sizeof(double); }
 
 int chol_solve_launch(const pls_chol_desc *f, const double *U, int64_t ldu, int64_t j, double *V, int64_t ldv,
@@ -597,6 +636,28 @@ int chol_solve_launch(const pls_chol_desc *f, const double *U, int64_t ldu, int6
     hipLaunchKernelGGL(tri_solve_strip_kernel, dim3((unsigned)cdiv(j, TS_SC)), dim3(512), strip_lds_bytes(), st, a, fwd_only);
   }
   return check_launch("tri_solve_strip");
+}
+
+// Y = Lc^-1 U.  With the inverse factor in the descriptor (pls_chol_build_inverse) and solve mode 1 this is ONE
+// triangular product on the MFMA contraction -- any number of columns fills the chip (a narrow J-shard gives the strip
+// kernel cdiv(j, 32) workgroups for 256 CUs); otherwise block forward substitution (strip kernel).
+int chol_forward_solve(const pls_chol_desc *f, const double *U, int64_t ldu, int64_t j, double *Y, int64_t ldy, hipStream_t st) {
+  if (f->LinvT && solve_mode() != 0)
+    return gemm_tn_ex(f->LinvT, f->ldlinvt, U, ldu, Y, ldy, f->m, j, f->m, 1.0, 0.0, 1, st);
+  if (!f->Sf || !f->Sb) return fail(PLS_ERR_INVALID_ARGUMENT, "forward solve: the factor has neither substitution operators nor its inverse");
+  return chol_solve_launch(f, U, ldu, j, Y, ldy, 1, st);
+}
+
+// V = Lc^-T Lc^-1 U; tmp (m x j, leading dimension j) is only needed by the two-product form
+int chol_full_solve(const pls_chol_desc *f, const double *U, int64_t ldu, int64_t j, double *V, int64_t ldv, double *tmp,
+                    hipStream_t st) {
+  if (tmp && f->Linv && f->LinvT && solve_mode() != 0) {
+    int rc = gemm_tn_ex(f->LinvT, f->ldlinvt, U, ldu, tmp, j, f->m, j, f->m, 1.0, 0.0, 1, st);  // y = Linv u: k <= row
+    if (rc) return rc;
+    return gemm_tn_ex(f->Linv, f->ldlinv, tmp, j, V, ldv, f->m, j, f->m, 1.0, 0.0, 2, st);  // v = Linv^T y: k >= row
+  }
+  if (!f->Sf || !f->Sb) return fail(PLS_ERR_INVALID_ARGUMENT, "solve: the factor has neither substitution operators nor its inverse");
+  return chol_solve_launch(f, U, ldu, j, V, ldv, 0, st);
 }
 
 }  // namespace plship
@@ -676,6 +737,38 @@ int pls_chol_solve(const pls_chol_desc *f, const double *U, int64_t ldu, int64_t
   PLS_REQUIRE(U != V, "chol_solve: V must not alias U");
   if (j == 0) return PLS_OK;
   return chol_solve_launch(f, U, ldu, j, V, ldv, 0, S(stream));
+}
+
+int pls_chol_build_inverse(const pls_chol_desc *f, double *Linv, int64_t ldlinv, double *LinvT, int64_t ldlinvt, void *stream) {
+  PLS_REQUIRE(f && f->Sf && f->Sb && f->m > 0 && f->ldsf >= f->m && f->ldsb >= f->m, "chol_build_inverse: bad factor descriptor");
+  PLS_REQUIRE(Linv && LinvT && Linv != LinvT && ldlinv >= f->m && ldlinvt >= f->m, "chol_build_inverse: bad arguments");
+  PLS_REQUIRE(((ldlinv | ldlinvt) & 1) == 0 && ((reinterpret_cast<uintptr_t>(Linv) | reinterpret_cast<uintptr_t>(LinvT)) & 15) == 0,
+              "chol_build_inverse: outputs must be 16-byte aligned with even leading dimensions");
+  hipStream_t st = S(stream);
+  // the identity (in LinvT) as the right-hand side of a forward substitution: column c of Lc^-1 solves Lc x = e_c
+  int rc = launch_scale_add_diag(nullptr, 0, 0.0, 1.0, LinvT, ldlinvt, f->m, st);
+  if (rc) return rc;
+  rc = chol_solve_launch(f, LinvT, ldlinvt, f->m, Linv, ldlinv, 1, st);
+  if (rc) return rc;
+  return launch_transpose(Linv, ldlinv, LinvT, ldlinvt, f->m, f->m, st);
+}
+
+int pls_chol_forward_solve(const pls_chol_desc *f, const double *U, int64_t ldu, int64_t j, double *Y, int64_t ldy, void *stream) {
+  PLS_REQUIRE(f && f->m > 0, "chol_forward_solve: bad factor descriptor");
+  PLS_REQUIRE(U && Y && j >= 0 && ldu >= j && ldy >= j && U != Y, "chol_forward_solve: bad arguments");
+  if (j == 0) return PLS_OK;
+  return chol_forward_solve(f, U, ldu, j, Y, ldy, S(stream));
+}
+
+size_t pls_chol_solve_workspace_bytes(int64_t m, int64_t j) { return (m > 0 && j > 0) ? (size_t)m * j * sizeof(double) : 0; }
+
+int pls_chol_solve_ws(const pls_chol_desc *f, const double *U, int64_t ldu, int64_t j, double *V, int64_t ldv, void *workspace,
+                      size_t workspace_bytes, void *stream) {
+  PLS_REQUIRE(f && f->m > 0, "chol_solve_ws: bad factor descriptor");
+  PLS_REQUIRE(U && V && j >= 0 && ldu >= j && ldv >= j && U != V, "chol_solve_ws: bad arguments");
+  if (j == 0) return PLS_OK;
+  double *tmp = (workspace && workspace_bytes >= pls_chol_solve_workspace_bytes(f->m, j)) ? static_cast<double *>(workspace) : nullptr;
+  return chol_full_solve(f, U, ldu, j, V, ldv, tmp, S(stream));
 }
 
 int pls_tri_multiply(const double *LcT, int64_t ldlct, int64_t m, const double *X, int64_t ldx, int64_t j, double *out,

@@ -26,7 +26,7 @@ static int launch_gemm_cfg(GemmShape g, const Epi &epi, hipStream_t st) {
   g.nti = (int)cdiv(g.I, BI);
   g.ntj = (int)cdiv(g.J, BJ);
   // (a triangular operand pairs tile rows t and nti - 1 - t in one workgroup: gemm_tn_f64_kernel)
-  const int64_t nwg = (int64_t)(g.tri ? (g.nti + 1) / 2 : g.nti) * g.ntj;
+  const int64_t nwg = (int64_t)((g.tri && Epi::kTag == 1) ? (g.nti + 1) / 2 : g.nti) * g.ntj;
   if (nwg <= 0) return PLS_OK;
   if (nwg > 0x7fffffff) return fail(PLS_ERR_INVALID_ARGUMENT, "gemm: too many tiles");
   unsigned nsplit = 1;

@@ -36,7 +36,8 @@ struct GemmShape {
   int64_t I, J, K;
   int nti, ntj;
   int64_t kchunk;  // split-K: block (x, y) contracts k in [y * kchunk, min(K, (y + 1) * kchunk)); gridDim.y slabs
-  int tri;         // L[k][i] == 0 for k > i (upper-triangular k-major operand): a tile contracts k < i0 + BI only
+  int tri;         // 1: L[k][i] == 0 for k > i (upper-triangular k-major operand), a tile contracts k < i0 + BI only;
+                   // 2: L[k][i] == 0 for k < i (lower-triangular), a tile contracts k >= i0 only
 #ifdef PLS_STAMP
   unsigned long long *stamps;  // diagnostic build only: 4 s_memtime stamps per workgroup (never read by the kernel)
 #endif
@@ -402,7 +403,13 @@ __device__ __forceinline__ void gemm_tile(GemmShape g, const Epilogue &epi, int 
     g.K = (g.K - k0 < g.kchunk) ? g.K - k0 : g.kchunk;
   }
 
-  if (g.tri && i0 + BI < g.K) g.K = i0 + BI;  // triangular operand: the rows below the tile's last column are zero
+  if (g.tri == 1 && i0 + BI < g.K) g.K = i0 + BI;  // L[k][i] == 0 for k > i: the rows below the tile's last column are zero
+  if (g.tri == 2) {  // L[k][i] == 0 for k < i: the rows above the tile's first column are zero
+    const int64_t k0 = i0 < g.K ? i0 : g.K;
+    g.L += k0 * g.ldl;
+    g.R += k0 * g.ldr;
+    g.K -= k0;
+  }
   PLS_STAMP_AT(0);
   AccFrag<TI, TJ> acc;
 #pragma unroll

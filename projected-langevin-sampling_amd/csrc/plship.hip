@@ -55,8 +55,7 @@ struct EpiGaussianQuad {
                         int tile_i, int, double *lds) const {
     double s = 0.0;
     const double cl = load_row_constants(c, iw, lane, I);
-    const double laml = load_row_constants(lam, iw, lane, I);
-    const double hil = (iw + lane < I) ? 0.5 / laml : 0.0;  // 0.5 / lambda_i
+    const double hil = (lam && iw + lane < I) ? 0.5 / lam[iw + lane] : 0.0;  // 0.5 / lambda_i (lam == NULL: no prior term)
     epilogue_row_pairs<TI, TJ>(acc, iw, jw, lane, wave, I, J, lds, cl, hil,
                                [&](int64_t, int64_t, double v0, bool hi, double v1, const RowConsts &rc) {
                                  const double u0 = rc.x_lo;
@@ -165,7 +164,7 @@ struct EpiLangevinGaussian {
     const int ldo4 = (int)(ldo * 32), ldu4 = (int)(ldu * 32);  // bytes per 4 rows
     // per-row constants of the wave's 64 rows -> wave-private LDS
     wlds[lane] = c[iw + lane];
-    wlds[64 + lane] = 1.0 / lam[iw + lane];
+    wlds[64 + lane] = lam ? 1.0 / lam[iw + lane] : 0.0;  // (lam == NULL: no prior term)
     // per-column constants of this lane's TJ columns
     double a2[TJ], s2[TJ], es[TJ];
     uint32_t jg[TJ];
@@ -268,8 +267,7 @@ struct EpiLangevinGaussian {
     double es = 0.0;
     const double pscale = 0.5 * inv_noise;
     const double cl = load_row_constants(c, iw, lane, I);
-    const double laml = load_row_constants(lam, iw, lane, I);
-    const double ilaml = (iw + lane < I) ? 1.0 / laml : 0.0;
+    const double ilaml = (lam && iw + lane < I) ? 1.0 / lam[iw + lane] : 0.0;
     const uint64_t nstep = nz.live_step();
     // a lane owns ONE column for the whole epilogue: its step size and Philox column are loop invariants
     const int64_t jl = jw + lane % (TJ * 16);
@@ -327,6 +325,41 @@ struct EpiLangevinGaussian {
   }
 };
 
+
+// Last product of the whitened inducing-point step: acc = Lc dS (the update mapped back from whitened coordinates),
+//   out = [U +] acc + sqrt(2 eta_col) * e      (e: injected, already coloured noise of a parity run; NULL otherwise)
+// (tagged as a plain store: with a triangular operand the launcher pairs tile rows t and nti - 1 - t like EpiStore's)
+struct EpiIpbFinish {
+  static constexpr int kTag = PLS_TAG_GEMM_STORE;
+  static constexpr bool kDirect = false;
+  double *out;
+  int64_t ldo;
+  const double *U;
+  int64_t ldu;
+  int add_u;
+  EtaP etap;
+  const double *xi;
+  int64_t ldxi;
+  template <int TI, int TJ>
+  __device__ void apply(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int wave, int64_t I, int64_t J, int, int,
+                        double *lds) const {
+    const int64_t jl = jw + lane % (TJ * 16);
+    const int64_t jc = jl < J ? jl : J - 1;
+    const double s2 = xi ? sqrt(2.0 * etap.at(jc)) : 0.0;
+    epilogue_row_pairs<TI, TJ, 0>(
+        acc, iw, jw, lane, wave, I, J, lds, 0.0, 0.0,
+        [&](int64_t i, int64_t j, double v0, bool hi, double v1, const RowConsts &rc) {
+          double o0 = add_u ? rc.x_lo + v0 : v0, o1 = add_u ? rc.x_hi + v1 : v1;
+          if (xi) {
+            o0 = fma(s2, xi[i * ldxi + j], o0);
+            if (hi) o1 = fma(s2, xi[(i + 4) * ldxi + j], o1);
+          }
+          out[i * ldo + j] = o0;
+          if (hi) out[(i + 4) * ldo + j] = o1;
+        },
+        add_u ? U : nullptr, ldu);
+  }
+};
 
 // Split-K plan for the back-projection D (I x J) = L^T R with a long contraction (K = rows of the N chunk).  Two reasons
 // to cut the contraction into slabs (summed in a fixed order by the update kernel: deterministic, no atomics):
@@ -915,6 +948,12 @@ __global__ __launch_bounds__(256) void matvec_rows_kernel(const double *__restri
   if (threadIdx.x == 0) c[blockIdx.x] = red[0];
 }
 
+// out[i] = alpha * in[i], i < n
+__global__ __launch_bounds__(256) void scale_copy_kernel(const double *__restrict__ in, double alpha, double *__restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = alpha * in[i];
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // greedy conditional-variance inducing-point selection (reference: src/inducing_point_selectors/conditional_variance.py)
 // ---------------------------------------------------------------------------------------------------------------
@@ -1123,6 +1162,8 @@ static int validate_noise(const pls_noise_desc *n, int64_t rows) {
 // ---- small projection ranks: fused kernels (small_rank.h) -------------------------------------------------------
 static std::atomic<int64_t> g_small_rank_max{128};  // pls_set_option(PLS_OPT_SMALL_RANK_MAX)
 static std::atomic<int64_t> g_ipb_explicit_inverse{0};  // pls_set_option(PLS_OPT_IPB_EXPLICIT_INVERSE)
+static std::atomic<int64_t> g_solve_mode{1};  // pls_set_option(PLS_OPT_SOLVE_MODE): 0 block substitution, 1 inverse-factor products where available
+int64_t solve_mode() { return g_solve_mode.load(); }
 
 static bool small_rank_ok(const double *Lb, int64_t ldlb, int64_t kdim) {
   return kdim >= 1 && kdim <= g_small_rank_max.load() && (ldlb & 1) == 0 && (reinterpret_cast<uintptr_t>(Lb) & 15) == 0;
@@ -1292,6 +1333,71 @@ __global__ __launch_bounds__(256) void block_means_kernel(const double *__restri
 
 using namespace plship;
 
+// The Gaussian/identity step as a function of its operator: out = [U +] -eta (inv_noise (B U - c) + U / lam) + sqrt(2 eta) xi,
+// one fused contraction.  The orthonormal basis passes (A A^T, A y, lam, 1 / sigma2); the inducing-point basis in
+// whitened coordinates passes (Q, c~, NULL, 1) -- see pls_ipb_build_whitened.  energy_in: per-particle energy of the INPUT
+// particles from the same product,  sum_i u_i (inv_noise / 2 (B u)_i - inv_noise c_i) + u_i^2 / (2 lam_i) + yscale * yty.
+struct FastOp {
+  const double *B;
+  int64_t ldb;
+  const double *c, *lam;
+  int64_t mk;
+  double inv_noise, yscale;
+  const double *yty;
+};
+
+static int fast_step_launch(const FastOp &op, const double *U, int64_t ldu, int64_t j, const EtaP &etap, const NoiseP &nz,
+                            double *out, int64_t ldo, int out_mode, double *energy_in, void *workspace,
+                            size_t workspace_bytes, hipStream_t st, const char *who) {
+  const bool big = pick_gemm_cfg(op.B, op.ldb, U, ldu, op.mk, j, op.mk) == CFG_BIG;
+  const int64_t parts = big ? 2 * cdiv(op.mk, 128) : cdiv(op.mk, 64);
+  double *epart = nullptr;
+  if (energy_in) {
+    if (!workspace || workspace_bytes < (size_t)parts * j * sizeof(double))
+      return fail(PLS_ERR_WORKSPACE_TOO_SMALL, "%s: energy by-product needs %zu workspace bytes", who,
+                  (size_t)parts * j * sizeof(double));
+    epart = static_cast<double *>(workspace);
+  }
+  EpiLangevinGaussian e{out, ldo, U, ldu, op.c, op.lam, etap, op.inv_noise, out_mode, nz, epart, j, 2, big ? 128 : 64};
+  int rc = launch_gemm_any(op.B, op.ldb, U, ldu, op.mk, j, op.mk, e, st);
+  if (rc || !energy_in) return rc;
+  hipLaunchKernelGGL(gaussian_energy_finish_kernel, dim3((unsigned)cdiv(j, 256)), dim3(256), 0, st, epart, j, parts, j,
+                     energy_in, op.yscale, op.yty);
+  return check_launch("gaussian_energy_finish");
+}
+
+// e_j = (inv_noise / 2) u^T B u - inv_noise c^T u + sum_i u_i^2 / (2 lam_i) + yscale * yty: one contraction, reduced per
+// tile then per column
+static int fast_energy_launch(const FastOp &op, const double *U, int64_t ldu, int64_t j, double *e, void *workspace,
+                              size_t workspace_bytes, hipStream_t st, const char *who) {
+  const GemmCfg cfg = pick_gemm_cfg(op.B, op.ldb, U, ldu, op.mk, j, op.mk);
+  const int64_t parts = cfg == CFG_BIG ? cdiv(op.mk, 128) : cdiv(op.mk, 64);
+  if (!workspace || workspace_bytes < (size_t)parts * j * sizeof(double))
+    return fail(PLS_ERR_WORKSPACE_TOO_SMALL, "%s: workspace %zu bytes too small", who, workspace_bytes);
+  double *partial = static_cast<double *>(workspace);
+  GemmShape g{op.B, op.ldb, U, ldu, op.mk, j, op.mk, 0, 0, 0};
+  const double ps = 0.5 * op.inv_noise;
+  int rc;
+  if (cfg == CFG_BIG) {
+    EpiGaussianQuad<128, 128, 64, 64> ep{partial, j, U, ldu, op.c, op.lam, ps};
+    rc = launch_gemm_cfg<128, 128, 64, 64>(g, ep, st);
+  } else if (cfg == CFG_KG2) {
+    EpiGaussianQuad<64, 64, 16, 32> ep{partial, j, U, ldu, op.c, op.lam, ps};
+    rc = launch_gemm_kg<2>(g, ep, st);
+  } else if (cfg == CFG_KG1) {
+    EpiGaussianQuad<64, 64, 32, 32> ep{partial, j, U, ldu, op.c, op.lam, ps};
+    rc = launch_gemm_kg<1>(g, ep, st);
+  } else {
+    EpiGaussianQuad<64, 64, 32, 32> ep{partial, j, U, ldu, op.c, op.lam, ps};
+    rc = launch_gemm_cfg<64, 64, 32, 32>(g, ep, st);
+  }
+  if (rc) return rc;
+  hipLaunchKernelGGL(gaussian_energy_finish_kernel, dim3((unsigned)cdiv(j, 256)), dim3(256), 0, st, partial, j, parts, j, e,
+                     op.yscale, op.yty);
+  return check_launch("gaussian_energy_finish");
+}
+
+
 // =================================================================================================================
 // C ABI
 // =================================================================================================================
@@ -1309,6 +1415,10 @@ int pls_set_option(int32_t option, int64_t value) {
     case PLS_OPT_IPB_EXPLICIT_INVERSE:
       PLS_REQUIRE(value == 0 || value == 1, "set_option: ipb explicit inverse must be 0 or 1");
       g_ipb_explicit_inverse.store(value);
+      return PLS_OK;
+    case PLS_OPT_SOLVE_MODE:
+      PLS_REQUIRE(value == 0 || value == 1, "set_option: solve mode must be 0 or 1");
+      g_solve_mode.store(value);
       return PLS_OK;
     case PLS_OPT_KSPLIT_MODE:
       PLS_REQUIRE(value >= 0 && value <= 3, "set_option: k-split mode must be 0..3");
@@ -1334,6 +1444,7 @@ int64_t pls_get_option(int32_t option) {
   switch (option) {
     case PLS_OPT_SMALL_RANK_MAX: return g_small_rank_max.load();
     case PLS_OPT_IPB_EXPLICIT_INVERSE: return g_ipb_explicit_inverse.load();
+    case PLS_OPT_SOLVE_MODE: return g_solve_mode.load();
     case PLS_OPT_KSPLIT_MODE: return g_ksplit_mode.load();
     case PLS_OPT_KSPLIT_MAX_TILES: return g_ksplit_max_tiles.load();
     default: return -1;
@@ -1661,23 +1772,8 @@ static int onb_step_impl(const pls_onb_desc *basis, const pls_cost_desc *cost, c
   const EtaP etap = make_etap(eta, blocks);
   hipStream_t st = S(stream);
   if (onb_fast_path(basis, cost, force_generic)) {
-    const bool big = pick_gemm_cfg(basis->B, basis->ldb, U, ldu, basis->mk, j, basis->mk) == CFG_BIG;
-    double *epart = nullptr;
-    if (energy_in) {
-      const int64_t parts = big ? 2 * cdiv(basis->mk, 128) : cdiv(basis->mk, 64);
-      if (!workspace || workspace_bytes < (size_t)parts * j * sizeof(double))
-        return fail(PLS_ERR_WORKSPACE_TOO_SMALL, "onb_step: energy by-product needs %zu workspace bytes",
-                    (size_t)parts * j * sizeof(double));
-      epart = static_cast<double *>(workspace);
-    }
-    EpiLangevinGaussian e{out, ldo, U, ldu, basis->c, basis->lam, etap, 1.0 / cost->p[0], out_mode, nz,
-                          epart, j, 2, big ? 128 : 64};
-    rc = launch_gemm_any(basis->B, basis->ldb, U, ldu, basis->mk, j, basis->mk, e, st);
-    if (rc || !energy_in) return rc;
-    const int64_t parts = big ? 2 * cdiv(basis->mk, 128) : cdiv(basis->mk, 64);
-    hipLaunchKernelGGL(gaussian_energy_finish_kernel, dim3((unsigned)cdiv(j, 256)), dim3(256), 0, st, epart, j, parts, j,
-                       energy_in, 0.5 / cost->p[0], basis->c + basis->mk);
-    return check_launch("gaussian_energy_finish");
+    const FastOp op{basis->B, basis->ldb, basis->c, basis->lam, basis->mk, 1.0 / cost->p[0], 0.5 / cost->p[0], basis->c + basis->mk};
+    return fast_step_launch(op, U, ldu, j, etap, nz, out, ldo, out_mode, energy_in, workspace, workspace_bytes, st, "onb_step");
   }
   // workspace: [D slabs][cost partial rows (energy by-product)][G chunk]; the chunk length follows from what is left
   const size_t d_bytes = align_up((size_t)basis->mk * j * sizeof(double), 256);
@@ -1751,30 +1847,8 @@ int pls_onb_energy(const pls_onb_desc *basis, const pls_cost_desc *cost, const d
   if (j == 0) return PLS_OK;
   if (onb_fast_path(basis, cost, force_generic)) {
     // cost_j = (u^T B u - 2 c^T u + y^T y) / (2 sigma2): one Mk x Mk x J contraction, reduced per tile then per column
-    const GemmCfg cfg = pick_gemm_cfg(basis->B, basis->ldb, U, ldu, basis->mk, j, basis->mk);
-    const int64_t parts = cfg == CFG_BIG ? cdiv(basis->mk, 128) : cdiv(basis->mk, 64);
-    if (!workspace || workspace_bytes < (size_t)parts * j * sizeof(double))
-      return fail(PLS_ERR_WORKSPACE_TOO_SMALL, "onb_energy: workspace %zu bytes too small", workspace_bytes);
-    double *partial = static_cast<double *>(workspace);
-    GemmShape g{basis->B, basis->ldb, U, ldu, basis->mk, j, basis->mk, 0, 0, 0};
-    if (cfg == CFG_BIG) {
-      EpiGaussianQuad<128, 128, 64, 64> ep{partial, j, U, ldu, basis->c, basis->lam, 0.5 / cost->p[0]};
-      rc = launch_gemm_cfg<128, 128, 64, 64>(g, ep, S(stream));
-    } else if (cfg == CFG_KG2) {
-      EpiGaussianQuad<64, 64, 16, 32> ep{partial, j, U, ldu, basis->c, basis->lam, 0.5 / cost->p[0]};
-      rc = launch_gemm_kg<2>(g, ep, S(stream));
-    } else if (cfg == CFG_KG1) {
-      EpiGaussianQuad<64, 64, 32, 32> ep{partial, j, U, ldu, basis->c, basis->lam, 0.5 / cost->p[0]};
-      rc = launch_gemm_kg<1>(g, ep, S(stream));
-    } else {
-      EpiGaussianQuad<64, 64, 32, 32> ep{partial, j, U, ldu, basis->c, basis->lam, 0.5 / cost->p[0]};
-      rc = launch_gemm_cfg<64, 64, 32, 32>(g, ep, S(stream));
-    }
-    if (rc) return rc;
-    // e_j = sum of the tile partials + y^T y / (2 sigma2): enters as 1.0 * (sum + padd) with padd pre-scaled on the fly
-    hipLaunchKernelGGL(gaussian_energy_finish_kernel, dim3((unsigned)cdiv(j, 256)), dim3(256), 0, S(stream), partial, j, parts, j,
-                       e, 0.5 / cost->p[0], basis->c + basis->mk);
-    return check_launch("column_reduce");
+    const FastOp op{basis->B, basis->ldb, basis->c, basis->lam, basis->mk, 1.0 / cost->p[0], 0.5 / cost->p[0], basis->c + basis->mk};
+    return fast_energy_launch(op, U, ldu, j, e, workspace, workspace_bytes, S(stream), "onb_energy");
   }
   // rows per chunk such that the partial buffer ((chunk/64) x j doubles) fits
   const int64_t max_parts = (int64_t)(workspace_bytes / ((size_t)j * sizeof(double)));
@@ -1805,7 +1879,11 @@ static int validate_ipb(const pls_ipb_desc *b) {
   PLS_REQUIRE(b != nullptr, "ipb descriptor is NULL");
   PLS_REQUIRE(b->m > 0 && b->n > 0, "ipb: m and n must be positive");
   PLS_REQUIRE(b->Kzx && b->Kxz, "ipb: Kzx and Kxz must be set");
-  PLS_REQUIRE((b->Sf && b->Sb) || b->W, "ipb: k(Z,Z) must enter as substitution operators Sf / Sb (pls_chol_factor) or as W");
+  PLS_REQUIRE((b->Sf && b->Sb) || b->W || (b->Linv && b->LinvT),
+              "ipb: k(Z,Z) must enter as substitution operators Sf / Sb (pls_chol_factor), as the inverse factor Linv / LinvT or as W");
+  PLS_REQUIRE((b->Linv == nullptr) == (b->LinvT == nullptr), "ipb: Linv and LinvT go together");
+  if (b->Linv) PLS_REQUIRE(b->ldlinv >= b->m && b->ldlinvt >= b->m, "ipb: ldlinv / ldlinvt < m");
+  if (b->Q) PLS_REQUIRE(b->ldq >= b->m && b->ct, "ipb: Q needs ldq >= m and ct");
   PLS_REQUIRE((b->Sf == nullptr) == (b->Sb == nullptr), "ipb: Sf and Sb go together");
   PLS_REQUIRE(b->ldkzx >= b->n && b->ldkxz >= b->m, "ipb: leading dimension too small");
   if (b->W) PLS_REQUIRE(b->ldw >= b->m, "ipb: ldw < m");
@@ -1815,13 +1893,37 @@ static int validate_ipb(const pls_ipb_desc *b) {
   return PLS_OK;
 }
 
-// V (m x j, ld j) = k(Z,Z)^-1 U: forward + backward substitution with the Cholesky factor (one launch), or -- A/B option,
-// or a descriptor without the substitution operators -- the contraction with the explicit inverse W.
-static int ipb_apply_kinv(const pls_ipb_desc *b, const double *U, int64_t ldu, int64_t j, double *V, void *stream) {
-  const bool explicit_inverse = !b->Sf || (g_ipb_explicit_inverse.load() != 0 && b->W);
+static pls_chol_desc ipb_factor(const pls_ipb_desc *b) {
+  return pls_chol_desc{b->m, nullptr, 0, b->LcT, b->ldlct, b->Sf, b->ldsf, b->Sb, b->ldsb, b->Linv, b->ldlinv, b->LinvT, b->ldlinvt};
+}
+
+// V (m x j, ld j) = k(Z,Z)^-1 U = Lc^-T Lc^-1 U.  Two triangular products with the inverse factor when the descriptor
+// carries it and `tmp` (m x j doubles) is there to hold Lc^-1 U; else forward + backward block substitution in one launch;
+// or -- A/B option, or a descriptor without a factor -- the contraction with the explicit inverse W.
+static int ipb_apply_kinv(const pls_ipb_desc *b, const double *U, int64_t ldu, int64_t j, double *V, void *stream,
+                          double *tmp = nullptr) {
+  const bool explicit_inverse = (!b->Sf && !b->Linv) || (g_ipb_explicit_inverse.load() != 0 && b->W);
   if (explicit_inverse) return pls_gemm_tn(b->W, b->ldw, U, ldu, V, j, b->m, j, b->m, 1.0, 0.0, stream);  // W symmetric
-  pls_chol_desc f{b->m, nullptr, 0, b->LcT, b->ldlct, b->Sf, b->ldsf, b->Sb, b->ldsb};
-  return chol_solve_launch(&f, U, ldu, j, V, j, 0, S(stream));
+  const pls_chol_desc f = ipb_factor(b);
+  return chol_full_solve(&f, U, ldu, j, V, j, tmp, S(stream));
+}
+
+// ---- the Gaussian/identity step in whitened coordinates ----------------------------------------------------------------
+// With S = Lc^-1 U (k(Z,Z) = Lc Lc^T) the update of inducing_point.py:117-150 under gaussian.py:86-88,
+//     dU = -eta ((B V - c) / sigma2 + M V) + sqrt(2 eta) Lc xi,   V = k(Z,Z)^-1 U = Lc^-T S,
+// reads  dU = Lc dS,  dS = -eta (Q S - c~) + sqrt(2 eta) xi  with  Q = Lc^-1 (B / sigma2 + M I) Lc^-T,  c~ = Lc^-1 c / sigma2
+// (built once per sigma2 by pls_ipb_build_whitened), and the energy of inducing_point.py:95-115 is
+// S^T Q S / 2 - c~^T S + y^T y / (2 sigma2).  dS is exactly the orthonormal basis' fused fast-path kernel with operator
+// (Q, c~) and no prior term -- the Philox noise of that kernel is the xi of the reference's e = Lc xi.  A step is then
+// forward solve (M^2 J flop) + Q S (2 M^2 J) + Lc dS (M^2 J) in three launches, against solve (2 M^2 J) + B V (2 M^2 J) +
+// Lc xi (M^2 J) + noise + update in six; a loop that keeps S between steps pays 2 M^2 J per step.
+static bool ipb_whitened_ok(const pls_ipb_desc *b, const pls_cost_desc *c) {
+  return b->Q && b->ct && b->LcT && b->ldq >= b->m && b->q_inv_noise == 1.0 / c->p[0] && (b->LinvT || (b->Sf && b->Sb)) &&
+         g_ipb_explicit_inverse.load() == 0;
+}
+
+static FastOp ipb_whitened_op(const pls_ipb_desc *b) {
+  return FastOp{b->Q, b->ldq, b->ct, nullptr, b->m, 1.0, 0.5 * b->q_inv_noise, b->ct + b->m};
 }
 
 int pls_ipb_forward(const pls_ipb_desc *basis, const double *U, int64_t ldu, int64_t j, double *F, int64_t ldf,
@@ -1901,7 +2003,7 @@ int pls_ipb_particle_update(const pls_ipb_desc *basis, const double *U, int64_t 
   char *w = static_cast<char *>(workspace);
   double *V = reinterpret_cast<double *>(w), *D = reinterpret_cast<double *>(w + mj);
   double *xi = reinterpret_cast<double *>(w + 2 * mj), *e = reinterpret_cast<double *>(w + 3 * mj);
-  rc = ipb_apply_kinv(basis, U, ldu, j, V, stream);
+  rc = ipb_apply_kinv(basis, U, ldu, j, V, stream, xi);  // (xi is free until the noise is drawn)
   if (rc) return rc;
   rc = pls_gemm_tn(basis->Kxz, basis->ldkxz, G, ldg, D, j, basis->m, j, basis->n, 1.0, 0.0, stream);
   if (rc) return rc;
@@ -1948,7 +2050,24 @@ static int ipb_step_impl(const pls_ipb_desc *basis, const pls_cost_desc *cost, c
   double *vpart = reinterpret_cast<double *>(w + fixed);
   double *Gbuf = reinterpret_cast<double *>(w + fixed + onb_energy_partial_bytes(n_chunk, j));
   hipStream_t st = S(stream);
-  rc = ipb_apply_kinv(basis, U, ldu, j, V, stream);
+  if (ipb_fast_path(basis, cost, force_generic) && ipb_whitened_ok(basis, cost)) {
+    // whitened route: S = Lc^-1 U -> dS (fused kernel, energy by-product) -> out = [U +] Lc dS
+    double *Sw = V, *Wd = xi, *epart = e;  // (m x j each; the partial rows of the energy fit: 2 cdiv(m, 128) <= m + 1)
+    const pls_chol_desc f = ipb_factor(basis);
+    rc = chol_forward_solve(&f, U, ldu, j, Sw, j, st);
+    if (rc) return rc;
+    NoiseP nz = make_noisep(noise, blocks);
+    const bool injected = nz.kind == PLS_NOISE_INJECTED;
+    const double *e_inj = injected ? nz.xi : nullptr;
+    const int64_t ld_inj = nz.ldxi;
+    if (injected) nz.kind = PLS_NOISE_NONE;  // (the injected noise is already coloured: it enters after the product with Lc)
+    rc = fast_step_launch(ipb_whitened_op(basis), Sw, j, j, make_etap(eta, blocks), nz, Wd, j, 0, energy_in, epart,
+                          2 * mj, st, "ipb_step");
+    if (rc) return rc;
+    EpiIpbFinish fin{out, ldo, U, ldu, out_mode, make_etap(eta, blocks), e_inj, ld_inj};
+    return launch_gemm_any(basis->LcT, basis->ldlct, Wd, j, basis->m, j, basis->m, fin, st, 0, 1);
+  }
+  rc = ipb_apply_kinv(basis, U, ldu, j, V, stream, xi);  // (xi is free until the noise is drawn)
   if (rc) return rc;
   if (ipb_fast_path(basis, cost, force_generic)) {
     const double inv_noise = 1.0 / cost->p[0];
@@ -2023,7 +2142,13 @@ int pls_ipb_energy(const pls_ipb_desc *basis, const pls_cost_desc *cost, const d
     if (workspace_bytes < 2 * mj) return fail(PLS_ERR_WORKSPACE_TOO_SMALL, "ipb_energy: workspace %zu < %zu bytes", workspace_bytes, 2 * mj);
     double *D = reinterpret_cast<double *>(static_cast<char *>(workspace) + mj);
     const double inv_noise = 1.0 / cost->p[0];
-    rc = ipb_apply_kinv(basis, U, ldu, j, V, stream);
+    if (ipb_whitened_ok(basis, cost)) {  // S = Lc^-1 U, then the quadratic form in whitened coordinates
+      const pls_chol_desc f = ipb_factor(basis);
+      rc = chol_forward_solve(&f, U, ldu, j, V, j, S(stream));
+      if (rc) return rc;
+      return fast_energy_launch(ipb_whitened_op(basis), V, j, j, e, D, workspace_bytes - mj, S(stream), "ipb_energy");
+    }
+    rc = ipb_apply_kinv(basis, U, ldu, j, V, stream, D);
     if (rc) return rc;
     rc = pls_gemm_tn(basis->B, basis->ldb, V, j, D, j, basis->m, j, basis->m, inv_noise, 0.0, stream);
     if (rc) return rc;
@@ -2058,6 +2183,121 @@ int pls_ipb_prior_energy(const pls_ipb_desc *basis, const double *U, int64_t ldu
                      (int64_t)(cost ? 1 : 0), j, e, 0, 2, (const double *)V, j, basis->m, (const double *)nullptr,
                      0.5 * (double)basis->m, 1.0, (const double *)nullptr);
   return check_launch("column_reduce");
+}
+
+// ---- whitened coordinates of the inducing-point basis (see ipb_whitened_ok above) ------------------------------------
+size_t pls_ipb_build_whitened_workspace_bytes(int64_t m) {
+  if (m <= 0) return 0;
+  const int64_t ldt = (m + 1) & ~(int64_t)1;
+  return 2 * align_up((size_t)m * ldt * sizeof(double), 256);
+}
+
+int pls_ipb_build_whitened(const pls_ipb_desc *basis, double inv_noise, double *Q, int64_t ldq, double *ct, void *workspace,
+                           size_t workspace_bytes, void *stream) {
+  int rc = validate_ipb(basis);
+  if (rc) return rc;
+  PLS_REQUIRE(basis->B && basis->c, "ipb_build_whitened: the descriptor needs B and c (pls_ipb_build_gaussian)");
+  PLS_REQUIRE(basis->LinvT || (basis->Sf && basis->Sb), "ipb_build_whitened: the descriptor needs the Cholesky factor's operators");
+  PLS_REQUIRE(Q && ct && ldq >= basis->m && inv_noise > 0.0, "ipb_build_whitened: bad arguments");
+  PLS_REQUIRE((ldq & 1) == 0 && (reinterpret_cast<uintptr_t>(Q) & 15) == 0, "ipb_build_whitened: Q must be 16-byte aligned, ldq even");
+  const int64_t m = basis->m, ldt = (m + 1) & ~(int64_t)1;
+  if (!workspace || workspace_bytes < pls_ipb_build_whitened_workspace_bytes(m))
+    return fail(PLS_ERR_WORKSPACE_TOO_SMALL, "ipb_build_whitened: workspace %zu < %zu bytes", workspace_bytes,
+                pls_ipb_build_whitened_workspace_bytes(m));
+  hipStream_t st = S(stream);
+  double *T1 = static_cast<double *>(workspace);
+  double *T2 = reinterpret_cast<double *>(static_cast<char *>(workspace) + align_up((size_t)m * ldt * sizeof(double), 256));
+  const pls_chol_desc f = ipb_factor(basis);
+  // Q = Lc^-1 B' Lc^-T with B' = B / sigma2 + M I:  T2 = Lc^-1 B',  Q = Lc^-1 T2^T (B' symmetric)
+  rc = launch_scale_add_diag(basis->B, basis->ldb, inv_noise, (double)m, T1, ldt, m, st);
+  if (rc) return rc;
+  rc = chol_forward_solve(&f, T1, ldt, m, T2, ldt, st);
+  if (rc) return rc;
+  rc = launch_transpose(T2, ldt, T1, ldt, m, m, st);
+  if (rc) return rc;
+  rc = chol_forward_solve(&f, T1, ldt, m, Q, ldq, st);
+  if (rc) return rc;
+  // c~ = Lc^-1 c / sigma2, then y^T y
+  hipLaunchKernelGGL(scale_copy_kernel, dim3((unsigned)cdiv(m, 256)), dim3(256), 0, st, basis->c, inv_noise, T1, m);
+  rc = check_launch("scale_copy");
+  if (rc) return rc;
+  rc = chol_forward_solve(&f, T1, 1, 1, ct, 1, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(scale_copy_kernel, dim3(1), dim3(256), 0, st, basis->c + m, 1.0, ct + m, (int64_t)1);
+  return check_launch("scale_copy");
+}
+
+int pls_ipb_whiten(const pls_ipb_desc *basis, const double *U, int64_t ldu, int64_t j, double *Sw, int64_t lds, void *stream) {
+  int rc = validate_ipb(basis);
+  if (rc) return rc;
+  PLS_REQUIRE(U && Sw && U != Sw && j >= 0 && ldu >= j && lds >= j, "ipb_whiten: bad arguments");
+  if (j == 0) return PLS_OK;
+  const pls_chol_desc f = ipb_factor(basis);
+  return chol_forward_solve(&f, U, ldu, j, Sw, lds, S(stream));
+}
+
+int pls_ipb_unwhiten(const pls_ipb_desc *basis, const double *Sw, int64_t lds, int64_t j, double *U, int64_t ldu, void *stream) {
+  int rc = validate_ipb(basis);
+  if (rc) return rc;
+  PLS_REQUIRE(basis->LcT, "ipb_unwhiten: the descriptor needs LcT");
+  PLS_REQUIRE(U && Sw && U != Sw && j >= 0 && ldu >= j && lds >= j, "ipb_unwhiten: bad arguments");
+  if (j == 0) return PLS_OK;
+  return gemm_tn_ex(basis->LcT, basis->ldlct, Sw, lds, U, ldu, basis->m, j, basis->m, 1.0, 0.0, 1, S(stream));
+}
+
+size_t pls_ipb_whitened_workspace_bytes(const pls_ipb_desc *basis, int64_t j) {
+  if (!basis || j <= 0) return 0;
+  return (size_t)(2 * cdiv(basis->m, 128)) * j * sizeof(double);
+}
+
+static int ipb_whitened_step_impl(const pls_ipb_desc *basis, const pls_cost_desc *cost, const double *Sw, int64_t lds, int64_t j,
+                                  double eta, const pls_block_desc *blocks, const pls_noise_desc *noise, double *out, int64_t ldo,
+                                  int32_t out_mode, double *energy_in, void *workspace, size_t workspace_bytes, void *stream) {
+  int rc = validate_ipb(basis);
+  if (rc) return rc;
+  rc = validate_cost(cost);
+  if (rc) return rc;
+  rc = validate_noise(noise, basis->m);
+  if (rc) return rc;
+  rc = validate_blocks(blocks, j);
+  if (rc) return rc;
+  PLS_REQUIRE(cost->cost == PLS_COST_GAUSSIAN && cost->link == PLS_LINK_IDENTITY, "ipb_whitened_step: Gaussian cost with the identity link only");
+  PLS_REQUIRE(basis->Q && basis->ct && basis->q_inv_noise == 1.0 / cost->p[0],
+              "ipb_whitened_step: the descriptor's Q / ct were not built for this observation noise (pls_ipb_build_whitened)");
+  PLS_REQUIRE(Sw && out && out != Sw && j >= 0 && lds >= j && ldo >= j && eta >= 0.0, "ipb_whitened_step: bad arguments");
+  PLS_REQUIRE(out_mode == 0 || out_mode == 1, "ipb_whitened_step: out_mode must be 0 or 1");
+  if (j == 0) return PLS_OK;
+  return fast_step_launch(ipb_whitened_op(basis), Sw, lds, j, make_etap(eta, blocks), make_noisep(noise, blocks), out, ldo,
+                          out_mode, energy_in, workspace, workspace_bytes, S(stream), "ipb_whitened_step");
+}
+
+int pls_ipb_whitened_step(const pls_ipb_desc *basis, const pls_cost_desc *cost, const double *Sw, int64_t lds, int64_t j,
+                          double eta, const pls_noise_desc *noise, double *out, int64_t ldo, int32_t out_mode, double *energy_in,
+                          void *workspace, size_t workspace_bytes, void *stream) {
+  return ipb_whitened_step_impl(basis, cost, Sw, lds, j, eta, nullptr, noise, out, ldo, out_mode, energy_in, workspace,
+                                workspace_bytes, stream);
+}
+
+int pls_ipb_whitened_step_blocks(const pls_ipb_desc *basis, const pls_cost_desc *cost, const double *Sw, int64_t lds, int64_t j,
+                                 const pls_block_desc *blocks, const pls_noise_desc *noise, double *out, int64_t ldo,
+                                 int32_t out_mode, double *energy_in, void *workspace, size_t workspace_bytes, void *stream) {
+  PLS_REQUIRE(blocks != nullptr, "ipb_whitened_step_blocks: block descriptor is NULL");
+  return ipb_whitened_step_impl(basis, cost, Sw, lds, j, 0.0, blocks, noise, out, ldo, out_mode, energy_in, workspace,
+                                workspace_bytes, stream);
+}
+
+int pls_ipb_whitened_energy(const pls_ipb_desc *basis, const pls_cost_desc *cost, const double *Sw, int64_t lds, int64_t j,
+                            double *e, void *workspace, size_t workspace_bytes, void *stream) {
+  int rc = validate_ipb(basis);
+  if (rc) return rc;
+  rc = validate_cost(cost);
+  if (rc) return rc;
+  PLS_REQUIRE(cost->cost == PLS_COST_GAUSSIAN && cost->link == PLS_LINK_IDENTITY, "ipb_whitened_energy: Gaussian cost with the identity link only");
+  PLS_REQUIRE(basis->Q && basis->ct && basis->q_inv_noise == 1.0 / cost->p[0],
+              "ipb_whitened_energy: the descriptor's Q / ct were not built for this observation noise");
+  PLS_REQUIRE(Sw && e && j >= 0 && lds >= j, "ipb_whitened_energy: bad arguments");
+  if (j == 0) return PLS_OK;
+  return fast_energy_launch(ipb_whitened_op(basis), Sw, lds, j, e, workspace, workspace_bytes, S(stream), "ipb_whitened_energy");
 }
 
 size_t pls_select_inducing_workspace_bytes(int64_t n, int64_t m) {

@@ -20,7 +20,11 @@ def _own_workspace(basis, cost, particles: torch.Tensor, with_energy: bool, forc
     """A workspace buffer that belongs to ONE capture (never shared with, nor freed by, the basis)."""
     cd = cost.desc()
     if cd.cost == L.COST_GAUSSIAN and cd.link == L.LINK_IDENTITY and not force_generic:
-        basis.prepare_gaussian(cost.y_device())  # (allocates B and c: must not happen inside the capture)
+        # (allocates B, c and the whitened operator: must not happen inside the capture)
+        if hasattr(basis, "_prepare_for"):
+            basis._prepare_for(cost)
+        else:
+            basis.prepare_gaussian(cost.y_device())
     nbytes = basis.step_workspace_bytes(cost, particles.shape[1], with_energy, force_generic)
     return torch.empty(max(nbytes // 8 + 1, 1), dtype=torch.float64, device=particles.device)
 

@@ -50,6 +50,12 @@ def test_options_validate_without_touching_the_gpu():
     assert lib.pls_set_option(L.OPT_IPB_EXPLICIT_INVERSE, 2) != 0
     assert lib.pls_set_option(L.OPT_IPB_EXPLICIT_INVERSE, 1) == 0 and lib.pls_get_option(L.OPT_IPB_EXPLICIT_INVERSE) == 1
     assert lib.pls_set_option(L.OPT_IPB_EXPLICIT_INVERSE, 0) == 0
+    assert lib.pls_get_option(L.OPT_KSPLIT_MODE) == 1 and lib.pls_get_option(L.OPT_KSPLIT_MAX_TILES) == 256
+    assert lib.pls_set_option(L.OPT_KSPLIT_MODE, 4) != 0 and lib.pls_set_option(L.OPT_KSPLIT_MAX_TILES, -1) != 0
+    assert lib.pls_set_option(L.OPT_KSPLIT_MODE, 0) == 0 and lib.pls_get_option(L.OPT_KSPLIT_MODE) == 0
+    assert lib.pls_set_option(L.OPT_KSPLIT_MODE, 1) == 0
+    assert lib.pls_get_option(L.OPT_SOLVE_MODE) == 1 and lib.pls_set_option(L.OPT_SOLVE_MODE, 2) != 0
+    assert lib.pls_set_option(L.OPT_SOLVE_MODE, 0) == 0 and lib.pls_set_option(L.OPT_SOLVE_MODE, 1) == 0
 
 
 def test_struct_layouts_match_the_header():
@@ -60,10 +66,35 @@ def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(L.CostDesc) == 4 * 4 + 4 * 8 + 8
     assert ctypes.sizeof(L.NoiseDesc) == 8 + 8 + 8 + 8 + 8 + 8 + 8
     assert ctypes.sizeof(L.OnbDesc) == 10 * 8
-    assert ctypes.sizeof(L.IpbDesc) == 17 * 8
-    assert ctypes.sizeof(L.CholDesc) == 9 * 8
+    assert ctypes.sizeof(L.IpbDesc) == 25 * 8
+    assert ctypes.sizeof(L.CholDesc) == 13 * 8
     assert ctypes.sizeof(L.BlockDesc) == 2 * 8
     assert L.CostDesc.p.offset == 16 and L.CostDesc.jitter.offset == 48
+
+
+def test_struct_layouts_match_what_a_c_compiler_makes_of_the_header(tmp_path):
+    """sizeof and the offset of the last field of every descriptor, as gcc lays the header's structs out."""
+    import shutil
+    import subprocess
+
+    import projected_langevin_sampling_amd as pkg
+
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler")
+    L = pkg._lib
+    structs = {"pls_cost_desc": (L.CostDesc, "jitter"), "pls_noise_desc": (L.NoiseDesc, "step_base"),
+               "pls_onb_desc": (L.OnbDesc, "c"), "pls_ipb_desc": (L.IpbDesc, "q_inv_noise"),
+               "pls_chol_desc": (L.CholDesc, "ldlinvt"), "pls_block_desc": (L.BlockDesc, "eta")}
+    src = tmp_path / "layout.c"
+    body = "".join(f'  printf("{n} %zu %zu\\n", sizeof({n}), offsetof({n}, {last}));\n' for n, (_, last) in structs.items())
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "plship.h"\nint main(void) {\n' + body + "  return 0;\n}\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    for k in range(0, len(out), 3):
+        cls, last = structs[out[k]]
+        assert ctypes.sizeof(cls) == int(out[k + 1]), out[k]
+        assert getattr(cls, last).offset == int(out[k + 2]), out[k]
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -240,3 +240,64 @@ def test_bench_self_launches_its_ranks(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
     assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_whitened_route_and_inverse_factor_products_are_as_accurate_as_substitution():
+    """Numerics behind round 3's inducing-point Gaussian step, in plain torch on the host.
+    With ONE Cholesky factor of k(Z,Z) (cond 2e10 here) the whitened route  Lc (Q S - c~),  Q = Lc^-1 (B / sigma2 + M I) Lc^-T,
+    S = Lc^-1 U  -- with Lc^-1 applied as an explicit triangular inverse or by substitution -- equals the reference's
+    (B V - c) / sigma2 + M V,  V = k(Z,Z)^-1 U  (inducing_point.py:130-150, gaussian.py:86-88) to 1e-12, whereas two
+    equally valid factors of the same matrix (LAPACK's and a right-looking blocked one) already move either route by
+    ~cond * 1e-17: the factorisation, not the way its inverse is applied, sets the accuracy."""
+    import torch
+
+    from oracle import pls_oracle as O
+
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        g = torch.Generator().manual_seed(6660)
+        n, m, j, sigma2 = 600, 60, 50, 0.3
+        x = torch.rand(n, 2, generator=g) * 2 - 1
+        z = x[torch.randperm(n, generator=g)[:m]].clone()
+        y = torch.sin(2.0 * x.sum(dim=1)) + 0.1 * torch.randn(n, generator=g)
+        u = torch.randn(m, j, generator=g)
+        kern = O.RBFARDKernel(torch.tensor([0.55, 0.75]), 1.3)
+        k, kzx = kern(z, z), kern(z, x)
+        cond = torch.linalg.cond(k).item()
+        assert 1e7 < cond < 1e12, cond
+        b, c = kzx @ kzx.T, kzx @ y
+
+        def blocked(a, nb=8):  # right-looking blocked Cholesky: the rounding pattern of pls_chol_factor, not LAPACK's
+            a = a.clone()
+            for s in range(0, m, nb):
+                e = min(m, s + nb)
+                a[s:e, s:e] = torch.linalg.cholesky(a[s:e, s:e])
+                if e < m:
+                    a[e:, s:e] = torch.linalg.solve_triangular(a[s:e, s:e], a[e:, s:e].T, upper=False).T
+                    a[e:, e:] -= a[e:, s:e] @ a[e:, s:e].T
+            return torch.tril(a)
+
+        def reference_route(lc):
+            v = torch.cholesky_solve(u, lc)
+            return (b @ v - c[:, None]) / sigma2 + m * v
+
+        def whitened_route(lc, explicit_inverse):
+            if explicit_inverse:
+                linv = torch.linalg.solve_triangular(lc, torch.eye(m), upper=False)
+                fwd = lambda t: linv @ t
+            else:
+                fwd = lambda t: torch.linalg.solve_triangular(lc, t, upper=False)
+            q = fwd(fwd(b / sigma2 + m * torch.eye(m)).T)
+            return lc @ (q @ fwd(u) - fwd(c[:, None]) / sigma2)
+
+        rel = lambda a, r: ((a - r).abs().max() / r.abs().max()).item()
+        l0, l1 = torch.linalg.cholesky(k), blocked(k)
+        for lc in (l0, l1):
+            ref = reference_route(lc)
+            assert rel(whitened_route(lc, True), ref) < 1e-11 and rel(whitened_route(lc, False), ref) < 1e-11
+        moved = rel(reference_route(l1), reference_route(l0))
+        assert moved > 1e-11, "two factors of an ill-conditioned matrix are expected to disagree beyond the route's own rounding"
+        assert moved < cond * 1e-15
+    finally:
+        torch.set_default_dtype(prev)
