@@ -97,6 +97,18 @@ def host_cores() -> int:
     return max(1, n)
 
 
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+
+    return platform.processor() or platform.machine()
+
+
 def cpu_baseline(cfg, x, z, y, ls, lam_all, vec_all):
     """The oracle ("port": faithful torch-CPU restatement of the reference's step, oracle/pls_oracle.py) timed on this
     box's host cores.  The step is MEASURED at the configuration's full (N, J) whenever 1 warm-up + 2 timed steps fit the
@@ -117,11 +129,11 @@ def cpu_baseline(cfg, x, z, y, ls, lam_all, vec_all):
         def step_flop(n, j):  # reference association: (K_XZ V~) U, V~^T K_ZX then @ G, + the dense diag(1/lam) @ U
             return 4.0 * n * m * mk + 4.0 * n * mk * j + 2.0 * mk * mk * j
 
-        budget = 1.3e13  # ~25 s at the ~0.5 TFLOP/s these 16 host cores sustain in fp64
+        budget = 1.8e13  # 1 warm-up + 3 timed steps in ~30 s at the ~0.5 TFLOP/s these 16 host cores sustain in fp64
         n_s, j_s = n_full, j_full
-        while 3 * step_flop(n_s, j_s) > budget and j_s > max(256, j_full // 8):
+        while 4 * step_flop(n_s, j_s) > budget and j_s > max(256, j_full // 8):
             j_s //= 2
-        while 3 * step_flop(n_s, j_s) > budget and n_s > 20_000:
+        while 4 * step_flop(n_s, j_s) > budget and n_s > 20_000:
             n_s //= 2
         xs, ys = x[:n_s], y[:n_s]
         ob = O.OrthonormalBasis.__new__(O.OrthonormalBasis)  # reuse the spectrum already computed for the GPU basis
@@ -147,7 +159,7 @@ def cpu_baseline(cfg, x, z, y, ls, lam_all, vec_all):
         t0 = time.perf_counter()
         u += pls.calculate_particle_update(u, 1e-12)  # warm-up (thread pool, page faults of the N x J temporaries)
         log(f"cpu baseline: warm-up step {time.perf_counter() - t0:.1f} s")
-        reps = 2
+        reps = 3  # (at least three timed steps after one warm-up)
         t0 = time.perf_counter()
         for _ in range(reps):
             u += pls.calculate_particle_update(u, 1e-12)  # faithful: eigh(I) noise, dense diag @ U, full F and G
@@ -185,6 +197,7 @@ def cpu_baseline(cfg, x, z, y, ls, lam_all, vec_all):
             "value": 1.0 / t_full,
             "unit": "steps/s",
             "cores": cores,
+            "cpu_model": cpu_model(),
             "kind": "port",
             "extrapolated": not full,
             "fair_variant": {"value": 1.0 / (t_fair * fair_scale), "unit": "steps/s", "s_per_step": t_fair * fair_scale,
@@ -286,6 +299,10 @@ def main():
     ap.add_argument("--select-inducing", action="store_true", help="also time the greedy inducing-point selection (setup)")
     ap.add_argument("--eigh-device", default="cpu", choices=["cpu", "cuda"],
                     help="where the one-time eigh of k(Z,Z)/M runs (cpu = the reference's host LAPACK call)")
+    ap.add_argument("--sustained-steps", type=int, default=300,
+                    help="like-for-like steps of the `sustained` block (>= 10 s at configs[1]; 0 = skip)")
+    ap.add_argument("--profiler-steps", type=int, default=100,
+                    help="T of the reference's profiler protocol: construction + T steps timed as one block (0 = skip)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="development aid: run rank 0's particle shard of an N-GPU job on ONE GPU (no collectives); "
                          "the JSON line is marked emulated and is not a scaling result")
@@ -322,10 +339,20 @@ def main():
     L = pkg._lib
     x, z, y, ls = make_data(cfg)
     log("synthetic data ready")
+    setup = {}
+    t0 = time.perf_counter()
+    torch.zeros(1, device="cuda")
+    torch.cuda.synchronize()
+    setup["hip_context_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    _w = torch.ones(64, 64, dtype=torch.float64, device="cuda")
+    pkg._ops.gemm_tn(_w, _w)  # the first libplship launch loads the library's code object onto the device
+    torch.cuda.synchronize()
+    setup["code_object_load_first_launch_s"] = time.perf_counter() - t0
     t_setup = time.perf_counter()
     kernel = pkg.PLSKernel(pkg.ARDKernel(ls, 1.0), z)
     basis = OrthonormalBasis(kernel, z, x, eigenvalue_threshold=cfg.get("threshold", 0.0), verbose=False, keep_gram=False,
-                             eigh_device=args.eigh_device)
+                             eigh_device=args.eigh_device, setup_times=setup)
     basis.workspace_bytes = int(args.workspace_gb * (1 << 30))
     mk = basis.approximation_dimension
     if cfg["cost"] == "poisson":
@@ -346,17 +373,32 @@ def main():
     ping = u_full[:, j0:j1].contiguous().cuda()
     pong = torch.empty_like(ping)
     del u_full
-    rho = None
+    rho_max = None
     if cfg["cost"] == "gaussian":
+        t0 = time.perf_counter()
         basis.prepare_gaussian(cost.y_device())
+        torch.cuda.synchronize()
+        setup["gaussian_constants_B_c_s"] = time.perf_counter() - t0
         # Euler-Maruyama is stable for eta * rho < 2, rho = largest eigenvalue of the drift Jacobian B/sigma2 + Lambda^-1;
-        # the reference finds a usable step by search (experiments/runners.py:356-433), here it is read off the spectrum
-        jac = (basis._B.cpu() / cfg["obs"]) + torch.diag(1.0 / basis.eigenvalues.cpu())
-        rho = torch.linalg.eigvalsh(jac)
-        eta = min(eta, 1.0 / rho.max().item())
+        # the reference finds a usable step by search (experiments/runners.py:356-433), here it is read off the spectrum:
+        # block power iteration on the device (the contraction is pls_gemm_tn), Rayleigh quotient at the end.  (Round 2
+        # took a full host eigvalsh of the 1024 x 1024 Jacobian to read off this one number: 0.4 s of the setup.)
+        t0 = time.perf_counter()
+        inv_lam, inv_obs = (1.0 / basis.eigenvalues)[:, None], 1.0 / cfg["obs"]
+        v = torch.randn(mk, 4, dtype=torch.float64, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+        jv = None
+        for it in range(60):
+            v, _ = torch.linalg.qr(v)
+            jv = pkg._ops.gemm_tn(basis._B, v.contiguous()) * inv_obs + inv_lam * v
+            if it < 59:
+                v = jv
+        rho_max = float(torch.linalg.eigvalsh(v.T @ jv).max().item())  # (4 x 4 Ritz values)
+        setup["step_size_power_iteration_s"] = time.perf_counter() - t0
+        eta = min(eta, 1.0 / rho_max)
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup
-    log(f"basis ready (M_k = {mk}), setup {t_setup:.2f} s")
+    setup = {k: round(v, 4) for k, v in setup.items()}
+    log(f"basis ready (M_k = {mk}), setup {t_setup:.2f} s: {setup}")
 
     def settle(seconds: float = 1.0):
         torch.cuda.synchronize()
@@ -440,6 +482,7 @@ def main():
                 traffic = sum(k["hbm_bytes_per_launch"] for k in ks) / len(ks)
                 traffic_src = f"profiles/{os.path.basename(prof)} (kernel sources {here[:12]})"
                 break
+    step_tflops = flop_per_step_rank / (ms_per_step * 1e-3) / 1e12  # whole step: every launch and every gap of the timed region
     roofline = {
         "kernel": ("small_rank_kernel<KB,drift> (F, d cost/d f and back-projection fused; N x J intermediates never written)"
                    if dom[0] == "small_rank_drift" else
@@ -449,6 +492,12 @@ def main():
         "peak": FP64_MFMA_PEAK_TFLOPS,
         "unit": "TFLOP/s",
         "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+        "frac_note": "algorithmic flop of the step's dominant launches / their summed durations (HIP events around every launch)",
+        "step_achieved": step_tflops,
+        "step_frac": step_tflops / FP64_MFMA_PEAK_TFLOPS,
+        "step_frac_note": "the same flop / ms_per_step: update kernel, launch gaps and host overhead of the timed region included",
+        "algorithmic_bytes_per_step": 8.0 * (n * m + 2 * m * j_loc),
+        "algorithmic_bytes_note": "SURVEY 8(d): A once, U in, U out; the two-GEMM path below also writes and re-reads G",
         "traffic": traffic,
         "traffic_unit": "bytes per launch (fabric-side L2 misses incl. Infinity-Cache hits)",
         "traffic_source": traffic_src,
@@ -475,9 +524,29 @@ def main():
         **({"emulated_world": shard_world} if shard_world != world else {}),
         "config": {"workload": cfg["workload"], "N": n, "M": cfg["m"], "M_k": mk, "J": j_total, "J_per_gpu": j_loc,
                    "path": "like-for-like: F=A^T U -> d cost/d f -> A G, 4*N*M*J flop/step", "step_size": eta,
-                   "parallelism": f"J-sharded x{world}, no per-step collective", "setup_s": round(t_setup, 2)},
+                   "parallelism": f"J-sharded x{world}, no per-step collective", "setup_s": round(t_setup, 2),
+                   "setup_breakdown": setup},
         "roofline": roofline,
     }
+    # ---- sustained: the same like-for-like step for >= 10 s, in windows of 50 steps (does the clock hold?) ----
+    if args.sustained_steps >= 50:
+        win = 50
+        nwin = args.sustained_steps // win
+        run(force_generic=True, steps=2, warmup=0, timeline=False)
+        windows = []
+        t_all = time.perf_counter()
+        for _ in range(nwin):
+            dtw, _ = run(force_generic=True, steps=win, warmup=0, timeline=False)
+            windows.append(dtw / win * 1e3)
+        t_all = time.perf_counter() - t_all
+        out["sustained"] = {
+            "steps": nwin * win, "wall_s": t_all, "ms_per_step": sum(windows) / len(windows),
+            "steps_per_s": nwin * win / (sum(windows) * win * 1e-3),
+            "window_ms_per_step": [round(w, 3) for w in windows], "window_steps": win,
+            "frac": flop_per_step_rank / (sum(windows) / len(windows) * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+            "note": "like-for-like steps back to back; every window is its own timed region (barrier + sync on both sides)",
+        }
+        log(f"sustained: {nwin * win} steps, {out['sustained']['ms_per_step']:.2f} ms/step, windows {windows[0]:.2f} .. {windows[-1]:.2f}")
     # ---- Gaussian algebraic fast path, same run ----
     if cfg["cost"] == "gaussian":
         fsteps = max(args.steps * 10, 50)
@@ -525,7 +594,7 @@ def main():
     if cfg["cost"] == "gaussian" and args.converge_steps > 0:
         from projected_langevin_sampling_amd.trainers import train_pls
 
-        eta_c = 1.0 / rho.max().item()
+        eta_c = 1.0 / rho_max
         patience = 100 * eta_c
         u0 = torch.normal(0.0, 1.0, size=(mk, j_total), generator=torch.Generator().manual_seed(0), dtype=torch.float64)
         particles = u0[:, j0:j1].contiguous().cuda()
@@ -543,7 +612,7 @@ def main():
             "step_size": eta_c, "patience_simulated_time": patience, "first_energy": energies[0] if energies else None,
             "final_energy": energies[-1] if energies else None, "ms_per_step_with_energy": wall / max(len(energies), 1) * 1e3,
             "loop": "train_pls (experiments/trainers.py:139-162): fused step + energy (.item() sync) + EarlyStopper every step",
-            "relaxation_rate_min": rho.min().item(), "stiffness_max": rho.max().item(),
+            "relaxation_rate_lower_bound": 1.0 / basis.eigenvalues.max().item(), "stiffness_max": rho_max,
         }
         log(f"train_pls: {len(energies)} steps in {wall:.2f} s, energy {energies[0]:.4g} -> {energies[-1]:.4g}")
         if world == 1:
@@ -644,15 +713,68 @@ def main():
                 a, b = b, a
             barrier()
             dti_fast = (time.perf_counter() - t0) / reps
+        dti_white = None
+        if cfg["cost"] == "gaussian":  # a loop that keeps S = Lc^-1 U between the steps: one contraction per step
+            sw = ipb.whiten(a)
+            sb = torch.empty_like(sw)
+            reps = 50
+            for w in range(2 + reps):
+                if w == 2:
+                    barrier()
+                    t0 = time.perf_counter()
+                ipb.whitened_step(cost, sw, eta_i, out=sb, new_state=True, noise=NoiseSpec(seed=7, step=200 + w, j_offset=j0))
+                sw, sb = sb, sw
+            barrier()
+            dti_white = (time.perf_counter() - t0) / reps
+            del sw, sb
         out["inducing_point_basis"] = {
             "ms_per_step": dti * 1e3, "steps": args.ipb_steps, "setup_s": round(t_ipb, 2),
             "step": "V = K_ZZ^-1 U (MFMA) -> F = K_XZ V -> d cost/d f -> K_ZX G -> e = L_c xi (Philox + MFMA) -> update",
             "flop_per_step": 4.0 * n * cfg["m"] * j_loc + 4.0 * cfg["m"] ** 2 * j_loc,
             "tflops": (4.0 * n * cfg["m"] * j_loc + 4.0 * cfg["m"] ** 2 * j_loc) / dti / 1e12,
             "gaussian_fast_path_ms_per_step": None if dti_fast is None else dti_fast * 1e3,
+            "gaussian_fast_path_note": "U -> U per call in whitened coordinates: S = Lc^-1 U (triangular product with the inverse "
+                                       "factor), dS = -eta (Q S - c~) + sqrt(2 eta) xi (one fused kernel), dU = Lc dS: 4 M^2 J flop",
+            "gaussian_whitened_loop_ms_per_step": None if dti_white is None else dti_white * 1e3,
+            "gaussian_whitened_loop_note": "a loop that keeps S between steps (pls_ipb_whitened_step): 2 M^2 J flop, one kernel per step",
         }
         log(f"inducing-point basis: {dti * 1e3:.2f} ms/step")
         del ipb, a, b
+    # ---- the reference's profiler protocol (experiments/profiler/main.py:41-82, :141-169): construction of kernel, basis,
+    # cost and PLS, particle initialisation and T steps `particles += pls.calculate_particle_update(particles, eta)` timed
+    # as ONE block ----
+    if rank == 0 and world == 1 and args.profiler_steps > 0 and shard_world == 1:
+        del ping, pong
+        torch.cuda.empty_cache()
+        barrier()
+        t0 = time.perf_counter()
+        k2 = pkg.PLSKernel(pkg.ARDKernel(ls, 1.0), z)
+        b2 = OrthonormalBasis(k2, z, x, eigenvalue_threshold=cfg.get("threshold", 0.0), verbose=False, keep_gram=False,
+                              eigh_device=args.eigh_device)
+        b2.workspace_bytes = basis.workspace_bytes
+        if cfg["cost"] == "poisson":
+            c2 = PoissonCost(y, SquareLinkFunction())
+        elif cfg["cost"] == "bernoulli":
+            c2 = type(cost)(y, cost.link_function)
+        else:
+            c2 = GaussianCost(cfg["obs"], y, IdentityLinkFunction())
+        pls2 = pkg.PLS(b2, c2)
+        torch.manual_seed(0)
+        p2 = pls2.initialise_particles(number_of_particles=j_total, noise_only=True)
+        torch.cuda.synchronize()
+        t_construct = time.perf_counter() - t0
+        for _ in range(args.profiler_steps):
+            p2 += pls2.calculate_particle_update(particles=p2, step_size=eta)
+        torch.cuda.synchronize()
+        t_block = time.perf_counter() - t0
+        out["construct_plus_T_steps"] = {
+            "T": args.profiler_steps, "seconds": t_block, "construction_s": t_construct, "steps_s": t_block - t_construct,
+            "protocol": "experiments/profiler/main.py:41-82 inside one timed block: PLSKernel + OrthonormalBasis (host eigh, like the "
+                        "reference) + cost + PLS + initialise_particles (host generator, like the reference) + T x "
+                        "`particles += pls.calculate_particle_update(particles, step_size)` through the drop-in API",
+        }
+        log(f"profiler protocol: construction {t_construct:.2f} s + {args.profiler_steps} steps = {t_block:.2f} s")
+        del b2, p2, pls2
     # ---- CPU baseline (rank 0, N=1 only) ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         lam_all, vec_all = basis.eigenvalues.cpu(), basis.eigenvectors.cpu()

@@ -197,6 +197,12 @@ typedef struct {
 typedef struct {
   int64_t block_cols;
   const double *eta; /* device, cdiv(j, block_cols) entries */
+  /* Optional output (ABI 3), Gaussian/identity fast paths with energy_in != NULL only: cdiv(j, 256) doubles, entry i = the
+   * sum of the per-particle energies of columns [256 i, 256 (i + 1)) in the library's fixed order (pls_chunk_sums), written
+   * by the launch that finishes the energy by-product.  The mean energy of a block of columns that starts at a multiple of
+   * 256 is then a few host additions over these entries (ascending order: the value pls_block_means returns, bit for bit)
+   * -- no second launch per training iteration.  May point to pinned host memory mapped into the device.  NULL: not written. */
+  double *energy_sums;
 } pls_block_desc;
 
 const char *pls_last_error(void);
@@ -308,6 +314,10 @@ int pls_normal_fill(double *out, int64_t ldout, int64_t rows, int64_t j, uint64_
  * step-size candidate when the particle matrix holds several (pls_block_desc).  `out` may be device memory or pinned
  * host memory mapped into the device (the training loop reads it after an event, without a copy kernel). */
 int pls_block_means(const double *e, int64_t j, int64_t block_cols, double *out, void *stream);
+
+/* out[i] = sum of e[256 i .. min(j, 256 (i + 1))): the chunk sums every energy mean of the library is built from (xor
+ * butterfly inside each wave, then (w0 + w1) + (w2 + w3); pls_block_means adds the chunks of a block in ascending order). */
+int pls_chunk_sums(const double *e, int64_t j, double *out, void *stream);
 
 /* Cholesky factorisation on the device: K (M x M, SPD, row-major; only read) + jitter * I = Lc Lc^T.
  * Replaces the factorisation inside gpytorch.solve(lhs = k(Z,Z), ...) (inducing_point.py:89-93, :104-106, :130-132,

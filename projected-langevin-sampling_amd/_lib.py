@@ -112,7 +112,7 @@ class CholDesc(C.Structure):
 
 
 class BlockDesc(C.Structure):
-    _fields_ = [("block_cols", C.c_int64), ("eta", C.c_void_p)]
+    _fields_ = [("block_cols", C.c_int64), ("eta", C.c_void_p), ("energy_sums", C.c_void_p)]
 
 
 _P, _I64, _I32, _U64, _D, _SZ = C.c_void_p, C.c_int64, C.c_int32, C.c_uint64, C.c_double, C.c_size_t
@@ -158,6 +158,7 @@ SIGNATURES = {
     "pls_ipb_energy_workspace_bytes": (_SZ, [_ID, _I64, _I64]),
     "pls_ipb_energy": (C.c_int, [_ID, _CD, _P, _P, _I64, _I64, _P, _I32, _P, _SZ, _P]),
     "pls_block_means": (C.c_int, [_P, _I64, _I64, _P, _P]),
+    "pls_chunk_sums": (C.c_int, [_P, _I64, _P, _P]),
     "pls_chol_factor": (C.c_int, [_P, _I64, _I64, _D, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P]),
     "pls_chol_build_operators": (C.c_int, [_P, _I64, _P, _I64, _I64, _P, _I64, _P, _I64, _P]),
     "pls_chol_solve": (C.c_int, [_CHD, _P, _I64, _I64, _P, _I64, _P]),

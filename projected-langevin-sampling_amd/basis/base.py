@@ -45,15 +45,19 @@ class BlockSpec:
     run as S blocks of ``block_cols`` columns.  ``eta`` is a device float64 vector, one entry per block; writing 0
     freezes a block."""
 
-    def __init__(self, block_cols: int, eta: torch.Tensor):
+    def __init__(self, block_cols: int, eta: torch.Tensor, energy_sums: int | None = None):
+        """``energy_sums`` (optional): raw address (device, or pinned host memory) of cdiv(J, 256) doubles that receive the
+        256-column chunk sums of the per-particle energies from the launch that finishes the step's energy by-product
+        (Gaussian/identity fast paths; see pls_block_desc)."""
         assert block_cols > 0
         L.require_gpu_tensor(eta, "eta")
         assert eta.dim() == 1 and eta.is_contiguous()
-        self.block_cols, self.eta = int(block_cols), eta
+        self.block_cols, self.eta, self.energy_sums = int(block_cols), eta, energy_sums
 
     def desc(self) -> L.BlockDesc:
         d = L.BlockDesc()
         d.block_cols, d.eta = self.block_cols, self.eta.data_ptr()
+        d.energy_sums = self.energy_sums
         return d
 
 

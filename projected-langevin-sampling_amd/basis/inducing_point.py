@@ -314,6 +314,10 @@ class InducingPointBasis(PLSBasis):
     def supports_input_energy(self, cost) -> bool:
         return bool(cost.is_native())
 
+    def supports_energy_sums(self, cost) -> bool:
+        """the whitened Gaussian/identity route (see OrthonormalBasis.supports_energy_sums)"""
+        return bool(cost.is_native()) and self.whitened and self._is_gaussian(cost, False)
+
     def fused_particle_energy(self, cost, particles: torch.Tensor, force_generic: bool = False) -> torch.Tensor:
         u = _rows_contiguous(L.require_gpu_tensor(particles, "particles"))
         j = u.shape[1]

@@ -31,14 +31,29 @@ class OrthonormalBasis(PLSBasis):
         keep_gram: bool = True,
         verbose: bool = True,
         eigh_device: str = "cpu",
+        setup_times: dict | None = None,
     ):
         super().__init__(additional_predictive_noise_distribution=additional_predictive_noise_distribution)
+        import time
+
+        #: seconds per setup phase (gram / eigh / projection), filled when ``setup_times`` is a dict (each phase is then
+        #: closed by a device synchronisation; bench.py reports them as config.setup_breakdown)
+        self.setup_times = setup_times
+
+        def lap(name, t0):
+            if setup_times is not None:
+                torch.cuda.synchronize()
+                setup_times[name] = setup_times.get(name, 0.0) + time.perf_counter() - t0
+            return time.perf_counter()
+
+        t_lap = time.perf_counter()
         self.kernel = kernel
         self.x_induce = x_induce  # (M, D)
         m = x_induce.shape[0]
         self.base_gram_induce = self.kernel.base_kernel(x1=x_induce, x2=x_induce)  # k(Z,Z) (M, M)   :36-38
         base_gram_induce_train = self.kernel.base_kernel(x1=x_induce, x2=x_train)  # k(Z,X) (M, N)   :39-41
         dev = self.base_gram_induce.device
+        t_lap = lap("gram_s", t_lap)
         if spectrum is None:
             # :46-48.  "cpu" is the reference's own call (host LAPACK: 0.8 s at M = 1024, the whole setup otherwise
             # takes 0.1 s); "cuda" runs the same factorisation through torch on the GPU (0.09 s) -- another, equally
@@ -50,6 +65,7 @@ class OrthonormalBasis(PLSBasis):
             eigenvalues, eigenvectors = eigenvalues.cpu(), eigenvectors.cpu()
         else:
             eigenvalues, eigenvectors = (t.detach().cpu().to(torch.float64) for t in spectrum)
+        t_lap = lap("eigh_s", t_lap)
         idx = torch.where(eigenvalues > eigenvalue_threshold)[0]  # :52
         eigenvalues = eigenvalues[idx].real
         eigenvectors = eigenvectors[:, idx].real
@@ -75,6 +91,7 @@ class OrthonormalBasis(PLSBasis):
                 "pls_onb_build_projection",
             )
         self.base_gram_induce_train = base_gram_induce_train if keep_gram else None
+        lap("projection_s", t_lap)
         self._B = None  # Gaussian fast path constants, keyed by the y they were built from
         self._c = None
         self._gauss_key = None
@@ -209,6 +226,12 @@ class OrthonormalBasis(PLSBasis):
         Gaussian/identity: the quadratic form of the same B U product; otherwise the cost VALUE of the same F tile the
         derivative is taken of (the reference recomputes F for the energy: projected_langevin_sampling.py:125-138)."""
         return bool(cost.is_native())
+
+    def supports_energy_sums(self, cost) -> bool:
+        """True if the launch that finishes the step's energy by-product can also leave the 256-column chunk sums of the
+        energies (BlockSpec.energy_sums): the Gaussian/identity fast path."""
+        cd = cost.desc() if cost.is_native() else None
+        return cd is not None and cd.cost == L.COST_GAUSSIAN and cd.link == L.LINK_IDENTITY
 
     def step_workspace_bytes(self, cost, j: int, with_energy: bool, force_generic: bool = False) -> int:
         """Bytes fused_step asks of its workspace for ``j`` columns (graph captures allocate their own buffer)."""

@@ -701,15 +701,38 @@ __global__ __launch_bounds__(256) void ipb_gaussian_energy_kernel(const double *
   if (sl == 0 && col < j) e[col] = ((part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl])) + 0.5 * inv_noise * c[m];
 }
 
-// e[col] = sum_p partial[p][col] + yscale * (*yty)
+// Sum of one value per thread over a 256-thread workgroup in a FIXED order: xor butterfly inside each wave (offsets 32, 16,
+// 8, 4, 2, 1), then (w0 + w1) + (w2 + w3).  Every mean of per-particle energies in the library is built from these chunk
+// sums added in ascending chunk order (block_means_kernel, the fused finish kernel below, the host side of the training
+// loops), so all loop variants report bit-identical energies.  Returns the sum in every thread; `ws`: 4 doubles of LDS.
+__device__ __forceinline__ double chunk256_sum(double v, double *ws) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();  // (ws may still be read from a previous call)
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+
+// e[col] = sum_p partial[p][col] + yscale * (*yty);  sums (optional): sums[blockIdx.x] = the chunk sum of this workgroup's 256
+// entries of e (device or pinned host memory: the training loops read the mean energy without a second launch)
 __global__ __launch_bounds__(256) void gaussian_energy_finish_kernel(const double *__restrict__ partial, int64_t ldp,
                                                                       int64_t nparts, int64_t j, double *__restrict__ e,
-                                                                      double yscale, const double *__restrict__ yty) {
+                                                                      double yscale, const double *__restrict__ yty,
+                                                                      double *sums) {
+  __shared__ double ws[4];
   const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (col >= j) return;
-  double s = 0.0;
-  for (int64_t p = 0; p < nparts; ++p) s += partial[p * ldp + col];
-  e[col] = s + yscale * (*yty);
+  double v = 0.0;
+  if (col < j) {
+    double s = 0.0;
+    for (int64_t p = 0; p < nparts; ++p) s += partial[p * ldp + col];
+    v = s + yscale * (*yty);
+    e[col] = v;
+  }
+  if (sums) {  // (kernel-uniform)
+    const double t = chunk256_sum(v, ws);
+    if (threadIdx.x == 0) sums[blockIdx.x] = t;
+  }
 }
 
 __global__ __launch_bounds__(256) void link_transform_kernel(int link, double jitter, const double *__restrict__ in,
@@ -1313,20 +1336,37 @@ int gemm_tn_ex(const double *L, int64_t ldl, const double *R, int64_t ldr, doubl
   return launch_gemm_any(L, ldl, R, ldr, I, J, K, e, st, 0, tri);
 }
 
-// out[b] = mean of e[b * bc, min(j, (b + 1) * bc)): one block per column block, fixed-order tree
+// out[b] = mean of e[b * bc, min(j, (b + 1) * bc)): one workgroup per column block; chunk sums of 256 consecutive entries
+// (chunk256_sum's order) added in ascending order
 __global__ __launch_bounds__(256) void block_means_kernel(const double *__restrict__ e, int64_t j, int64_t bc, double *out) {
-  __shared__ double red[256];
+  __shared__ double wsum[512][4];
   const int64_t c0 = (int64_t)blockIdx.x * bc;
   const int64_t c1 = (c0 + bc < j) ? c0 + bc : j;
-  double s = 0.0;
-  for (int64_t c = c0 + threadIdx.x; c < c1; c += 256) s += e[c];
-  red[threadIdx.x] = s;
-  __syncthreads();
-  for (int w = 128; w > 0; w >>= 1) {
-    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+  const int64_t nchunk = cdiv(c1 - c0, 256);
+  double total = 0.0;
+  for (int64_t k0 = 0; k0 < nchunk; k0 += 512) {
+    const int64_t kb = (nchunk - k0 < 512) ? nchunk - k0 : 512;
+    for (int64_t k = 0; k < kb; ++k) {
+      const int64_t c = c0 + (k0 + k) * 256 + threadIdx.x;
+      double v = (c < c1) ? e[c] : 0.0;
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+      if ((threadIdx.x & 63) == 0) wsum[k][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+      for (int64_t k = 0; k < kb; ++k) total += (wsum[k][0] + wsum[k][1]) + (wsum[k][2] + wsum[k][3]);
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[blockIdx.x] = red[0] / (double)(c1 - c0);
+  if (threadIdx.x == 0) out[blockIdx.x] = total / (double)(c1 - c0);
+}
+
+// out[i] = chunk sum of e[256 i, min(j, 256 (i + 1)))
+__global__ __launch_bounds__(256) void chunk_sums_kernel(const double *__restrict__ e, int64_t j, double *out) {
+  __shared__ double ws[4];
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const double t = chunk256_sum(c < j ? e[c] : 0.0, ws);
+  if (threadIdx.x == 0) out[blockIdx.x] = t;
 }
 
 }  // namespace plship
@@ -1348,7 +1388,7 @@ struct FastOp {
 
 static int fast_step_launch(const FastOp &op, const double *U, int64_t ldu, int64_t j, const EtaP &etap, const NoiseP &nz,
                             double *out, int64_t ldo, int out_mode, double *energy_in, void *workspace,
-                            size_t workspace_bytes, hipStream_t st, const char *who) {
+                            size_t workspace_bytes, hipStream_t st, const char *who, double *esums = nullptr) {
   const bool big = pick_gemm_cfg(op.B, op.ldb, U, ldu, op.mk, j, op.mk) == CFG_BIG;
   const int64_t parts = big ? 2 * cdiv(op.mk, 128) : cdiv(op.mk, 64);
   double *epart = nullptr;
@@ -1362,7 +1402,7 @@ static int fast_step_launch(const FastOp &op, const double *U, int64_t ldu, int6
   int rc = launch_gemm_any(op.B, op.ldb, U, ldu, op.mk, j, op.mk, e, st);
   if (rc || !energy_in) return rc;
   hipLaunchKernelGGL(gaussian_energy_finish_kernel, dim3((unsigned)cdiv(j, 256)), dim3(256), 0, st, epart, j, parts, j,
-                     energy_in, op.yscale, op.yty);
+                     energy_in, op.yscale, op.yty, esums);
   return check_launch("gaussian_energy_finish");
 }
 
@@ -1393,7 +1433,7 @@ static int fast_energy_launch(const FastOp &op, const double *U, int64_t ldu, in
   }
   if (rc) return rc;
   hipLaunchKernelGGL(gaussian_energy_finish_kernel, dim3((unsigned)cdiv(j, 256)), dim3(256), 0, st, partial, j, parts, j, e,
-                     op.yscale, op.yty);
+                     op.yscale, op.yty, (double *)nullptr);
   return check_launch("gaussian_energy_finish");
 }
 
@@ -1531,6 +1571,13 @@ int pls_block_means(const double *e, int64_t j, int64_t block_cols, double *out,
   PLS_REQUIRE(cdiv(j, block_cols) <= 0x7fffffff, "block_means: too many blocks");
   hipLaunchKernelGGL(block_means_kernel, dim3((unsigned)cdiv(j, block_cols)), dim3(256), 0, S(stream), e, j, block_cols, out);
   return check_launch("block_means");
+}
+
+int pls_chunk_sums(const double *e, int64_t j, double *out, void *stream) {
+  PLS_REQUIRE(e && out && j >= 0, "chunk_sums: bad arguments");
+  if (j == 0) return PLS_OK;
+  hipLaunchKernelGGL(chunk_sums_kernel, dim3((unsigned)cdiv(j, 256)), dim3(256), 0, S(stream), e, j, out);
+  return check_launch("chunk_sums");
 }
 
 int pls_cost_derivative(const pls_cost_desc *cost, const double *F, int64_t ldf, const double *y, int64_t n, int64_t j,
@@ -1773,7 +1820,8 @@ static int onb_step_impl(const pls_onb_desc *basis, const pls_cost_desc *cost, c
   hipStream_t st = S(stream);
   if (onb_fast_path(basis, cost, force_generic)) {
     const FastOp op{basis->B, basis->ldb, basis->c, basis->lam, basis->mk, 1.0 / cost->p[0], 0.5 / cost->p[0], basis->c + basis->mk};
-    return fast_step_launch(op, U, ldu, j, etap, nz, out, ldo, out_mode, energy_in, workspace, workspace_bytes, st, "onb_step");
+    return fast_step_launch(op, U, ldu, j, etap, nz, out, ldo, out_mode, energy_in, workspace, workspace_bytes, st, "onb_step",
+                            blocks ? blocks->energy_sums : nullptr);
   }
   // workspace: [D slabs][cost partial rows (energy by-product)][G chunk]; the chunk length follows from what is left
   const size_t d_bytes = align_up((size_t)basis->mk * j * sizeof(double), 256);
@@ -2062,7 +2110,7 @@ static int ipb_step_impl(const pls_ipb_desc *basis, const pls_cost_desc *cost, c
     const int64_t ld_inj = nz.ldxi;
     if (injected) nz.kind = PLS_NOISE_NONE;  // (the injected noise is already coloured: it enters after the product with Lc)
     rc = fast_step_launch(ipb_whitened_op(basis), Sw, j, j, make_etap(eta, blocks), nz, Wd, j, 0, energy_in, epart,
-                          2 * mj, st, "ipb_step");
+                          2 * mj, st, "ipb_step", blocks ? blocks->energy_sums : nullptr);
     if (rc) return rc;
     EpiIpbFinish fin{out, ldo, U, ldu, out_mode, make_etap(eta, blocks), e_inj, ld_inj};
     return launch_gemm_any(basis->LcT, basis->ldlct, Wd, j, basis->m, j, basis->m, fin, st, 0, 1);
@@ -2268,7 +2316,8 @@ static int ipb_whitened_step_impl(const pls_ipb_desc *basis, const pls_cost_desc
   PLS_REQUIRE(out_mode == 0 || out_mode == 1, "ipb_whitened_step: out_mode must be 0 or 1");
   if (j == 0) return PLS_OK;
   return fast_step_launch(ipb_whitened_op(basis), Sw, lds, j, make_etap(eta, blocks), make_noisep(noise, blocks), out, ldo,
-                          out_mode, energy_in, workspace, workspace_bytes, S(stream), "ipb_whitened_step");
+                          out_mode, energy_in, workspace, workspace_bytes, S(stream), "ipb_whitened_step",
+                          blocks ? blocks->energy_sums : nullptr);
 }
 
 int pls_ipb_whitened_step(const pls_ipb_desc *basis, const pls_cost_desc *cost, const double *Sw, int64_t lds, int64_t j,

@@ -107,6 +107,13 @@ class CapturedTraining:
         self._start = torch.empty_like(particles)  # particles at the start of the last replay (roll-back point)
         self._e = torch.empty(particles.shape[1], dtype=torch.float64, device=particles.device)
         self.means = torch.zeros(steps_per_replay, dtype=torch.float64, device=particles.device)
+        # Gaussian/identity fast paths: the finishing launch of the energy by-product leaves the 256-column chunk sums; the
+        # host adds them after the replay (no mean launch inside the graph)
+        j = particles.shape[1]
+        self._fused_sums = bool(getattr(pls.basis, "supports_energy_sums", lambda c: False)(pls.cost))
+        self._nchunk = (j + 255) // 256
+        self._sums = torch.zeros(steps_per_replay, self._nchunk, dtype=torch.float64, device=particles.device)
+        self._eta = torch.full((1,), float(step_size), dtype=torch.float64, device=particles.device)
         self.counter = torch.zeros(1, dtype=torch.int64, device=particles.device)
         basis, cost = pls.basis, pls.cost
         self._ws = _own_workspace(basis, cost, particles, with_energy=True)  # owned by the capture (see CapturedSteps)
@@ -116,9 +123,16 @@ class CapturedTraining:
             cur, nxt = self.particles, self._pong
             for s in range(self.k):
                 spec = NoiseSpec(seed=self.seed, step=s, j_offset=basis.j_offset, step_base=self.counter)
-                basis.fused_step(cost, cur, self.step_size, out=nxt, new_state=True, noise=spec, input_energy=self._e,
-                                 workspace=self._ws)
-                _ops.block_means(self._e, out=self.means[s: s + 1])  # E(U_{k0 + s}), the INPUT of launch k0 + s
+                if self._fused_sums:
+                    from .basis.base import BlockSpec
+
+                    blocks = BlockSpec(cur.shape[1], self._eta, energy_sums=self._sums[s].data_ptr())
+                    basis.fused_step(cost, cur, self.step_size, out=nxt, new_state=True, noise=spec, input_energy=self._e,
+                                     workspace=self._ws, blocks=blocks)
+                else:
+                    basis.fused_step(cost, cur, self.step_size, out=nxt, new_state=True, noise=spec, input_energy=self._e,
+                                     workspace=self._ws)
+                    _ops.block_means(self._e, out=self.means[s: s + 1])  # E(U_{k0 + s}), the INPUT of launch k0 + s
                 cur, nxt = nxt, cur
             if cur is not self.particles:
                 self.particles.copy_(cur)
@@ -157,6 +171,11 @@ class CapturedTraining:
         """K more steps; returns the (K,) host vector [E(U_k0), ..., E(U_{k0+K-1})], k0 = steps done before the call."""
         self.graph.replay()
         self.steps_done += self.k
+        if self._fused_sums:
+            from .trainers import mean_from_chunk_sums
+
+            rows = self._sums.cpu().tolist()
+            return torch.tensor([mean_from_chunk_sums(r, self.particles.shape[1]) for r in rows], dtype=torch.float64)
         return self.means.cpu()
 
     def roll_back(self) -> None:

@@ -30,6 +30,19 @@ class EarlyStopper:
             return False
 
 
+def mean_from_chunk_sums(sums, count: int) -> float:
+    """Mean energy from the 256-column chunk sums the step's finishing launch leaves (pls_block_desc.energy_sums): the
+    chunks added in ascending order, divided by the particle count -- what pls_block_means computes, bit for bit."""
+    total = 0.0
+    for v in sums:
+        total += float(v)
+    return total / count
+
+
+def _supports_energy_sums(pls: PLS) -> bool:
+    return bool(getattr(pls.basis, "supports_energy_sums", lambda c: False)(pls.cost))
+
+
 def _mean_energy(e: torch.Tensor) -> float:
     """Mean over the particles of the per-particle energies (orthonormal.py:126's .mean().item()): libplship's fixed-order
     reduction for device vectors, so that every loop variant (plain, pipelined, captured) reports identical values."""
@@ -111,13 +124,21 @@ def _train_pls_two_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs
     index as the plain loop (tests/test_gpu_parity.py)."""
     from .basis.base import NoiseSpec
 
+    from .basis.base import BlockSpec
+
     T = number_of_epochs
     j = particles.shape[1]
     bufs = [particles, torch.empty_like(particles, memory_format=torch.contiguous_format),
             torch.empty_like(particles, memory_format=torch.contiguous_format)]
     e_dev = [torch.empty(j, dtype=torch.float64, device=particles.device) for _ in range(3)]
-    host = torch.empty(3, dtype=torch.float64).pin_memory()
+    # Gaussian/identity fast paths: the launch that finishes the energy by-product also leaves the 256-column chunk sums of
+    # the energies -- straight in pinned host memory -- so an iteration is the step kernel and ONE small launch (round 2: a
+    # finishing launch plus a mean launch, 15 us of a 280 us iteration); other costs keep the separate mean launch
+    fused_sums = _supports_energy_sums(pls)
+    nchunk = (j + 255) // 256 if fused_sums else 1
+    host = torch.empty(3 * nchunk, dtype=torch.float64).pin_memory()
     host_ptr = host.data_ptr()  # (hipHostMalloc'ed by torch: host and device addresses coincide)
+    eta_dev = torch.full((1,), float(step_size), dtype=torch.float64, device=particles.device) if fused_sums else None
     events = [torch.cuda.Event() for _ in range(3)]
     rng_states = {}
     launched = 0
@@ -127,13 +148,23 @@ def _train_pls_two_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs
         k = launched
         rng_states[k] = torch.get_rng_state()  # (a speculative launch may have to be un-drawn)
         spec = NoiseSpec(injected=noises[k]) if noises is not None else None
-        pls.basis.fused_step(pls.cost, bufs[k % 3], float(step_size), out=bufs[(k + 1) % 3], new_state=True, noise=spec,
-                             input_energy=e_dev[k % 3])
-        # E(U_k): the reduction kernel stores the mean straight into pinned host memory (mapped into the device's address
-        # space); the host reads it after the event -- no torch reduce kernel, no copy kernel per iteration
-        _ops.block_means(e_dev[k % 3], out_ptr=host_ptr + 8 * (k % 3))
+        if fused_sums:  # one column block = all particles, its step size from a device word, chunk sums to the host slot
+            blocks = BlockSpec(j, eta_dev, energy_sums=host_ptr + 8 * nchunk * (k % 3))
+            pls.basis.fused_step(pls.cost, bufs[k % 3], float(step_size), out=bufs[(k + 1) % 3], new_state=True, noise=spec,
+                                 input_energy=e_dev[k % 3], blocks=blocks)
+        else:
+            pls.basis.fused_step(pls.cost, bufs[k % 3], float(step_size), out=bufs[(k + 1) % 3], new_state=True, noise=spec,
+                                 input_energy=e_dev[k % 3])
+            # E(U_k): the reduction kernel stores the mean straight into pinned host memory (mapped into the device's
+            # address space); the host reads it after the event -- no torch reduce kernel, no copy kernel per iteration
+            _ops.block_means(e_dev[k % 3], out_ptr=host_ptr + 8 * (k % 3))
         events[k % 3].record()
         launched += 1
+
+    def read_energy(slot: int) -> float:
+        if fused_sums:
+            return mean_from_chunk_sums(host[slot * nchunk:(slot + 1) * nchunk].tolist(), j)
+        return host[slot].item()
 
     energy_potentials: List[float] = []
     final = None
@@ -142,7 +173,7 @@ def _train_pls_two_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs
             launch()
         if t + 1 < T:
             events[(t + 1) % 3].synchronize()
-            energy_potential = host[(t + 1) % 3].item()
+            energy_potential = read_energy((t + 1) % 3)
         else:  # the energy after the last update has no following launch to ride on
             energy_potential = _mean_energy(pls.particle_energy_potential(bufs[T % 3]))
         if early_stopper.should_stop(loss=energy_potential, step_size=step_size):

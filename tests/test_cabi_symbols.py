@@ -68,7 +68,7 @@ def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(L.OnbDesc) == 10 * 8
     assert ctypes.sizeof(L.IpbDesc) == 25 * 8
     assert ctypes.sizeof(L.CholDesc) == 13 * 8
-    assert ctypes.sizeof(L.BlockDesc) == 2 * 8
+    assert ctypes.sizeof(L.BlockDesc) == 3 * 8
     assert L.CostDesc.p.offset == 16 and L.CostDesc.jitter.offset == 48
 
 
@@ -84,7 +84,7 @@ def test_struct_layouts_match_what_a_c_compiler_makes_of_the_header(tmp_path):
     L = pkg._lib
     structs = {"pls_cost_desc": (L.CostDesc, "jitter"), "pls_noise_desc": (L.NoiseDesc, "step_base"),
                "pls_onb_desc": (L.OnbDesc, "c"), "pls_ipb_desc": (L.IpbDesc, "q_inv_noise"),
-               "pls_chol_desc": (L.CholDesc, "ldlinvt"), "pls_block_desc": (L.BlockDesc, "eta")}
+               "pls_chol_desc": (L.CholDesc, "ldlinvt"), "pls_block_desc": (L.BlockDesc, "energy_sums")}
     src = tmp_path / "layout.c"
     body = "".join(f'  printf("{n} %zu %zu\\n", sizeof({n}), offsetof({n}, {last}));\n' for n, (_, last) in structs.items())
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "plship.h"\nint main(void) {\n' + body + "  return 0;\n}\n")
