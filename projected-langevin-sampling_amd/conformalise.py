@@ -1,8 +1,9 @@
 """Conformal prediction intervals (drop-in for src/conformalise/base.py:9-160 and src/conformalise/pls.py:8-62).
 
 The per-test-point quantiles over the J particles are the J-reduction of this wrapper; they run as one LDS sort per
-test point (pls_row_quantiles).  On a J-sharded run the prediction samples of all ranks are all-gathered first
-(collective C3 of SURVEY.md 2.2), because an order statistic needs every sample of its row."""
+test point (pls_row_quantiles).  On a J-sharded run every rank predicts its own particles' samples, the rows (test points)
+are dealt out over the ranks by an all-to-all, each rank sorts its N*/G rows of all J samples, and the quantiles are
+all-gathered (distributed.sharded_row_quantiles: collective C3 of SURVEY.md 8e)."""
 from __future__ import annotations
 
 from dataclasses import dataclass
@@ -10,7 +11,6 @@ from typing import Tuple
 
 import numpy as np
 import torch
-import torch.distributed as dist
 
 from . import _ops
 from .kernel import _dev
@@ -25,22 +25,6 @@ class ConformalPrediction:
     upper: torch.Tensor
 
 
-def _gather_columns(local: torch.Tensor, group=None) -> torch.Tensor:
-    """(N*, J_local) per rank -> (N*, J) on every rank; shards may differ by one column."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return local
-    world = dist.get_world_size(group)
-    widths = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(world)]
-    dist.all_gather(widths, torch.tensor([local.shape[1]], dtype=torch.int64, device=local.device), group=group)
-    widths = [int(w.item()) for w in widths]
-    wmax = max(widths)
-    padded = torch.zeros((wmax, local.shape[0]), dtype=local.dtype, device=local.device)
-    padded[: local.shape[1]] = local.T
-    parts = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(parts, padded, group=group)
-    return torch.cat([p[:w].T for p, w in zip(parts, widths)], dim=1).contiguous()
-
-
 class ConformalisePLS:
     """conformalise/pls.py:8-62 on top of conformalise/base.py:19-160 (https://arxiv.org/abs/2107.07511)."""
 
@@ -52,17 +36,20 @@ class ConformalisePLS:
         self.y_calibration = y_calibration
         self.number_of_calibration_points = x_calibration.shape[0]
 
-    def _samples(self, x: torch.Tensor) -> torch.Tensor:
+    def _quantiles(self, x: torch.Tensor, q) -> torch.Tensor:
+        """(N*, len(q)) quantiles over all J particles: this rank's samples, then the sharded reduction"""
+        from .distributed import sharded_row_quantiles
+
         samples = self.pls.predict_samples(x=x, particles=self.particles, predictive_noise=None, observation_noise=None)
-        return _gather_columns(samples, self.group)
+        return sharded_row_quantiles(samples, q, self.group)
 
     def _predict_uncalibrated_coverage(self, coverage: float, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """Quantiles 0.5 -/+ coverage/2 of the particle predictions (conformalise/pls.py:24-45)."""
-        q = _ops.row_quantiles(self._samples(x), [0.5 - coverage / 2, 0.5 + coverage / 2])
+        q = self._quantiles(x, [0.5 - coverage / 2, 0.5 + coverage / 2])
         return q[:, 0].contiguous(), q[:, 1].contiguous()
 
     def predict_median(self, x: torch.Tensor) -> torch.Tensor:
-        return _ops.row_quantiles(self._samples(x), [0.5])[:, 0].contiguous()  # conformalise/pls.py:47-62
+        return self._quantiles(x, [0.5])[:, 0].contiguous()  # conformalise/pls.py:47-62
 
     def _calculate_calibration(self, coverage: float) -> float:
         """conformalise/base.py:58-90: the (n+1) c / n quantile of the conformity scores."""

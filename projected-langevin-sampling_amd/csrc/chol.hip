@@ -224,12 +224,6 @@ struct StripArgs {
 [[maybe_unused]] constexpr int TS_NQ = TS_BK / 4;        // k-quads per sub-step
 [[maybe_unused]] constexpr int TS_NSUB = TS_RK / TS_BK;  // sub-steps per R tile
 constexpr int TS_TILE = TS_RK * TS_SC;  // doubles per LDS tile
-#ifndef PLS_STRIP_AD
-#define PLS_STRIP_AD 1  // sub-steps between the request of an A fragment and its MFMAs (1, or 3 for the A/B build)
-#endif
-#ifndef PLS_STRIP_INTERLEAVE
-#define PLS_STRIP_INTERLEAVE 1  // 0: all operand requests of a sub-step in one burst ahead of its MFMAs (A/B builds)
-#endif
 
 struct TileDesc {  // wave-uniform
   const double *S;  // first operator row of the tile (S + k0 * lds); range 0 = no tile
@@ -296,20 +290,6 @@ __device__ __forceinline__ TileDesc make_tile(const StripArgs &a, const RowState
   const bool global_rows = r.valid && !handover;
   d.R = global_rows ? (d.r_is_u ? a.U : a.V) + k0 * d.ldr : nullptr;
   d.r_bytes = global_rows ? clamp_range((r.kend - k0) * d.ldr * 8) : 0;
-#if defined(PLS_STRIP_ABL_NORU)  // ablation builds: no U tiles / no V tiles / every tile from the same hot rows of V
-  if (d.r_is_u) d.r_bytes = 0;
-#endif
-#if defined(PLS_STRIP_ABL_NORV)
-  if (!d.r_is_u) d.r_bytes = 0;
-#endif
-#if defined(PLS_STRIP_ABL_RHOT)
-  if (global_rows) {
-    d.R = a.V;
-    d.ldr = a.ldv;
-    d.r_is_u = 0;
-    d.r_bytes = clamp_range((int64_t)TS_NB * a.ldv * 8);
-  }
-#endif
   return d;
 }
 
@@ -366,7 +346,6 @@ __device__ __forceinline__ void strip_solve(const StripArgs &a, int fwd_only, in
   // A fragments of k-quads 2 p, 2 p + 1 of sub-step `sub` of tile d -> afr[sub]
   auto load_a_pair = [&](const TileDesc &d, int voff, auto sub_tag, int p) {
     constexpr int sub = decltype(sub_tag)::value;
-#if !defined(PLS_STRIP_ABL_NOA)
     const __amdgpu_buffer_rsrc_t ra =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(d.S), 0, d.s_bytes, 0x00020000);
     const int row4 = (int)(d.lds * 32);  // bytes per 4 rows of S
@@ -374,16 +353,10 @@ __device__ __forceinline__ void strip_solve(const StripArgs &a, int fwd_only, in
 #pragma unroll
     for (int kq = 2 * p; kq < 2 * p + 2; ++kq)
       afr[sub][kq] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(ra, voff, sub_off + kq * row4, 0));
-#else
-    (void)d, (void)voff, (void)p;
-#endif
   };
   // B fragments of the same pair of k-quads of sub-step `sub` of an LDS tile -> bq[buf]
   auto read_b_pair = [&](const double *tile, int sub, auto buf_tag, int p) {
     constexpr int buf = decltype(buf_tag)::value;
-#if defined(PLS_STRIP_ABL_NOB)
-    return;
-#endif
     const double *r0 = tile + sub * TS_BK * TS_SC + bo0, *r1 = tile + sub * TS_BK * TS_SC + bo1;
 #pragma unroll
     for (int kq = 2 * p; kq < 2 * p + 2; ++kq) {
@@ -398,9 +371,6 @@ __device__ __forceinline__ void strip_solve(const StripArgs &a, int fwd_only, in
   // sub-step 2 are requested after these, so the MFMAs of sub-step 2 (which precede the tile's barrier) cannot start
   // before the rows have landed.  Ragged strips go through registers (store_r after sub-step 1).
   auto load_r_part = [&](const TileDesc &d, double *tile, int p) {
-#if defined(PLS_STRIP_ABL_NOR)
-    return;
-#endif
     const __amdgpu_buffer_rsrc_t rr =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(d.R ? d.R : a.V), 0, d.r_bytes, 0x00020000);
     if constexpr (VEC) {
@@ -416,9 +386,6 @@ __device__ __forceinline__ void strip_solve(const StripArgs &a, int fwd_only, in
     }
   };
   auto store_r = [&](double *tile) {
-#if defined(PLS_STRIP_ABL_NOR)
-    return;
-#endif
     if constexpr (!VEC) {
 #pragma unroll
       for (int p = 0; p < NSUB; ++p) *reinterpret_cast<double2v *>(tile + p * TS_BK * TS_SC + st_off) = rreg[p];
@@ -442,25 +409,13 @@ __device__ __forceinline__ void strip_solve(const StripArgs &a, int fwd_only, in
                      const TileDesc *dr, double *rtile) {
 #pragma unroll
     for (int p = 0; p < NQ / 2; ++p) {
-#if PLS_STRIP_INTERLEAVE
       load_a_pair(da, voffa, asub_tag, p);
       if (dr) load_r_part(*dr, rtile, p);
       read_b_pair(tileb, bsub, bbuf_tag, p);
       __builtin_amdgcn_sched_barrier(0);
       mfma_pair(sub_tag, p);
       __builtin_amdgcn_sched_barrier(0);
-#else
-      load_a_pair(da, voffa, asub_tag, p);
-      if (dr) load_r_part(*dr, rtile, p);
-      read_b_pair(tileb, bsub, bbuf_tag, p);
-#endif
     }
-#if !PLS_STRIP_INTERLEAVE
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int p = 0; p < NQ / 2; ++p) mfma_pair(sub_tag, p);
-    __builtin_amdgcn_sched_barrier(0);
-#endif
   };
   using B0 = std::integral_constant<int, 0>;
   using B1 = std::integral_constant<int, 1>;
@@ -482,26 +437,11 @@ __device__ __forceinline__ void strip_solve(const StripArgs &a, int fwd_only, in
     load_r_part(cur, Rs, p);
     load_a_pair(cur, voff_cur, S0{}, p);
   }
-#if PLS_STRIP_AD == 3
-#pragma unroll
-  for (int p = 0; p < NQ / 2; ++p) {
-    load_a_pair(cur, voff_cur, S1{}, p);
-    load_a_pair(cur, voff_cur, S2{}, p);
-  }
-#endif
-#if defined(PLS_STRIP_ABL_NOA)
-  for (int sb = 0; sb < NSUB; ++sb)
-    for (int kq = 0; kq < NQ; ++kq) afr[sb][kq] = 1e-3 * (lane + kq + sb);
-#endif
   store_r(Rs);
   __syncthreads();
   const double *curbuf = Rs;
 #pragma unroll
   for (int p = 0; p < NQ / 2; ++p) read_b_pair(curbuf, 0, B0{}, p);
-#if defined(PLS_STRIP_ABL_NOB)
-  for (int bb = 0; bb < 2; ++bb)
-    for (int kq = 0; kq < NQ; ++kq) bq[bb][kq][0] = bq[bb][kq][1] = 1e-3 * (lane + kq);
-#endif
   int gcount = 1;  // global tiles staged so far: the next one goes to Rs[gcount & 1]
 
   for (;;) {
@@ -512,34 +452,16 @@ __device__ __forceinline__ void strip_solve(const StripArgs &a, int fwd_only, in
     double *const nxt_rs = Rs + (gcount & 1) * TS_TILE;
     const double *nxtbuf = nxt.R ? nxt_rs : Hs + nxt.hbuf * TS_TILE;
     // sub-step 0: also requests the next tile's rows (range 0 if it has none)
-#if PLS_STRIP_AD == 3
-    // A/B build: A fragments requested THREE sub-steps ahead.  Loads complete in order, so a slow tile request holds back
-    // every younger load of the wave, and the first touch of a block of U IS slow (all 256 strips ask for theirs at the
-    // same moment: ablation at M = 1024 -- every tile served from hot lines 0.326 ms, no U tiles 0.333, shipped 0.377).
-    // Measured: no change (0.384 vs 0.383 ms) -- the latency is not paid by the MFMAs waiting for fragments but at the
-    // tile's barrier, which must see the rows landed three sub-steps after they were requested.
-    substep(S0{}, cur, voff_cur, S3{}, curbuf, 1, B1{}, &nxt, nxt_rs);
-    substep(S1{}, nxt, voff_nxt, S0{}, curbuf, 2, B0{}, nullptr, nullptr);
-    store_r(nxt_rs);
-    substep(S2{}, nxt, voff_nxt, S1{}, curbuf, 3, B1{}, nullptr, nullptr);
-#else
     substep(S0{}, cur, voff_cur, S1{}, curbuf, 1, B1{}, &nxt, nxt_rs);
     substep(S1{}, cur, voff_cur, S2{}, curbuf, 2, B0{}, nullptr, nullptr);
     store_r(nxt_rs);
     substep(S2{}, cur, voff_cur, S3{}, curbuf, 3, B1{}, nullptr, nullptr);
-#endif
-#if !defined(PLS_STRIP_ABL_NOBAR)
     if (cur.first)
       __syncthreads();  // once per block row: also completes this wave's stores of the previous row's block
     else
       lds_barrier();
-#endif
     // sub-step 3 fetches the next tile's first operands (a hand-over tile that this row is about to write is read again below)
-#if PLS_STRIP_AD == 3
-    substep(S3{}, nxt, voff_nxt, S2{}, nxtbuf, 0, B0{}, nullptr, nullptr);
-#else
     substep(S3{}, nxt, voff_nxt, S0{}, nxtbuf, 0, B0{}, nullptr, nullptr);
-#endif
     if (cur.last) {  // the block row is complete: result -> global V and the hand-over tile
       double *const hand = Hs + (cur.s & 1) * TS_TILE;
 #pragma unroll

@@ -2,7 +2,8 @@
 
 Every particle column evolves independently given the replicated basis, so a rank owns a contiguous block of
 columns and the Langevin step needs NO collective.  RCCL (torch.distributed backend "nccl") is used only where
-the reference reduces over J: the mean energy (orthonormal.py:126) and predictive moments (gaussian.py:49-52).
+the reference reduces over J: the mean energy (orthonormal.py:126), predictive moments (gaussian.py:49-52) and the
+per-test-point quantiles of the conformal wrapper (conformalise/pls.py:36-45).
 The noise counters use GLOBAL column indices (basis.j_offset), so 1/2/4/8-GPU runs give identical particles."""
 from __future__ import annotations
 
@@ -80,3 +81,53 @@ def gather_particles(local_particles: torch.Tensor, number_of_particles: int, gr
     out = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(out, padded, group=group)
     return torch.cat([o[: b - a].T for o, (a, b) in zip(out, widths)], dim=1)
+
+
+def sharded_row_quantiles(local_samples: torch.Tensor, q, group=None) -> torch.Tensor:
+    """Quantiles over ALL J particles of every row of (N*, J_local) prediction samples -> (N*, len(q)) on every rank
+    (collective C3 of SURVEY.md 8e; replaces torch.quantile(samples, q, dim=1) at conformalise/pls.py:36-45, :57-62).
+
+    An order statistic needs every sample of its row, but not every row on every rank: the rows are dealt out over the
+    ranks (all-to-all of N*/G x J_local blocks), each rank sorts its N*/G rows of all J samples, and the N* x len(q)
+    quantiles are all-gathered -- 1/G of the sorting work and of the receive volume of gathering all samples everywhere
+    (round 2 did that, and round 1 gathered the (M, J) particles and repeated the prediction on every rank).  The
+    result does not depend on the world size: a quantile is a function of the multiset of a row's samples.
+    Device tensors go through libplship's row quantiles; CPU tensors (gloo tests of the bookkeeping) through torch."""
+    qs = [float(v) for v in q]
+
+    def quantiles(block: torch.Tensor) -> torch.Tensor:
+        if block.device.type == "cuda":
+            from . import _ops
+
+            return _ops.row_quantiles(block, qs)
+        return torch.quantile(block, torch.tensor(qs, dtype=block.dtype), dim=1).T.contiguous()
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return quantiles(local_samples.contiguous())
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n = local_samples.shape[0]
+    widths = [torch.zeros(1, dtype=torch.int64, device=local_samples.device) for _ in range(world)]
+    dist.all_gather(widths, torch.tensor([local_samples.shape[1]], dtype=torch.int64, device=local_samples.device), group=group)
+    widths = [int(w.item()) for w in widths]
+    rows = [shard_bounds(n, r, world) for r in range(world)]
+    r0, r1 = rows[rank]
+    send = [local_samples[a:b, :].contiguous() for a, b in rows]
+    recv = [torch.empty((r1 - r0, w), dtype=local_samples.dtype, device=local_samples.device) for w in widths]
+    # the all-to-all as one batch of point-to-point operations (RCCL groups them into one exchange over the xGMI links;
+    # gloo, used by the CPU tests, has no all_to_all)
+    recv[rank].copy_(send[rank])
+    ops = []
+    for peer in range(world):
+        if peer != rank:
+            ops.append(dist.P2POp(dist.isend, send[peer], peer, group))
+            ops.append(dist.P2POp(dist.irecv, recv[peer], peer, group))
+    for req in dist.batch_isend_irecv(ops) if ops else []:
+        req.wait()
+    mine = quantiles(torch.cat(recv, dim=1).contiguous()) if r1 > r0 else torch.empty((0, len(qs)), dtype=local_samples.dtype,
+                                                                                     device=local_samples.device)
+    hmax = max(b - a for a, b in rows)
+    padded = torch.zeros((hmax, len(qs)), dtype=local_samples.dtype, device=local_samples.device)
+    padded[: r1 - r0] = mine
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded, group=group)
+    return torch.cat([p[: b - a] for p, (a, b) in zip(parts, rows)], dim=0).contiguous()

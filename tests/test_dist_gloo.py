@@ -45,6 +45,14 @@ def _worker(rank, world, port, j, out_dir):
     # C3: all-gather of ragged shards
     gathered = D.gather_particles(local, j)
     assert torch.equal(gathered, full)
+    # C3 as the conformal wrapper uses it: quantiles over all J samples of every test point, rows dealt out over the ranks
+    # (all-to-all), each rank sorts its share, quantiles all-gathered -- bit for bit the single-process quantiles
+    for n_star in (7, 4, 1):
+        pred_full = torch.randn(n_star, j, generator=torch.Generator().manual_seed(5 + n_star), dtype=torch.float64)
+        qs = [0.05, 0.5, 0.95]
+        want = torch.quantile(pred_full, torch.tensor(qs, dtype=torch.float64), dim=1).T
+        got = D.sharded_row_quantiles(pred_full[:, j0:j1].contiguous(), qs)
+        assert got.shape == (n_star, 3) and torch.equal(got, want), (n_star, rank)
     dist.barrier()
     dist.destroy_process_group()
     open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
