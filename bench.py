@@ -574,12 +574,13 @@ def main():
         # the same K steps as a captured hipGraph (10 steps per replay): what the launch overhead costs on small shards
         from projected_langevin_sampling_amd.graph import CapturedSteps
 
-        gsteps = 10
+        # (a replay costs 10-16 us of launch: narrow shards, whose step is tens of microseconds, get more steps per replay)
+        gsteps = 10 if j_loc >= 4096 else 50
         run_g = CapturedSteps(pkg.PLS(basis, cost), ping.clone(), eta, steps_per_replay=gsteps, seed=4321)
         run_g.replay(2)
         barrier()
         t0 = time.perf_counter()
-        reps = max(fsteps // gsteps, 5)
+        reps = max(fsteps // gsteps, 20)
         run_g.replay(reps)
         barrier()
         dtg = time.perf_counter() - t0
@@ -587,6 +588,7 @@ def main():
             tt = torch.tensor([dtg], dtype=torch.float64, device="cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dtg = tt.item()
+        out["gaussian_fast_path"]["hipgraph_steps_per_replay"] = gsteps
         out["gaussian_fast_path"]["hipgraph_ms_per_step"] = dtg / (reps * gsteps) * 1e3
         out["gaussian_fast_path"]["hipgraph_steps_per_s"] = reps * gsteps / dtg
         del run_g
