@@ -729,6 +729,16 @@ def main():
             barrier()
             dti_white = (time.perf_counter() - t0) / reps
             del sw, sb
+            # the reference's train loop on this basis (trainers.py:139-162): whitened between the steps, energy every step
+            from projected_langevin_sampling_amd.trainers import train_pls as _train
+
+            torch.manual_seed(1)
+            _train(pkg.PLS(ipb, cost), a.clone(), 10, eta_i, 1e30)
+            barrier()
+            t0 = time.perf_counter()
+            _, e_ipb = _train(pkg.PLS(ipb, cost), a, 200, eta_i, 1e30)
+            barrier()
+            dti_train = (time.perf_counter() - t0) / max(len(e_ipb), 1)
         out["inducing_point_basis"] = {
             "ms_per_step": dti * 1e3, "steps": args.ipb_steps, "setup_s": round(t_ipb, 2),
             "step": "V = K_ZZ^-1 U (MFMA) -> F = K_XZ V -> d cost/d f -> K_ZX G -> e = L_c xi (Philox + MFMA) -> update",
@@ -739,6 +749,7 @@ def main():
                                        "factor), dS = -eta (Q S - c~) + sqrt(2 eta) xi (one fused kernel), dU = Lc dS: 4 M^2 J flop",
             "gaussian_whitened_loop_ms_per_step": None if dti_white is None else dti_white * 1e3,
             "gaussian_whitened_loop_note": "a loop that keeps S between steps (pls_ipb_whitened_step): 2 M^2 J flop, one kernel per step",
+            "gaussian_train_pls_ms_per_iteration": None if dti_white is None else dti_train * 1e3,
         }
         log(f"inducing-point basis: {dti * 1e3:.2f} ms/step")
         del ipb, a, b

@@ -43,6 +43,43 @@ def _supports_energy_sums(pls: PLS) -> bool:
     return bool(getattr(pls.basis, "supports_energy_sums", lambda c: False)(pls.cost))
 
 
+class _LoopSpace:
+    """The coordinates a training loop keeps its particles in between steps.  Identity for every basis but one: the
+    inducing-point basis under the Gaussian cost with the identity link, whose step is ONE contraction per iteration in
+    whitened coordinates S = Lc^-1 U (InducingPointBasis.whitened_step: 2 M^2 J flop) against forward solve + contraction
+    + Lc dS per call (4 M^2 J) -- the loop whitens once, steps S, and maps back once (same chain, same noise counters,
+    same energies to rounding: tests/test_gpu_whitened.py).  Injected noise matrices are coloured (N(0, k(Z,Z)) samples
+    the reference's sampler would have drawn), so a loop that injects them stays in the original coordinates."""
+
+    def __init__(self, pls: PLS, noises):
+        basis, cost = pls.basis, pls.cost
+        self.pls = pls
+        self.whitened = bool(
+            noises is None and getattr(basis, "whitened", False) and hasattr(basis, "whitened_step")
+            and getattr(cost, "is_native", lambda: False)() and basis._is_gaussian(cost, False)
+        )
+
+    def enter(self, particles: torch.Tensor) -> torch.Tensor:
+        return self.pls.basis.whiten(particles) if self.whitened else particles
+
+    def step(self, state, step_size, out, noise, input_energy, blocks=None):
+        basis, cost = self.pls.basis, self.pls.cost
+        fn = basis.whitened_step if self.whitened else basis.fused_step
+        return fn(cost, state, float(step_size), out=out, new_state=True, noise=noise, input_energy=input_energy, blocks=blocks)
+
+    def energy(self, state) -> torch.Tensor:
+        if self.whitened:
+            return self.pls.basis.whitened_particle_energy(self.pls.cost, state)
+        return self.pls.particle_energy_potential(state)
+
+    def leave(self, state: torch.Tensor, particles: torch.Tensor) -> None:
+        """final state -> the caller's particle tensor"""
+        if self.whitened:
+            self.pls.basis.unwhiten(state, out=particles)
+        elif state.data_ptr() != particles.data_ptr():
+            particles.copy_(state)
+
+
 def _mean_energy(e: torch.Tensor) -> float:
     """Mean over the particles of the per-particle energies (orthonormal.py:126's .mean().item()): libplship's fixed-order
     reduction for device vectors, so that every loop variant (plain, pipelined, captured) reports identical values."""
@@ -88,14 +125,15 @@ def train_pls(
     if energy_reduce is None and particles.is_cuda:
         return _train_pls_two_in_flight(pls, particles, number_of_epochs, step_size, early_stopper, noises)
 
-    cur = particles
+    space = _LoopSpace(pls, noises)
+    cur = space.enter(particles)
     nxt = torch.empty_like(particles, memory_format=torch.contiguous_format)
     e_in = torch.empty(particles.shape[1], dtype=torch.float64, device=particles.device)
     stopped = False
     for t in range(number_of_epochs):
         rng_state = torch.get_rng_state()  # the speculative launch below may have to be un-drawn
         spec = NoiseSpec(injected=noises[t]) if noises is not None else None
-        pls.basis.fused_step(pls.cost, cur, float(step_size), out=nxt, new_state=True, noise=spec, input_energy=e_in)
+        space.step(cur, step_size, nxt, spec, e_in)
         if t >= 1:  # e_in = energy of `cur`, i.e. of the particles after update t-1 (trainers.py:158)
             energy_potential = reduce(e_in)
             if early_stopper.should_stop(loss=energy_potential, step_size=step_size):
@@ -105,11 +143,10 @@ def train_pls(
             energy_potentials.append(energy_potential)
         cur, nxt = nxt, cur
     if not stopped:  # energy after the last update
-        energy_potential = reduce(pls.particle_energy_potential(cur))
+        energy_potential = reduce(space.energy(cur))
         if not early_stopper.should_stop(loss=energy_potential, step_size=step_size):
             energy_potentials.append(energy_potential)
-    if cur.data_ptr() != particles.data_ptr():
-        particles.copy_(cur)
+    space.leave(cur, particles)
     return particles, energy_potentials
 
 
@@ -128,7 +165,8 @@ def _train_pls_two_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs
 
     T = number_of_epochs
     j = particles.shape[1]
-    bufs = [particles, torch.empty_like(particles, memory_format=torch.contiguous_format),
+    space = _LoopSpace(pls, noises)
+    bufs = [space.enter(particles), torch.empty_like(particles, memory_format=torch.contiguous_format),
             torch.empty_like(particles, memory_format=torch.contiguous_format)]
     e_dev = [torch.empty(j, dtype=torch.float64, device=particles.device) for _ in range(3)]
     # Gaussian/identity fast paths: the launch that finishes the energy by-product also leaves the 256-column chunk sums of
@@ -150,11 +188,9 @@ def _train_pls_two_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs
         spec = NoiseSpec(injected=noises[k]) if noises is not None else None
         if fused_sums:  # one column block = all particles, its step size from a device word, chunk sums to the host slot
             blocks = BlockSpec(j, eta_dev, energy_sums=host_ptr + 8 * nchunk * (k % 3))
-            pls.basis.fused_step(pls.cost, bufs[k % 3], float(step_size), out=bufs[(k + 1) % 3], new_state=True, noise=spec,
-                                 input_energy=e_dev[k % 3], blocks=blocks)
+            space.step(bufs[k % 3], step_size, bufs[(k + 1) % 3], spec, e_dev[k % 3], blocks=blocks)
         else:
-            pls.basis.fused_step(pls.cost, bufs[k % 3], float(step_size), out=bufs[(k + 1) % 3], new_state=True, noise=spec,
-                                 input_energy=e_dev[k % 3])
+            space.step(bufs[k % 3], step_size, bufs[(k + 1) % 3], spec, e_dev[k % 3])
             # E(U_k): the reduction kernel stores the mean straight into pinned host memory (mapped into the device's
             # address space); the host reads it after the event -- no torch reduce kernel, no copy kernel per iteration
             _ops.block_means(e_dev[k % 3], out_ptr=host_ptr + 8 * (k % 3))
@@ -175,7 +211,7 @@ def _train_pls_two_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs
             events[(t + 1) % 3].synchronize()
             energy_potential = read_energy((t + 1) % 3)
         else:  # the energy after the last update has no following launch to ride on
-            energy_potential = _mean_energy(pls.particle_energy_potential(bufs[T % 3]))
+            energy_potential = _mean_energy(space.energy(bufs[T % 3]))
         if early_stopper.should_stop(loss=energy_potential, step_size=step_size):
             if launched > t + 1:
                 torch.set_rng_state(rng_states[t + 1])
@@ -185,8 +221,7 @@ def _train_pls_two_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs
     if final is None:
         final = bufs[T % 3]
     torch.cuda.current_stream().synchronize()  # speculative launches still read / write the rotating buffers
-    if final.data_ptr() != particles.data_ptr():
-        particles.copy_(final)
+    space.leave(final, particles)
     return particles, energy_potentials
 
 

@@ -173,3 +173,43 @@ def test_whitened_philox_noise_is_coloured_by_kzz(P):
     finally:
         gb.whitened = True
     assert relerr(got, old) < 1e-10, "both routes draw the same xi"
+
+
+def test_train_pls_keeps_the_inducing_point_particles_whitened_between_steps(P):
+    """experiments/trainers.py:139-162 on the inducing-point basis with the Gaussian cost: the loop whitens once, steps S
+    (one contraction per iteration) and maps back once -- particles, every energy, the stop index and torch's RNG state
+    are those of the plain loop that calls the U -> U step and the energy every iteration."""
+    import numpy as np
+
+    from projected_langevin_sampling_amd import trainers
+
+    pr = make_problem(700, 64, 96, 2, seed=41 + FUZZ_SEED)
+    pr["ls"] = pr["ls"] * 0.4
+    ob, gb = build_ipb(P, pr)
+    _, gc = _gauss_pair(P, pr)
+    u0 = cu(pr["u"])
+    eta, steps = 2e-3, 40
+    for patience in (1e9, 6 * eta):
+        torch.manual_seed(3)
+        pls = P.pkg.PLS(gb, gc)
+        assert trainers._LoopSpace(pls, None).whitened
+        ua, ea = P.pkg.train_pls(pls, u0.clone(), steps, eta, patience)
+        state_a = torch.get_rng_state()
+        torch.manual_seed(3)
+        ub, eb, es = u0.clone(), [], trainers.EarlyStopper(patience=patience)
+        for _ in range(steps):
+            pls.step_(ub, eta)
+            e = pls.calculate_energy_potential(ub)
+            if es.should_stop(e, eta):
+                break
+            eb.append(e)
+        assert len(ea) == len(eb) and np.allclose(ea, eb, rtol=TOL, atol=0), (len(ea), len(eb))
+        assert relerr(ua, ub) < TOL
+        assert torch.equal(state_a, torch.get_rng_state())
+    # injected (coloured) noise keeps the loop in the original coordinates
+    noises = [cu(torch.randn(64, 96, generator=pr["gen"])) for _ in range(5)]
+    assert not trainers._LoopSpace(P.pkg.PLS(gb, gc), noises).whitened
+    oc, _ = _gauss_pair(P, pr)
+    uw, ew = O.train_pls(O.PLS(ob, oc), pr["u"].clone(), 5, eta, 1e9, noises=[n.cpu() for n in noises])
+    ug, eg = P.pkg.train_pls(P.pkg.PLS(gb, gc), u0.clone(), 5, eta, 1e9, noises=noises)
+    assert relerr(ug, uw) < 1e-8 and np.allclose(eg, ew, rtol=TOL)
