@@ -1188,6 +1188,17 @@ static std::atomic<int64_t> g_ipb_explicit_inverse{0};  // pls_set_option(PLS_OP
 static std::atomic<int64_t> g_solve_mode{1};  // pls_set_option(PLS_OPT_SOLVE_MODE): 0 block substitution, 1 inverse-factor products where available
 int64_t solve_mode() { return g_solve_mode.load(); }
 
+// Ranks [MIN, MAX] take small_rank2.h (pls_set_option(PLS_OPT_SMALL_RANK2_MIN / _MAX)).  Defaults from
+// profiles/r03_rank2_probe.txt (N = 1e5, J = 8192): the wave-pair kernel wins from ~170 functions (Gaussian +1 %, Poisson
+// +2 % at 176) to 240 (+8 / +9 %); below, the two-GEMM path's remainder tiles are cheaper than padding a half to 16; at
+// 241..256 the two-GEMM path runs its full 256-row configuration at 0.87-0.92 of peak.
+static std::atomic<int64_t> g_small_rank2_min{161}, g_small_rank2_max{240};
+
+static bool small_rank2_ok(const double *Lb, int64_t ldlb, int64_t kdim) {
+  return kdim > 128 && kdim <= 256 && kdim >= g_small_rank2_min.load() && kdim <= g_small_rank2_max.load() &&
+         (ldlb & 1) == 0 && (reinterpret_cast<uintptr_t>(Lb) & 15) == 0;
+}
+
 static bool small_rank_ok(const double *Lb, int64_t ldlb, int64_t kdim) {
   return kdim >= 1 && kdim <= g_small_rank_max.load() && (ldlb & 1) == 0 && (reinterpret_cast<uintptr_t>(Lb) & 15) == 0;
 }
@@ -1228,6 +1239,17 @@ static int stream_drift(const double *Lf, int64_t ldlf, const double *Lb, int64_
       SmallRankP p{Lb, ldlb, V, ldv, y, n, j, (int)kdim, rows_per_split, D, ldd, slab_stride, cp, es ? es->partial : nullptr, j};
       *slabs_used = ns;
       int rc = es ? launch_small_rank_drift_value(p, ns, st) : launch_small_rank_drift(p, ns, st);
+      if (rc || !es) return rc;
+      return reduce_partials(ns, 0, true);
+    }
+  }
+  if (small_rank2_ok(Lb, ldlb, kdim)) {  // 129 .. 256 basis functions: the same fusion with the rank split over wave pairs
+    int64_t rows_per_split = 0;
+    const int64_t ns = small_rank_splits(j, n, &rows_per_split);
+    if (ns <= max_slabs && (!es || ns <= es->rows_cap)) {
+      SmallRankP p{Lb, ldlb, V, ldv, y, n, j, (int)kdim, rows_per_split, D, ldd, slab_stride, cp, es ? es->partial : nullptr, j};
+      *slabs_used = ns;
+      int rc = es ? launch_small_rank2_drift_value(p, ns, st) : launch_small_rank2_drift(p, ns, st);
       if (rc || !es) return rc;
       return reduce_partials(ns, 0, true);
     }
@@ -1456,6 +1478,14 @@ int pls_set_option(int32_t option, int64_t value) {
       PLS_REQUIRE(value == 0 || value == 1, "set_option: ipb explicit inverse must be 0 or 1");
       g_ipb_explicit_inverse.store(value);
       return PLS_OK;
+    case PLS_OPT_SMALL_RANK2_MAX:
+      PLS_REQUIRE(value == 0 || (value >= 129 && value <= 256), "set_option: the wave-pair kernel's upper rank limit must be 0 or 129..256");
+      g_small_rank2_max.store(value);
+      return PLS_OK;
+    case PLS_OPT_SMALL_RANK2_MIN:
+      PLS_REQUIRE(value >= 129 && value <= 256, "set_option: the wave-pair kernel's lower rank limit must be 129..256");
+      g_small_rank2_min.store(value);
+      return PLS_OK;
     case PLS_OPT_SOLVE_MODE:
       PLS_REQUIRE(value == 0 || value == 1, "set_option: solve mode must be 0 or 1");
       g_solve_mode.store(value);
@@ -1484,6 +1514,8 @@ int64_t pls_get_option(int32_t option) {
   switch (option) {
     case PLS_OPT_SMALL_RANK_MAX: return g_small_rank_max.load();
     case PLS_OPT_IPB_EXPLICIT_INVERSE: return g_ipb_explicit_inverse.load();
+    case PLS_OPT_SMALL_RANK2_MAX: return g_small_rank2_max.load();
+    case PLS_OPT_SMALL_RANK2_MIN: return g_small_rank2_min.load();
     case PLS_OPT_SOLVE_MODE: return g_solve_mode.load();
     case PLS_OPT_KSPLIT_MODE: return g_ksplit_mode.load();
     case PLS_OPT_KSPLIT_MAX_TILES: return g_ksplit_max_tiles.load();
@@ -1753,7 +1785,7 @@ static bool onb_fast_path(const pls_onb_desc *b, const pls_cost_desc *c, int for
 static int64_t onb_max_slabs(int64_t mk, int64_t j, int64_t n) {
   int64_t kc;
   int64_t s = plan_split_k(mk, j, n, &kc);
-  if (mk <= 128) {  // the fused small-rank kernel cuts the rows into its own slabs (sized independently of the option)
+  if (mk <= 256) {  // the fused small-rank kernels cut the rows into their own slabs (sized independently of the options)
     int64_t rows;
     const int64_t sr = small_rank_splits(j, n, &rows);
     if (sr > s) s = sr;
