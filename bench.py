@@ -555,7 +555,10 @@ def main():
         # same launches measured 0.282 ms one second after it and 0.261-0.267 ms from a rested chip
         # (tools/fastpath_probe.py; the train_pls section further down, later in the same run: 0.267 ms)
         settle(4.0)
-        dtf, tlf = run(force_generic=False, steps=fsteps, warmup=max(args.warmup, 5), timeline=True)
+        # two passes: per-launch HIP events (two hipEventRecord per launch: ~6 us of bubbles per step, nothing at 45 ms per
+        # step, a tenth of a 50 us step on an 8-GPU shard) for the kernel's own duration, then the timed region without them
+        _, tlf = run(force_generic=False, steps=fsteps, warmup=max(args.warmup, 5), timeline=True)
+        dtf, _ = run(force_generic=False, steps=fsteps, warmup=2, timeline=False)
         log(f"gaussian fast path: {dtf / fsteps * 1e3:.3f} ms/step")
         k = tlf.get("gemm_langevin_gaussian", {"total_ms": 0.0, "launches": 0, "avg_ms": 0.0})
         fl = 2.0 * m * m * j_loc
