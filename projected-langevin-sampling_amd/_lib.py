@@ -212,6 +212,7 @@ OPT_KSPLIT_MAX_TILES = 4
 OPT_SOLVE_MODE = 5
 OPT_SMALL_RANK2_MAX = 6
 OPT_SMALL_RANK2_MIN = 7
+OPT_ROW_BLOCKS = 8
 TAG_NAMES = {1: "gemm_store", 2: "gemm_cost_deriv", 3: "gemm_cost_value", 4: "gemm_langevin_gaussian",
              5: "langevin_update", 6: "kernel_gram", 7: "other", 8: "small_rank_drift", 9: "small_rank_value",
              10: "tri_solve"}

@@ -97,9 +97,13 @@ struct AccFrag {
 //         Overhanging lanes then deposit real (finite or not) matrix data of other columns: harmless, because output
 //         (i, j) only ever combines column i of L with column j of R and the epilogue drops i >= I, j >= J.  The K tail
 //         (rows that must read as zero) always goes through registers.
-template <int BI, int BJ, int WI, int WJ, int BK, bool VEC, bool EDGE, bool DMA, int TI, int TJ>
+//   TIU / AST / a_off: the wave contracts its first TIU (<= TI) row blocks, AST columns of the L tile apart, starting at
+//         column a_off of the tile (the usual wave block: TIU = TI, AST = 16, a_off = the wave's row offset; the
+//         row-interleaved tiles of gemm_tn_f64_rows.h: AST = 32, a_off = 16 * wave row, TIU = the blocks that hold rows)
+template <int BI, int BJ, int WI, int WJ, int BK, bool VEC, bool EDGE, bool DMA, int TIU, int AST, int TI, int TJ>
 __device__ __forceinline__ void gemm_tn_mainloop(const GemmShape &g, int64_t i0, int64_t j0, double *lds,
-                                                 AccFrag<TI, TJ> &acc) {
+                                                 AccFrag<TI, TJ> &acc, int a_off) {
+  static_assert(TIU >= 1 && TIU <= TI && (AST == 16 || AST == 32), "row blocks of the wave");
   constexpr int NW = (BI / WI) * (BJ / WJ);
   constexpr int NT = NW * 64;
   constexpr int PAD = 16;
@@ -115,7 +119,7 @@ __device__ __forceinline__ void gemm_tn_mainloop(const GemmShape &g, int64_t i0,
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wi = (wave / (BJ / WJ)) * WI, wj = (wave % (BJ / WJ)) * WJ;
+  const int wi = a_off, wj = (wave % (BJ / WJ)) * WJ;
   const int q = lane >> 4, c16 = lane & 15;
 
   const int lcol = (tid % (BI / 2)) * 2, lrow = tid / (BI / 2);
@@ -229,9 +233,9 @@ __device__ __forceinline__ void gemm_tn_mainloop(const GemmShape &g, int64_t i0,
   auto compute = [&](int buf, int nq = BK / 4) {
     const double *l = Ls + buf * BK * SL + q * SL + wi + c16;
     const double *r = Rs + buf * BK * SR + q * SR + wj + c16;
-    double a[2][TI], b[2][TJ];
+    double a[2][TIU], b[2][TJ];
 #pragma unroll
-    for (int t = 0; t < TI; ++t) a[0][t] = l[t * 16];
+    for (int t = 0; t < TIU; ++t) a[0][t] = l[t * AST];
 #pragma unroll
     for (int t = 0; t < TJ; ++t) b[0][t] = r[t * 16];
 #pragma unroll
@@ -240,7 +244,7 @@ __device__ __forceinline__ void gemm_tn_mainloop(const GemmShape &g, int64_t i0,
       const int cur = kq & 1, nxt = cur ^ 1;
       if (kq + 1 < BK / 4) {
 #pragma unroll
-        for (int t = 0; t < TI; ++t) a[nxt][t] = l[(kq + 1) * 4 * SL + t * 16];
+        for (int t = 0; t < TIU; ++t) a[nxt][t] = l[(kq + 1) * 4 * SL + t * AST];
 #pragma unroll
         for (int t = 0; t < TJ; ++t) b[nxt][t] = r[(kq + 1) * 4 * SR + t * 16];
       }
@@ -251,7 +255,7 @@ __device__ __forceinline__ void gemm_tn_mainloop(const GemmShape &g, int64_t i0,
       __builtin_amdgcn_sched_barrier(0);
 #endif
 #pragma unroll
-      for (int ta = 0; ta < TI; ++ta)
+      for (int ta = 0; ta < TIU; ++ta)
 #pragma unroll
         for (int tb = 0; tb < TJ; ++tb)
           acc.v[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][ta], b[cur][tb], acc.v[ta][tb], 0, 0, 0);
@@ -289,24 +293,24 @@ __device__ __forceinline__ void gemm_tn_mainloop(const GemmShape &g, int64_t i0,
     // (Issuing the DMA of step k+2 right after the barrier of step k -- a full step of latency budget instead of
     // three quarters -- measured 3% SLOWER, tools/ab_gemm.py: the eight DMA issues delay the fragment fetch the last
     // quad's MFMAs wait for.)
-    auto read_frag = [&](int buf, int kq, double (&a)[TI], double (&b)[TJ]) {
+    auto read_frag = [&](int buf, int kq, double (&a)[TIU], double (&b)[TJ]) {
       const double *l = Ls + buf * BK * SL + (kq * 4 + q) * SL + wi + c16;
       const double *r = Rs + buf * BK * SR + (kq * 4 + q) * SR + wj + c16;
 #pragma unroll
-      for (int t = 0; t < TI; ++t) a[t] = l[t * 16];
+      for (int t = 0; t < TIU; ++t) a[t] = l[t * AST];
 #pragma unroll
       for (int t = 0; t < TJ; ++t) b[t] = r[t * 16];
     };
-    auto mfma_block = [&](const double (&a)[TI], const double (&b)[TJ]) {
+    auto mfma_block = [&](const double (&a)[TIU], const double (&b)[TJ]) {
 #pragma unroll
-      for (int ta = 0; ta < TI; ++ta)
+      for (int ta = 0; ta < TIU; ++ta)
 #pragma unroll
         for (int tb = 0; tb < TJ; ++tb)
           acc.v[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ta], b[tb], acc.v[ta][tb], 0, 0, 0);
     };
     static_assert(BK == 16, "the rotated loop is written for 4 k-quads per step");
     if (nk_full > 1) {
-      double fa[TI], fb[TJ], ga[TI], gb[TJ];
+      double fa[TIU], fb[TJ], ga[TIU], gb[TJ];
       read_frag(0, 0, fa, fb);
       // first = true: the very first 16 MFMAs of the tile take a literal zero as their C operand instead of reading
       // zero-initialised accumulators (64 v_mov per wave that would each queue behind a 64-cycle MFMA of the
@@ -318,7 +322,7 @@ __device__ __forceinline__ void gemm_tn_mainloop(const GemmShape &g, int64_t i0,
         read_frag(buf, 1, ga, gb);
         if constexpr (first) {
 #pragma unroll
-          for (int ta = 0; ta < TI; ++ta)
+          for (int ta = 0; ta < TIU; ++ta)
 #pragma unroll
             for (int tb = 0; tb < TJ; ++tb)
               acc.v[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ta], fb[tb], double4_t{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
@@ -417,6 +421,7 @@ __device__ __forceinline__ void gemm_tile(GemmShape g, const Epilogue &epi, int 
 #pragma unroll
     for (int b = 0; b < TJ; ++b) acc.v[a][b] = double4_t{0.0, 0.0, 0.0, 0.0};
 
+  const int wi0 = (int)(threadIdx.x >> 6) / (BJ / WJ) * WI;  // the wave's first row inside the tile
   // vector path: every row start is 16-B aligned; a pair that straddles the I/J edge stays inside its row's
   // padding because the leading dimension is even
   const bool vec = ((g.ldl & 1) == 0) && ((reinterpret_cast<uintptr_t>(g.L) & 15) == 0) && ((g.ldr & 1) == 0) &&
@@ -425,11 +430,11 @@ __device__ __forceinline__ void gemm_tile(GemmShape g, const Epilogue &epi, int 
   constexpr bool kDma = (BI == 128 && BJ == 128);
   if (vec) {
     if (!edge)
-      gemm_tn_mainloop<BI, BJ, WI, WJ, BK, true, false, kDma>(g, i0, j0, lds, acc);
+      gemm_tn_mainloop<BI, BJ, WI, WJ, BK, true, false, kDma, TI, 16>(g, i0, j0, lds, acc, wi0);
     else
-      gemm_tn_mainloop<BI, BJ, WI, WJ, BK, true, true, kDma>(g, i0, j0, lds, acc);
+      gemm_tn_mainloop<BI, BJ, WI, WJ, BK, true, true, kDma, TI, 16>(g, i0, j0, lds, acc, wi0);
   } else {
-    gemm_tn_mainloop<BI, BJ, WI, WJ, BK, false, true, false>(g, i0, j0, lds, acc);
+    gemm_tn_mainloop<BI, BJ, WI, WJ, BK, false, true, false, TI, 16>(g, i0, j0, lds, acc, wi0);
   }
 
   PLS_STAMP_AT(2);

@@ -19,6 +19,7 @@
 #include "gemm_tn_f64.h"
 #include "gemm_launch.h"
 #include "gemm_tn_f64_kg.h"
+#include "gemm_tn_f64_rows.h"
 #include "cost_epilogues.h"
 #include "philox.h"
 #include "small_rank.h"
@@ -449,6 +450,42 @@ static int launch_gemm_any(const double *L, int64_t ldl, const double *R, int64_
     return cfg == CFG_KG2 ? launch_gemm_kg<2>(g, epi, st) : launch_gemm_kg<1>(g, epi, st);
   }
   return launch_gemm(L, ldl, R, ldr, I, J, K, epi, st, kchunk, tri);
+}
+
+// ---- a row count that is not a multiple of 128: equal-height tiles, 16-row blocks dealt to the wave rows (gemm_tn_f64_rows.h) ----
+static std::atomic<int64_t> g_row_blocks_mode{1};  // pls_set_option(PLS_OPT_ROW_BLOCKS): 0 off (the round-2 pieces), 1 on
+
+static bool gemm_rows_ok(const double *L, int64_t ldl, const double *R, int64_t ldr, int64_t I, int64_t J, int64_t K, int64_t ldc,
+                         int64_t nsplit) {
+  const bool aligned = ((ldl | ldr) & 1) == 0 && ((reinterpret_cast<uintptr_t>(L) | reinterpret_cast<uintptr_t>(R)) & 15) == 0;
+  if (!(g_row_blocks_mode.load() != 0 && I > 128 && I % 128 != 0 && J >= 1 && K >= 1 && aligned && ldc >= 128 &&
+        ldc < kDirectMaxLd && use_big_tiles(I, J, nsplit)))
+    return false;
+  // every tile contracts cdiv(blocks, tiles) blocks: above two tiles that may pad more than the remainder launches cost
+  // (400 rows = 25 blocks run as 4 x 7: 9.8 ms against 9.5 ms for 384 + 16 rows, N = 1e5, J = 8192)
+  const int64_t blocks = cdiv(I, 16), tiles = cdiv(I, 128);
+  return tiles == 2 || tiles * cdiv(blocks, tiles) - blocks <= 1;
+}
+
+static int launch_gemm_rows(const double *L, int64_t ldl, const double *R, int64_t ldr, int64_t I, int64_t J, int64_t K,
+                            const EpiStore &e, hipStream_t st, int64_t kchunk) {
+  GemmShape g{L, ldl, R, ldr, I, J, K, 0, 0, kchunk, 0};
+  constexpr size_t lds_bytes = (size_t)2 * 16 * ((128 + 16) + (128 + 16)) * sizeof(double);
+  static std::atomic<uint64_t> lds_ready{0};
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(gemm_tn_f64_rows_kernel), lds_bytes, lds_ready)) return rc;
+  g.nti = (int)cdiv(I, 128);
+  g.ntj = (int)cdiv(J, 128);
+  const int tile_rows = 16 * (int)cdiv(cdiv(I, 16), g.nti);  // equal heights: 160 rows are 80 + 80, 129 are 80 + 49
+  const int64_t nwg = (int64_t)g.nti * g.ntj;
+  if (nwg > 0x7fffffff) return fail(PLS_ERR_INVALID_ARGUMENT, "gemm: too many tiles");
+  unsigned nsplit = 1;
+  if (kchunk > 0 && kchunk < K) nsplit = (unsigned)cdiv(K, kchunk);
+  RowsStore rs{e.C0, e.ldc, e.alpha, e.beta, e.slab};
+  {
+    LaunchScope scope(EpiStore::kTag, st);
+    hipLaunchKernelGGL(gemm_tn_f64_rows_kernel, dim3((unsigned)nwg, nsplit), dim3(256), lds_bytes, st, g, tile_rows, rs);
+  }
+  return check_launch("gemm_tn_f64_rows");
 }
 
 // cost-value GEMM (tile geometry is part of the epilogue type); returns the number of partial rows written
@@ -1188,11 +1225,12 @@ static std::atomic<int64_t> g_ipb_explicit_inverse{0};  // pls_set_option(PLS_OP
 static std::atomic<int64_t> g_solve_mode{1};  // pls_set_option(PLS_OPT_SOLVE_MODE): 0 block substitution, 1 inverse-factor products where available
 int64_t solve_mode() { return g_solve_mode.load(); }
 
-// Ranks [MIN, MAX] take small_rank2.h (pls_set_option(PLS_OPT_SMALL_RANK2_MIN / _MAX)).  Defaults from
-// profiles/r03_rank2_probe.txt (N = 1e5, J = 8192): the wave-pair kernel wins from ~170 functions (Gaussian +1 %, Poisson
-// +2 % at 176) to 240 (+8 / +9 %); below, the two-GEMM path's remainder tiles are cheaper than padding a half to 16; at
-// 241..256 the two-GEMM path runs its full 256-row configuration at 0.87-0.92 of peak.
-static std::atomic<int64_t> g_small_rank2_min{161}, g_small_rank2_max{240};
+// Ranks [MIN, MAX] take small_rank2.h (pls_set_option(PLS_OPT_SMALL_RANK2_MIN / _MAX)); MAX = 0 (the default): none.
+// profiles/r03_rank2_probe.txt (N = 1e5, J = 8192): against the round-2 two-GEMM path the wave-pair kernel won from ~170
+// functions (Gaussian +1 %, Poisson +2 % at 176) to 240 (+8 / +9 %).  With the back-projection in row blocks
+// (gemm_tn_f64_rows.h) the two-GEMM path is ahead at every rank 129 .. 256 (profiles/r03_step_sweep_ranks.txt: by
+// 6 .. 14 %), so the fused kernel is kept as an option (no N x J workspace for G) and is no longer a default.
+static std::atomic<int64_t> g_small_rank2_min{161}, g_small_rank2_max{0};
 
 static bool small_rank2_ok(const double *Lb, int64_t ldlb, int64_t kdim) {
   return kdim > 128 && kdim <= 256 && kdim >= g_small_rank2_min.load() && kdim <= g_small_rank2_max.load() &&
@@ -1285,7 +1323,10 @@ static int stream_drift(const double *Lf, int64_t ldlf, const double *Lb, int64_
     EpiStore e2{D, ldd, 1.0, c == 0 ? 0.0 : 1.0, slab_stride};
     const int64_t kc2 = nslab > 1 ? kchunk : 0;
     const int64_t main_rows = kdim / 128 * 128, rem_rows = kdim - main_rows;
-    if (main_rows > 0 && rem_rows > 0 && rem_rows <= 112 && use_big_tiles(kdim, j, nslab)) {
+    if (gemm_rows_ok(Lb + r0 * ldlb, ldlb, Gbuf, j, kdim, j, rows, ldd, nslab)) {
+      // a rank that is not a multiple of 128 in ONE launch whose MFMA count follows cdiv(kdim, 16)
+      rc = launch_gemm_rows(Lb + r0 * ldlb, ldlb, Gbuf, j, kdim, j, rows, e2, st, kc2);
+    } else if (main_rows > 0 && rem_rows > 0 && rem_rows <= 112 && use_big_tiles(kdim, j, nslab)) {
       // a rank that is not a multiple of 128 (129: one more 128-row tile would compute 256 rows for 129): the full
       // 128-row tiles with the big configuration, the remainder in pieces of 64, 32 and 16 rows (at most 15 idle rows)
       rc = launch_gemm(Lb + r0 * ldlb, ldlb, Gbuf, j, main_rows, j, rows, e2, st, kc2);
@@ -1498,6 +1539,10 @@ int pls_set_option(int32_t option, int64_t value) {
       PLS_REQUIRE(value >= 0, "set_option: k-split tile limit must be >= 0");
       g_ksplit_max_tiles.store(value);
       return PLS_OK;
+    case PLS_OPT_ROW_BLOCKS:
+      PLS_REQUIRE(value == 0 || value == 1, "set_option: row-block mode must be 0 or 1");
+      g_row_blocks_mode.store(value);
+      return PLS_OK;
     default: return fail(PLS_ERR_INVALID_ARGUMENT, "set_option: unknown option %d", (int)option);
   }
 }
@@ -1519,6 +1564,7 @@ int64_t pls_get_option(int32_t option) {
     case PLS_OPT_SOLVE_MODE: return g_solve_mode.load();
     case PLS_OPT_KSPLIT_MODE: return g_ksplit_mode.load();
     case PLS_OPT_KSPLIT_MAX_TILES: return g_ksplit_max_tiles.load();
+    case PLS_OPT_ROW_BLOCKS: return g_row_blocks_mode.load();
     default: return -1;
   }
 }

@@ -719,9 +719,9 @@ def test_captured_training_matches_the_eager_loop(P, cost_idx, epochs, k, patien
 
 @pytest.mark.parametrize("mk", [129, 144, 150, 165, 192, 200, 224, 241, 257, 300])
 def test_ranks_just_above_a_tile_multiple(P, mk):
-    """Ranks a little above a multiple of 128 take the back-projection as full 128-row tiles plus a 64-row-tile
-    remainder launch (129 rows would otherwise compute as 256).  Step and energy by-product against plain torch fp64
-    on the host, with the row slabs of the split-K plan in play (N = 40000)."""
+    """Ranks a little above a multiple of 128 take the back-projection in row blocks (csrc/gemm_tn_f64_rows.h: 129 rows
+    would otherwise compute as 256; J = 2200 leaves a ragged last column tile).  Step and energy by-product against
+    plain torch fp64 on the host, with the row slabs of the split-K plan in play (N = 40000)."""
     gen = torch.Generator().manual_seed(500 + mk)
     n, j, eta, s2 = 40000, 2200, 1e-3, 0.4
     a = torch.randn(mk, n, generator=gen, dtype=torch.float64) / mk ** 0.5

@@ -23,7 +23,7 @@ class rank2:
     def __enter__(self):
         L, lib = self.L, self.lib
         self.prev = (lib.pls_get_option(L.OPT_SMALL_RANK2_MIN), lib.pls_get_option(L.OPT_SMALL_RANK2_MAX))
-        assert self.prev == (161, 240), self.prev
+        assert self.prev == (161, 0), self.prev  # (off by default since the row-block back-projection)
         L.check(lib.pls_set_option(L.OPT_SMALL_RANK2_MIN, 129))
         L.check(lib.pls_set_option(L.OPT_SMALL_RANK2_MAX, self.limit))
 

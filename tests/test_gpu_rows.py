@@ -1,0 +1,125 @@
+"""GPU: the back-projection D = A G for a rank that is not a multiple of the 128-row tile (csrc/gemm_tn_f64_rows.h).
+
+Every eigenvalue threshold leaves such a rank (orthonormal.py:51-60); the launch cuts the rank into equal-height tiles
+and deals their 16-row blocks to the wave rows, so the MFMA count follows cdiv(M_k, 16) and G is read once.  The step
+(orthonormal.py:128-159) is held to plain torch fp64 on the host and to the round-2 launch sequence (128-row tiles plus
+remainder pieces) it replaces; padding rows of the projection are poisoned, so a store or a contraction that strays
+over the tile's last row shows.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from test_gpu_ksplit import P, _f64_default  # noqa: F401  (fixtures)
+from test_gpu_parity import cu, relerr
+
+
+class row_blocks:
+    """with row_blocks(P, 0 | 1): PLS_OPT_ROW_BLOCKS for the block, restored after"""
+
+    def __init__(self, P, mode):
+        self.L, self.lib, self.mode = P.pkg._lib, P.pkg._lib.load(), mode
+
+    def __enter__(self):
+        self.prev = self.lib.pls_get_option(self.L.OPT_ROW_BLOCKS)
+        self.L.check(self.lib.pls_set_option(self.L.OPT_ROW_BLOCKS, self.mode))
+
+    def __exit__(self, *exc):
+        self.L.check(self.lib.pls_set_option(self.L.OPT_ROW_BLOCKS, self.prev))
+        return False
+
+
+class two_gemm_path:
+    """with two_gemm_path(P): the wave-pair fused kernel (small_rank2.h) off, so ranks 129 .. 256 take the two-GEMM path"""
+
+    def __init__(self, P):
+        self.L, self.lib = P.pkg._lib, P.pkg._lib.load()
+
+    def __enter__(self):
+        self.prev = self.lib.pls_get_option(self.L.OPT_SMALL_RANK2_MAX)
+        self.L.check(self.lib.pls_set_option(self.L.OPT_SMALL_RANK2_MAX, 0))
+
+    def __exit__(self, *exc):
+        self.L.check(self.lib.pls_set_option(self.L.OPT_SMALL_RANK2_MAX, self.prev))
+        return False
+
+
+def _problem(mk, n, j, seed):
+    gen = torch.Generator().manual_seed(seed)
+    a = torch.randn(mk, n, generator=gen) / mk ** 0.5
+    lam = torch.rand(mk, generator=gen) + 0.5
+    u = torch.randn(mk, j, generator=gen)
+    xi = torch.randn(mk, j, generator=gen)
+    y = torch.randn(n, generator=gen)
+    return a, lam, u, xi, y
+
+
+# 129: 80 + 49 rows (blocks 3|2 and 2|2); 144, 160: equal tiles; 150: a partly filled last block; 255 / 257 / 300 / 383:
+# either side of two and three tiles; 1000: the rank a threshold leaves of 1024 inducing points (8 tiles, last one 7 blocks)
+@pytest.mark.parametrize("mk", [129, 144, 150, 160, 176, 192, 200, 224, 241, 255, 257, 300, 383, 1000])
+def test_step_through_the_row_block_launch(P, mk):
+    n, j, eta, s2 = (40000, 2048, 1e-3, 0.4) if mk < 400 else (12000, 1024, 1e-3, 0.4)
+    a, lam, u, xi, y = _problem(mk, n, j, 900 + mk)
+    basis = P.basis.OrthonormalBasis.from_projection(cu(a), cu(lam), poison_padding=True)
+    gc = P.costs.GaussianCost(s2, y, P.links.IdentityLinkFunction())
+    e_in = torch.empty(j, device="cuda")
+    with two_gemm_path(P):
+        with row_blocks(P, 1):
+            got = basis.fused_step(gc, cu(u), eta, noise=P.basis.NoiseSpec(injected=cu(xi)), force_generic=True, input_energy=e_in)
+        with row_blocks(P, 0):
+            old = basis.fused_step(gc, cu(u), eta, noise=P.basis.NoiseSpec(injected=cu(xi)), force_generic=True)
+    f = a.T @ u
+    want = -eta * (a @ ((f - y[:, None]) / s2)) - eta * u / lam[:, None] + math.sqrt(2 * eta) * xi
+    assert torch.isfinite(got).all()
+    assert relerr(got, want) < 1e-11
+    assert relerr(got, old) < 1e-12
+    e_want = ((f - y[:, None]) ** 2).sum(0) / (2 * s2) + 0.5 * (u * u / lam[:, None]).sum(0)
+    assert relerr(e_in, e_want) < 1e-11
+
+
+@pytest.mark.parametrize("mk,j", [(129, 2200), (176, 1999), (208, 2049), (250, 1153), (1000, 1100)])
+def test_row_block_launch_with_a_ragged_last_column_tile(P, mk, j):
+    """J off the 128-column grid (odd J: the last pair of a k-row straddles the edge): lanes beyond J store nothing"""
+    n, eta, s2 = (40000, 1e-3, 0.4) if mk < 400 else (12000, 1e-3, 0.4)
+    a, lam, u, xi, y = _problem(mk, n, j, 1300 + mk)
+    basis = P.basis.OrthonormalBasis.from_projection(cu(a), cu(lam), poison_padding=True)
+    gc = P.costs.GaussianCost(s2, y, P.links.IdentityLinkFunction())
+    e_in = torch.empty(j, device="cuda")
+    with two_gemm_path(P):
+        with row_blocks(P, 1):
+            got = basis.fused_step(gc, cu(u), eta, noise=P.basis.NoiseSpec(injected=cu(xi)), force_generic=True, input_energy=e_in)
+        with row_blocks(P, 0):
+            old = basis.fused_step(gc, cu(u), eta, noise=P.basis.NoiseSpec(injected=cu(xi)), force_generic=True)
+    f = a.T @ u
+    want = -eta * (a @ ((f - y[:, None]) / s2)) - eta * u / lam[:, None] + math.sqrt(2 * eta) * xi
+    assert relerr(got, want) < 1e-11
+    assert relerr(got, old) < 1e-12
+    e_want = ((f - y[:, None]) ** 2).sum(0) / (2 * s2) + 0.5 * (u * u / lam[:, None]).sum(0)
+    assert relerr(e_in, e_want) < 1e-11
+
+
+@pytest.mark.parametrize("mk", [129, 200, 300])
+def test_row_block_launch_with_the_rows_streamed_in_chunks(P, mk):
+    """a workspace for a third of the rows: the launch accumulates onto the slabs of the previous chunk (beta = 1)"""
+    n, j, eta = 30000, 1024, 2e-3
+    a, lam, u, xi, y = _problem(mk, n, j, 1700 + mk)
+    basis = P.basis.OrthonormalBasis.from_projection(cu(a), cu(lam), poison_padding=True)
+    lib = P.pkg._lib.load()
+    basis.workspace_bytes = lib.pls_onb_step_workspace_bytes(basis._desc(), j, n // 3)
+    fstar = (a.T @ u)[:, 0]
+    gc = P.costs.BernoulliCost((fstar > 0).double(), P.links.SigmoidLinkFunction())
+    with two_gemm_path(P):
+        with row_blocks(P, 1):
+            got = basis.fused_step(gc, cu(u), eta, noise=P.basis.NoiseSpec(injected=cu(xi)), force_generic=True)
+        with row_blocks(P, 0):
+            old = basis.fused_step(gc, cu(u), eta, noise=P.basis.NoiseSpec(injected=cu(xi)), force_generic=True)
+    f = a.T @ u
+    p = torch.sigmoid(f).clamp(1e-10, 1 - 1e-10)
+    yy = (fstar > 0).double()[:, None]
+    g = -yy * (1 - p) + (1 - yy) * p
+    want = -eta * (a @ g) - eta * u / lam[:, None] + math.sqrt(2 * eta) * xi
+    assert relerr(got, want) < 1e-10
+    assert relerr(got, old) < 1e-12

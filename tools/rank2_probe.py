@@ -1,5 +1,7 @@
-"""Like-for-like step for 129 .. 256 basis functions: the wave-pair fused kernel (csrc/small_rank2.h) against the two-GEMM
-path (pls_set_option(PLS_OPT_SMALL_RANK2_MAX, 0)), N = 1e5 (and 2e4), J = 8192, Gaussian and Poisson costs."""
+"""Like-for-like step for ranks that are not a multiple of 128 (129 .. 256, 300, 1000), N = 1e5, J = 8192, Gaussian and
+Poisson costs: the two-GEMM path with the back-projection as 128-row tiles + remainder launches (round 2), the same with
+the back-projection in row blocks (csrc/gemm_tn_f64_rows.h, the default), and the wave-pair fused kernel
+(csrc/small_rank2.h, pls_set_option(PLS_OPT_SMALL_RANK2_MAX, 256)).  -> profiles/r03_step_sweep_ranks.txt"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import projected_langevin_sampling_amd as P
@@ -23,9 +25,10 @@ def timeit(f, reps=5, warm=2):
 
 
 ns = [int(a) for a in sys.argv[1].split(",")] if len(sys.argv) > 1 else [100000]
-print(f"{'N':>8s} {'M_k':>5s}  {'cost':8s} {'two-GEMM ms':>12s} {'frac':>6s} {'fused ms':>9s} {'frac':>6s}  {'fused+energy ms':>15s}")
+print(f"{'N':>8s} {'M_k':>5s}  {'cost':8s} {'pieces ms':>10s} {'frac':>6s} {'row blocks ms':>13s} {'frac':>6s} {'fused ms':>9s} {'frac':>6s}  {'fused+energy ms':>15s}"
+      "     (pieces: two-GEMM path, 128-row tiles + remainder launches; row blocks: two-GEMM path, gemm_tn_f64_rows.h; fused: small_rank2.h)")
 for n in ns:
-    for mk in (129, 144, 160, 176, 192, 208, 224, 240, 256):
+    for mk in (129, 144, 160, 176, 192, 208, 224, 240, 256, 300, 1000):
         j = 8192
         a = torch.randn(mk, n, dtype=torch.float64, device="cuda") / mk ** 0.5
         lam = torch.rand(mk, dtype=torch.float64, device="cuda") + 0.5
@@ -39,14 +42,19 @@ for n in ns:
             f = lambda: basis.fused_step(cost, u, 1e-9, out=out, new_state=True, noise=NoiseSpec(none=True), force_generic=True)
             fe = lambda: basis.fused_step(cost, u, 1e-9, out=out, new_state=True, noise=NoiseSpec(none=True), force_generic=True, input_energy=en)
             res = {}
-            for name, limit in (("gemm", 0), ("fused", 256)):
+            for name, limit, rows in (("gemm", 0, 0), ("rows", 0, 1), ("fused", 256, 1)):
+                if name == "fused" and mk > 256:
+                    res["fused"] = res["fused_e"] = float("nan")
+                    continue
                 L.check(lib.pls_set_option(L.OPT_SMALL_RANK2_MAX, limit))
+                L.check(lib.pls_set_option(L.OPT_ROW_BLOCKS, rows))
                 basis._ws.clear()
                 res[name] = timeit(f)
                 if name == "fused":
                     res["fused_e"] = timeit(fe)
             fl = 4.0 * n * mk * j
-            print(f"{n:8d} {mk:5d}  {cname:8s} {res['gemm']:12.3f} {fl / res['gemm'] / 78.6e9:6.3f} {res['fused']:9.3f} {fl / res['fused'] / 78.6e9:6.3f}  {res['fused_e']:15.3f}", flush=True)
+            print(f"{n:8d} {mk:5d}  {cname:8s} {res['gemm']:10.3f} {fl / res['gemm'] / 78.6e9:6.3f} {res['rows']:13.3f} {fl / res['rows'] / 78.6e9:6.3f} "
+                  f"{res['fused']:9.3f} {fl / res['fused'] / 78.6e9:6.3f}  {res['fused_e']:15.3f}", flush=True)
         del a, basis, u, out
-L.check(lib.pls_set_option(L.OPT_SMALL_RANK2_MAX, 240))
+L.check(lib.pls_set_option(L.OPT_SMALL_RANK2_MAX, 0))
 L.check(lib.pls_set_option(L.OPT_SMALL_RANK2_MIN, 161))
