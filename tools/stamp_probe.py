@@ -2,7 +2,7 @@
 four s_memtime stamps per workgroup: start, after the prologue barrier, after the k-loop, after the epilogue, plus
 HW_ID / XCC_ID so the per-CU timeline (residency, launch gaps, tail) can be rebuilt).
 Build:  (cd projected-langevin-sampling_amd/csrc && hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DPLS_STAMP -shared \
-         -o ../../tools/libplship_stamp.so plship.hip gemm_cost.hip gemm_cost_value.hip small_rank_drift.hip small_rank_value.hip small_rank_drift_value.hip)
+         -o ../../tools/libplship_stamp.so plship.hip gemm_cost.hip gemm_cost_value.hip small_rank_drift.hip small_rank_value.hip small_rank_drift_value.hip small_rank2_drift.hip small_rank2_drift_value.hip chol.hip)
 Read the SHARES, not the lengths: the stamps serialise what the real kernel overlaps."""
 import ctypes as C, os, sys, torch
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -10,7 +10,8 @@ lib = C.CDLL(os.path.join(HERE, "libplship_stamp.so"))
 lib.pls_gemm_tn.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_void_p]
 lib.pls_debug_set_stamp_buffer.argtypes = [C.c_void_p]
 dev = "cuda"
-for (I, J, K) in [(100000, 8192, 1024), (1024, 8192, 14288)]:
+shapes = [tuple(int(v) for v in a.split(',')) for a in sys.argv[1:]] or [(100000, 8192, 1024), (1024, 8192, 14288)]
+for (I, J, K) in shapes:
     Lm = torch.randn(K, I, dtype=torch.float64, device=dev); Rm = torch.randn(K, J, dtype=torch.float64, device=dev)
     Cm = torch.empty(I, J, dtype=torch.float64, device=dev)
     ntiles = ((I + 127) // 128) * ((J + 127) // 128)
@@ -63,4 +64,5 @@ for (I, J, K) in [(100000, 8192, 1024), (1024, 8192, 14288)]:
     print(f"   CU finish time: min {ends.min():.3e} median {np.median(ends):.3e} max {ends.max():.3e} (span {span:.3e})")
     tot_t = ncu * ends.max()
     print(f"   CU-time shares up to the last finish: 2 WGs {res2 / tot_t:.3f}  1 WG {res1 / tot_t:.3f}  0 WG before own end {res0 / tot_t:.3f}  idle after own end {1 - (res0 + res1 + res2) / tot_t:.3f}")
+    if len(gaps) == 0: continue
     print(f"   end->next start gap on the same CU: median {np.median(gaps):.0f} p90 {np.quantile(gaps, 0.9):.0f} mean {gaps.mean():.0f} ticks")
