@@ -22,6 +22,14 @@ static int launch_gemm_cfg(GemmShape g, const Epi &epi, hipStream_t st) {
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds_bytes, lds_ready)) return rc;
 #ifdef PLS_STAMP
   g.stamps = g_stamp_buffer;
+  // diagnostic build only: PLS_STAMP_LDS_PAD=<bytes> of extra dynamic LDS (e.g. 90000: one workgroup per CU)
+  static const size_t pad = getenv("PLS_STAMP_LDS_PAD") ? (size_t)atol(getenv("PLS_STAMP_LDS_PAD")) : 0;
+  static std::atomic<uint64_t> pad_ready{0};
+  if (pad)
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds_bytes + pad, pad_ready)) return rc;
+  const size_t lds_launch = lds_bytes + pad;
+#else
+  const size_t lds_launch = lds_bytes;
 #endif
   g.nti = (int)cdiv(g.I, BI);
   g.ntj = (int)cdiv(g.J, BJ);
@@ -33,7 +41,7 @@ static int launch_gemm_cfg(GemmShape g, const Epi &epi, hipStream_t st) {
   if (g.kchunk > 0 && g.kchunk < g.K) nsplit = (unsigned)cdiv(g.K, g.kchunk);
   {
     LaunchScope scope(Epi::kTag, st);
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg, nsplit), dim3(NT), lds_bytes, st, g, epi);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg, nsplit), dim3(NT), lds_launch, st, g, epi);
   }
   return check_launch("gemm_tn_f64");
 }
