@@ -123,7 +123,7 @@ def train_pls(
     from .basis.base import NoiseSpec
 
     if energy_reduce is None and particles.is_cuda:
-        return _train_pls_two_in_flight(pls, particles, number_of_epochs, step_size, early_stopper, noises)
+        return _train_pls_in_flight(pls, particles, number_of_epochs, step_size, early_stopper, noises)
 
     space = _LoopSpace(pls, noises)
     cur = space.enter(particles)
@@ -150,34 +150,49 @@ def train_pls(
     return particles, energy_potentials
 
 
-def _train_pls_two_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs: int, step_size: float,
-                             early_stopper: EarlyStopper, noises) -> Tuple[torch.Tensor, List[float]]:
-    """The pipelined loop with TWO step launches queued: launch k computes U_{k+1} from U_k and, as a by-product, the
-    energy of U_k.  The mean energy travels to pinned host memory by an asynchronous copy followed by an event, and
-    launch k+1 is already queued behind it when the host waits for that event -- so the GPU never idles over the host's
-    round trip (sync + early-stop logic + next launch, ~30 us against a 290 us step at configs[1]).  Three particle
-    buffers rotate, so the (up to two) launches made speculatively past the stop never touch the returned state, and
-    the torch RNG state is rewound to what the plain loop would have consumed.  Same particles, energies and stop
-    index as the plain loop (tests/test_gpu_parity.py)."""
+#: step launches the pipelined loop keeps queued ahead of the energy it is waiting for (>= 2).  Two keep the GPU busy over
+#: the host's ordinary round trip (~30 us); on a shared host the Python thread is now and then descheduled for milliseconds
+#: (measured on the GPU boxes: the same loop 0.275 or 0.31 ms per iteration from one repetition to the next, the host's
+#: share of an iteration 29 or 63 us, tools/train_loop_probe.py), and a queue of eight 0.27 ms launches rides that out.
+#: Costs depth + 1 particle buffers and up to `depth` speculative launches past the stop (discarded).
+IN_FLIGHT_DEPTH = 8
+#: ... as long as the rotating particle buffers stay below this many bytes (depth is reduced, never below 2)
+IN_FLIGHT_BUFFER_BYTES = 4 << 30
+
+
+def _train_pls_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs: int, step_size: float,
+                         early_stopper: EarlyStopper, noises, depth: int | None = None) -> Tuple[torch.Tensor, List[float]]:
+    """The pipelined loop with `depth` step launches queued: launch k computes U_{k+1} from U_k and, as a by-product, the
+    energy of U_k.  The mean energy travels to pinned host memory by the launch that finishes the by-product, followed by
+    an event, and launches k+1 .. k+depth-1 are already queued behind it when the host waits for that event -- so the GPU
+    never idles over the host's round trip (sync + early-stop logic + next launch, ~30 us against a 270 us step at
+    configs[1]) nor over a descheduled host thread.  depth + 1 particle buffers rotate, so the launches made speculatively
+    past the stop never touch the returned state, and the torch RNG state is rewound to what the plain loop would have
+    consumed.  Same particles, energies and stop index as the plain loop (tests/test_gpu_parity.py)."""
     from .basis.base import NoiseSpec
 
     from .basis.base import BlockSpec
 
     T = number_of_epochs
     j = particles.shape[1]
+    if depth is None:
+        depth = IN_FLIGHT_DEPTH
+        while depth > 2 and (depth + 1) * particles.numel() * 8 > IN_FLIGHT_BUFFER_BYTES:
+            depth -= 1
+    depth = max(2, min(int(depth), max(T, 2)))
+    NB = depth + 1  # rotating slots: particle buffers, energy vectors, host sums, events
     space = _LoopSpace(pls, noises)
-    bufs = [space.enter(particles), torch.empty_like(particles, memory_format=torch.contiguous_format),
-            torch.empty_like(particles, memory_format=torch.contiguous_format)]
-    e_dev = [torch.empty(j, dtype=torch.float64, device=particles.device) for _ in range(3)]
+    bufs = [space.enter(particles)] + [torch.empty_like(particles, memory_format=torch.contiguous_format) for _ in range(NB - 1)]
+    e_dev = [torch.empty(j, dtype=torch.float64, device=particles.device) for _ in range(NB)]
     # Gaussian/identity fast paths: the launch that finishes the energy by-product also leaves the 256-column chunk sums of
     # the energies -- straight in pinned host memory -- so an iteration is the step kernel and ONE small launch (round 2: a
     # finishing launch plus a mean launch, 15 us of a 280 us iteration); other costs keep the separate mean launch
     fused_sums = _supports_energy_sums(pls)
     nchunk = (j + 255) // 256 if fused_sums else 1
-    host = torch.empty(3 * nchunk, dtype=torch.float64).pin_memory()
+    host = torch.empty(NB * nchunk, dtype=torch.float64).pin_memory()
     host_ptr = host.data_ptr()  # (hipHostMalloc'ed by torch: host and device addresses coincide)
     eta_dev = torch.full((1,), float(step_size), dtype=torch.float64, device=particles.device) if fused_sums else None
-    events = [torch.cuda.Event() for _ in range(3)]
+    events = [torch.cuda.Event() for _ in range(NB)]
     rng_states = {}
     launched = 0
 
@@ -187,14 +202,15 @@ def _train_pls_two_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs
         rng_states[k] = torch.get_rng_state()  # (a speculative launch may have to be un-drawn)
         spec = NoiseSpec(injected=noises[k]) if noises is not None else None
         if fused_sums:  # one column block = all particles, its step size from a device word, chunk sums to the host slot
-            blocks = BlockSpec(j, eta_dev, energy_sums=host_ptr + 8 * nchunk * (k % 3))
-            space.step(bufs[k % 3], step_size, bufs[(k + 1) % 3], spec, e_dev[k % 3], blocks=blocks)
+            blocks = BlockSpec(j, eta_dev, energy_sums=host_ptr + 8 * nchunk * (k % NB))
+            space.step(bufs[k % NB], step_size, bufs[(k + 1) % NB], spec, e_dev[k % NB], blocks=blocks)
         else:
-            space.step(bufs[k % 3], step_size, bufs[(k + 1) % 3], spec, e_dev[k % 3])
+            space.step(bufs[k % NB], step_size, bufs[(k + 1) % NB], spec, e_dev[k % NB])
             # E(U_k): the reduction kernel stores the mean straight into pinned host memory (mapped into the device's
             # address space); the host reads it after the event -- no torch reduce kernel, no copy kernel per iteration
-            _ops.block_means(e_dev[k % 3], out_ptr=host_ptr + 8 * (k % 3))
-        events[k % 3].record()
+            _ops.block_means(e_dev[k % NB], out_ptr=host_ptr + 8 * (k % NB))
+        events[k % NB].record()
+        rng_states.pop(k - NB - 1, None)
         launched += 1
 
     def read_energy(slot: int) -> float:
@@ -205,21 +221,23 @@ def _train_pls_two_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs
     energy_potentials: List[float] = []
     final = None
     for t in range(T):  # iteration t of the plain loop: update t done (U_{t+1}), its energy E(U_{t+1}) wanted
-        while launched < T and launched <= t + 2:  # launches t+1 (carries E(U_{t+1})) and t+2 (keeps the queue non-empty)
+        # launch t+1 carries E(U_{t+1}); t+2 .. t+depth keep the queue non-empty.  Launch k writes slot (k+1) % NB and the
+        # stop below may return slot (t+1) % NB: k + 1 - (t + 1) <= depth < NB, so that slot is never overwritten
+        while launched < T and launched <= t + depth:
             launch()
         if t + 1 < T:
-            events[(t + 1) % 3].synchronize()
-            energy_potential = read_energy((t + 1) % 3)
+            events[(t + 1) % NB].synchronize()
+            energy_potential = read_energy((t + 1) % NB)
         else:  # the energy after the last update has no following launch to ride on
-            energy_potential = _mean_energy(space.energy(bufs[T % 3]))
+            energy_potential = _mean_energy(space.energy(bufs[T % NB]))
         if early_stopper.should_stop(loss=energy_potential, step_size=step_size):
             if launched > t + 1:
                 torch.set_rng_state(rng_states[t + 1])
-            final = bufs[(t + 1) % 3]
+            final = bufs[(t + 1) % NB]
             break
         energy_potentials.append(energy_potential)
     if final is None:
-        final = bufs[T % 3]
+        final = bufs[T % NB]
     torch.cuda.current_stream().synchronize()  # speculative launches still read / write the rotating buffers
     space.leave(final, particles)
     return particles, energy_potentials

@@ -970,6 +970,18 @@ def test_config1_train_pls_trajectory(P):
         eb.append(e)
     assert len(ea) == len(eb) and np.allclose(ea, eb, rtol=1e-9) and relerr(ua, ub) < 1e-12
     assert torch.equal(state_a, torch.get_rng_state())
+    # ... whatever the number of launches the loop keeps queued (2 = round 2; the default rides out a descheduled host
+    # thread; 70 > the epochs): same stop index, bit-identical particles and energies, same generator state
+    runs = {}
+    for depth in (2, 3, trainers.IN_FLIGHT_DEPTH, 250):
+        torch.manual_seed(7)
+        uc, ec = trainers._train_pls_in_flight(P.pkg.PLS(gb, gc), cu(u0), steps, eta, trainers.EarlyStopper(patience=1.5 * eta),
+                                               None, depth=depth)
+        runs[depth] = (uc, ec, torch.get_rng_state())
+    u2, e2, s2 = runs[2]
+    assert 5 < len(e2) < steps - 1, f"this case is meant to stop early (stopped after {len(e2)})"
+    for depth, (uc, ec, sc) in runs.items():
+        assert ec == e2 and torch.equal(uc, u2) and torch.equal(sc, s2), depth
 
 
 def test_user_defined_python_cost_goes_through_unfused_entry_points(P):
