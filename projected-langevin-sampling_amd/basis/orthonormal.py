@@ -14,9 +14,9 @@ from .base import BlockSpec, NoiseSpec, PLSBasis, alloc_matrix
 class OrthonormalBasis(PLSBasis):
     """Particles live in the eigenbasis of k(Z,Z)/M (orthonormal.py:22-68).
 
-    Setup (once): k(Z,Z), k(Z,X) on the GPU; eigh on the host LAPACK like the reference (the eigenvector gauge is
-    implementation defined, so parity runs may pass ``spectrum=(eigenvalues, eigenvectors)``; ``eigh_device="cuda"`` moves
-    this one call to the GPU); then the projection
+    Setup (once): k(Z,Z), k(Z,X) on the GPU; torch.linalg.eigh like the reference, on the device the Gram matrix lives on
+    (``eigh_device="cpu"`` / ``samplers.DEFAULT_EIGH_DEVICE`` select host LAPACK, the reference's CPU path; the
+    eigenvector gauge is implementation defined, so parity runs may pass ``spectrum=(eigenvalues, eigenvectors)``); then the projection
     A = V~^T k(Z,X) and its transpose are built once on the GPU instead of re-associating three matrices per step
     (orthonormal.py:106-108, :151-155)."""
 
@@ -30,7 +30,7 @@ class OrthonormalBasis(PLSBasis):
         spectrum: tuple[torch.Tensor, torch.Tensor] | None = None,
         keep_gram: bool = True,
         verbose: bool = True,
-        eigh_device: str = "cpu",
+        eigh_device: str | None = None,
         setup_times: dict | None = None,
     ):
         super().__init__(additional_predictive_noise_distribution=additional_predictive_noise_distribution)
@@ -55,13 +55,15 @@ class OrthonormalBasis(PLSBasis):
         dev = self.base_gram_induce.device
         t_lap = lap("gram_s", t_lap)
         if spectrum is None:
-            # :46-48.  "cpu" is the reference's own call (host LAPACK: 0.8 s at M = 1024, the whole setup otherwise
-            # takes 0.1 s); "cuda" runs the same factorisation through torch on the GPU (0.09 s) -- another, equally
-            # valid, eigenvector gauge, and eigenvalues that differ in the last bits (a threshold that cuts through a
-            # cluster of tiny eigenvalues may keep a different count)
-            assert eigh_device in ("cpu", "cuda"), "eigh_device must be 'cpu' or 'cuda'"
+            # :46-48, torch.linalg.eigh where the matrix lives unless told otherwise (samplers.DEFAULT_EIGH_DEVICE).  "cpu"
+            # is the reference's CPU path (host LAPACK: 0.9 s at M = 1024, 21 s at 4096 on a GPU box's host share; the
+            # whole setup otherwise takes 0.1 s); on the GPU the same factorisation takes 0.03 / 0.15 s -- another,
+            # equally valid, eigenvector gauge, and eigenvalues that differ in the last bits (a threshold that cuts
+            # through a cluster of rounding-level eigenvalues may keep a different count)
+            from ..samplers import resolve_eigh_device
+
             g = (1 / m) * self.base_gram_induce
-            eigenvalues, eigenvectors = torch.linalg.eigh(g.cpu() if eigh_device == "cpu" else g)
+            eigenvalues, eigenvectors = torch.linalg.eigh(g.cpu() if resolve_eigh_device(eigh_device, g) == "cpu" else g)
             eigenvalues, eigenvectors = eigenvalues.cpu(), eigenvectors.cpu()
         else:
             eigenvalues, eigenvectors = (t.detach().cpu().to(torch.float64) for t in spectrum)

@@ -15,3 +15,16 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(autouse=True)
+def _host_eigh_gauge():
+    """Parity tests compare particle coordinates and sampler draws with the CPU oracle, so the eigendecompositions of setup
+    and prediction are pinned to host LAPACK (the oracle's eigenvector gauge).  The library default is "auto" (where the
+    matrix lives, like the reference's torch.linalg.eigh); the device path has its own gauge-invariant tests."""
+    from projected_langevin_sampling_amd import samplers
+
+    prev = samplers.DEFAULT_EIGH_DEVICE
+    samplers.DEFAULT_EIGH_DEVICE = "cpu"
+    yield
+    samplers.DEFAULT_EIGH_DEVICE = prev
