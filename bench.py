@@ -533,14 +533,17 @@ def main():
     }
     # ---- sustained: the same like-for-like step for >= 10 s, in windows of 50 steps (does the clock hold?) ----
     if args.sustained_steps >= 50:
-        win = 50
-        nwin = args.sustained_steps // win
+        # 50-step windows at configs[1] (300 steps = 13.4 s); a configuration whose step takes seconds (configs[4]: 1.8 s) gets
+        # the same six windows over ~20 s instead of 300 steps = 9 minutes
+        nwin = max(args.sustained_steps // 50, 1)
+        win = max(1, min(50, int(round(20.0 / nwin / (ms_per_step * 1e-3)))))
         run(force_generic=True, steps=2, warmup=0, timeline=False)
         windows = []
         t_all = time.perf_counter()
-        for _ in range(nwin):
+        for w in range(nwin):
             dtw, _ = run(force_generic=True, steps=win, warmup=0, timeline=False)
             windows.append(dtw / win * 1e3)
+            log(f"sustained window {w + 1}/{nwin}: {windows[-1]:.2f} ms/step")
         t_all = time.perf_counter() - t_all
         out["sustained"] = {
             "steps": nwin * win, "wall_s": t_all, "ms_per_step": sum(windows) / len(windows),
