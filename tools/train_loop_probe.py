@@ -1,5 +1,5 @@
-"""Where does a train_pls iteration go at configs[1] (Gaussian fast path)?  Wall time of the two-in-flight loop against the
-time the host spends waiting in Event.synchronize(): no waiting = the host is the bottleneck, not the GPU."""
+"""Where does a train_pls iteration go at configs[1] (Gaussian fast path)?  Wall time of the pipelined loop, three
+repetitions in one process (and, for loops that wait on events, the time spent in Event.synchronize())."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import projected_langevin_sampling_amd as P
