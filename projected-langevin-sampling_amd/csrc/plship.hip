@@ -1396,6 +1396,8 @@ int gemm_tn_ex(const double *L, int64_t ldl, const double *R, int64_t ldr, doubl
               (long long)ldl, (long long)I, (long long)ldr, (long long)J, (long long)ldc);
   if (I == 0 || J == 0) return PLS_OK;
   EpiStore e{C, ldc, alpha, beta, 0};
+  // many tiles and a row count off the 128-row grid (the projection A = V~^T k(Z,X) of a thresholded basis): row blocks
+  if (tri == 0 && gemm_rows_ok(L, ldl, R, ldr, I, J, K, ldc, 1)) return launch_gemm_rows(L, ldl, R, ldr, I, J, K, e, st, 0);
   return launch_gemm_any(L, ldl, R, ldr, I, J, K, e, st, 0, tri);
 }
 

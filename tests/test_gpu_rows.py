@@ -123,3 +123,51 @@ def test_row_block_launch_with_the_rows_streamed_in_chunks(P, mk):
     want = -eta * (a @ g) - eta * u / lam[:, None] + math.sqrt(2 * eta) * xi
     assert relerr(got, want) < 1e-10
     assert relerr(got, old) < 1e-12
+
+
+def test_row_block_contraction_fuzz_against_the_host_product_with_guard_bands(P):
+    """pls_gemm_tn takes the row-block launch for many tiles and I off the 128-row grid.  60 seeded draws of (I, J, K,
+    alpha, beta, leading dimensions): the result against torch's fp64 product on the host, and the memory AROUND the
+    output -- the row padding beyond J inside ldc, guard rows above and below -- must be untouched: the launch drops rows
+    of the next tile or beyond I through the range of a buffer descriptor and columns >= J through a lane offset, and
+    this is the check that neither leaks."""
+    import numpy as np
+
+    from projected_langevin_sampling_amd import _lib as L
+
+    lib = L.load()
+    rng = np.random.default_rng(20240 + 7)
+    guard = 7.25e300
+    for draw in range(60):
+        i = int(rng.integers(129, 256)) if draw % 2 == 0 else int(rng.choice([300, 383, 497, 500, 620, 761, 1000, 1023, 1090]))
+        j = int(rng.choice([128, 256, 1000, 1024, 1153, 2048, 2049, 3000]))
+        k = int(rng.choice([1, 3, 4, 15, 16, 17, 33, 64, 100, 257]))
+        while -(-i // 128) * -(-j // 128) < 256:  # (fewer tiles take the 64 x 64 kernels: not this test's subject)
+            j += 1024
+        alpha = float(rng.choice([1.0, -0.5, 2.25]))
+        beta = float(rng.choice([0.0, 0.0, 1.0, -0.75]))
+        ldl, ldr = i + (i & 1) + 2 * int(rng.integers(0, 5)), j + (j & 1) + 2 * int(rng.integers(0, 5))  # even: the DMA path
+        ldc = max(j + int(rng.integers(0, 9)), 128)
+        g = torch.Generator().manual_seed(5000 + draw)
+        lm = torch.randn(k, ldl, generator=g)
+        rm = torch.randn(k, ldr, generator=g)
+        c0 = torch.randn(i, j, generator=g)
+        lm[:, i:] = float("nan")  # row padding of the operands must never reach the result
+        rm[:, j:] = float("nan")
+        buf = torch.full((i + 6, ldc), guard)
+        buf[3:3 + i, :j] = c0
+        bg, lg, rg = cu(buf), cu(lm), cu(rm)
+        out = bg[3:3 + i]
+        L.check(lib.pls_gemm_tn(lg.data_ptr(), ldl, rg.data_ptr(), ldr, out.data_ptr(), ldc, i, j, k, alpha, beta, L.stream_ptr()))
+        got = bg.cpu()
+        want = alpha * (lm[:, :i].T @ rm[:, :j]) + beta * c0
+        tag = f"draw {draw}: I={i} J={j} K={k} alpha={alpha} beta={beta} ldl={ldl} ldr={ldr} ldc={ldc}"
+        scale = (lm[:, :i].abs().T @ rm[:, :j].abs()).max().item() + c0.abs().max().item()
+        assert (got[3:3 + i, :j] - want).abs().max().item() < 1e-14 * scale * max(4, k) ** 0.5, tag
+        assert (got[:3] == guard).all() and (got[3 + i:] == guard).all(), tag + ": guard rows written"
+        assert (got[3:3 + i, j:] == guard).all(), tag + ": row padding written"
+        with row_blocks(P, 0):
+            bg2 = cu(buf)
+            L.check(lib.pls_gemm_tn(lg.data_ptr(), ldl, rg.data_ptr(), ldr, bg2[3:3 + i].data_ptr(), ldc, i, j, k, alpha, beta,
+                                    L.stream_ptr()))
+        assert relerr(bg2[3:3 + i, :j], got[3:3 + i, :j]) < 1e-13, tag + ": vs the 128-row tiles"
