@@ -163,10 +163,10 @@ IN_FLIGHT_BUFFER_BYTES = 4 << 30
 def _train_pls_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs: int, step_size: float,
                          early_stopper: EarlyStopper, noises, depth: int | None = None) -> Tuple[torch.Tensor, List[float]]:
     """The pipelined loop with `depth` step launches queued: launch k computes U_{k+1} from U_k and, as a by-product, the
-    energy of U_k.  The mean energy travels to pinned host memory by the launch that finishes the by-product, followed by
-    an event, and launches k+1 .. k+depth-1 are already queued behind it when the host waits for that event -- so the GPU
-    never idles over the host's round trip (sync + early-stop logic + next launch, ~30 us against a 270 us step at
-    configs[1]) nor over a descheduled host thread.  depth + 1 particle buffers rotate, so the launches made speculatively
+    energy of U_k.  The mean energy travels to pinned host memory by the launch that finishes the by-product (the host
+    polls that slot; costs without fused chunk sums: a mean launch followed by an event), and launches k+1 .. k+depth-1
+    are already queued behind it while the host waits -- so the GPU never idles over the host's round trip (early-stop
+    logic + next launch, ~30 us against a 270 us step at configs[1]) nor over a descheduled host thread.  depth + 1 particle buffers rotate, so the launches made speculatively
     past the stop never touch the returned state, and the torch RNG state is rewound to what the plain loop would have
     consumed.  Same particles, energies and stop index as the plain loop (tests/test_gpu_parity.py)."""
     from .basis.base import NoiseSpec
