@@ -20,7 +20,9 @@ Pinning (tests/test_oracle_goldens.py):
   * NOT pinned by any reference test: ``_calculate_particle_update`` of either real basis
     and the RBF/ARD base kernel values (third party gpytorch.kernels.RBFKernel; restated
     from its published closed form) -> those two are "parity unpinned" beyond their
-    building blocks.
+    building blocks (the kernel values are cross-checked against scikit-learn's
+    ConstantKernel * RBF in tests/test_oracle_goldens.py: an independent implementation
+    of the same closed form, not the reference's library).
 
 Third-party arithmetic restated here:
   * ``gpytorch.solve(input=K, rhs=U[, lhs=L])`` == ``L @ K^{-1} @ U`` through a Cholesky

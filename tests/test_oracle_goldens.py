@@ -314,3 +314,25 @@ def test_philox4x32_10_known_answer_vectors(ctr, key, want):
 
     got = philox_ref.philox4x32_10(*[np.array([c], dtype=np.uint64) for c in ctr], key[0], key[1])
     assert tuple(int(g[0]) for g in got) == want
+
+
+def test_rbf_ard_kernel_against_an_independent_implementation():
+    """The reference's tests never evaluate its base kernel (all use a linear MockKernel), and gpytorch is not installable
+    here, so the oracle's ScaleKernel(RBFKernel(ard_num_dims=D)) is a restatement of the published closed form
+    k(a, b) = s exp(-1/2 sum_d ((a_d - b_d) / l_d)^2) (experiments/uci/regression/main.py:171-173, README.md:144-146) with no
+    reference-held number behind it.  This pins it to another implementation of the same formula, scikit-learn's
+    ConstantKernel * RBF(length_scale = l) -- not the reference's library, but not this repository's code either."""
+    sk = pytest.importorskip("sklearn.gaussian_process.kernels")
+    g = torch.Generator().manual_seed(3)
+    for d, n1, n2 in ((1, 17, 9), (3, 40, 40), (8, 33, 70), (20, 12, 5)):
+        x1 = torch.randn(n1, d, generator=g, dtype=torch.float64)
+        x2 = torch.randn(n2, d, generator=g, dtype=torch.float64) * 1.7 + 0.3
+        ls = torch.rand(d, generator=g, dtype=torch.float64) + 0.4
+        s = 2.5
+        want = (sk.ConstantKernel(s) * sk.RBF(length_scale=ls.numpy()))(x1.numpy(), x2.numpy())
+        got = O.RBFARDKernel(ls, s)(x1, x2).numpy()
+        assert np.allclose(got, want, rtol=1e-13, atol=1e-300), (d, n1, n2)
+        # and the README's 1-D toy kernel (l = 0.15, s = 3): diagonal = s, symmetric
+        k = O.RBFARDKernel([0.15], 3.0)(x1[:, :1], x1[:, :1])
+        assert torch.allclose(k.diagonal(), torch.full((n1,), 3.0, dtype=torch.float64)) and torch.equal(k, k.T)
+
