@@ -198,6 +198,26 @@ def _run_one_by_one(pls: PLS, particles: torch.Tensor, runs: List[_CandidateRun]
         ledger.judge_ready(runs)
 
 
+#: A step of J particles shorter than this is launch-bound: the S candidates then run as column blocks of one launch per
+#: epoch.  Above it the block launch buys nothing -- its column-steps equal the sequential search's -- and pays a host
+#: round trip per epoch, while train_pls keeps eight launches queued.  Measured at N = 1e5, M_k = 1024, Gaussian, 8
+#: candidates (tools/runner_probe.py): J = 256 (25 us per step) 0.18 s in blocks vs 0.25 s one by one; J = 1024 (40 us)
+#: 0.30 s vs 0.26 s.
+LAUNCH_BOUND_STEP_SECONDS = 30e-6
+
+
+def _step_is_launch_bound(pls: PLS, j: int) -> bool:
+    """estimated duration of one step of j particles (at half the fp64 MFMA peak) below LAUNCH_BOUND_STEP_SECONDS"""
+    basis = pls.basis
+    mk = int(basis.approximation_dimension)
+    if getattr(basis, "supports_energy_sums", lambda c: False)(pls.cost):
+        flop = 2.0 * mk * mk * j  # Gaussian/identity: one M_k x M_k x J contraction
+    else:
+        n = int(getattr(pls.cost, "y_train").shape[0])
+        flop = 4.0 * n * mk * j  # F = A^T U and A G
+    return flop / 39.3e12 < LAUNCH_BOUND_STEP_SECONDS
+
+
 def train_pls_runner(
     pls: PLS,
     particle_name: str,
@@ -213,17 +233,23 @@ def train_pls_runner(
     particles: torch.Tensor,
     metric_to_optimise: str = "nll",
     train_fn: Optional[Callable] = None,
+    batched: Optional[bool] = None,
 ) -> Tuple[torch.Tensor, float, int]:
     """Same arguments and return value as the reference's runner -- (best particles, best step size, number of energies
     of the best run), runners.py:446 -- with ``experiment_data`` replaced by the two tensors it is read for
     (experiment_data.train.x / .y, :374-391); plotting is out of scope.  ``train_fn`` (extension): train the candidates
-    one at a time with this loop (e.g. ``train_pls_captured``) instead of the batched launch."""
+    one at a time with this loop (e.g. ``train_pls_captured``) instead of the batched launch.  ``batched`` (extension):
+    force the column-block launch (True) or the one-at-a-time loop (False); None chooses by the step's size."""
     step_sizes = candidate_step_sizes(step_size_upper, simulation_duration, maximum_number_of_steps, number_of_step_searches)
     runs = [_CandidateRun(float(s), int(simulation_duration / s)) for s in step_sizes]  # :363
     ledger = _SearchLedger(pls, metric_to_optimise, x_train, y_train, minimum_change_in_energy_potential,
                            fallback_particles=particles.detach().clone())
-    batched = (train_fn is None and particles.is_cuda and pls._fused()
-               and getattr(pls.basis, "supports_input_energy", lambda c: False)(pls.cost))
+    can_batch = (train_fn is None and particles.is_cuda and pls._fused()
+                 and getattr(pls.basis, "supports_input_energy", lambda c: False)(pls.cost))
+    if batched is None:
+        batched = can_batch and _step_is_launch_bound(pls, particles.shape[1])
+    else:
+        assert not batched or can_batch, "batched=True needs a fused step with the energy by-product on the GPU"
     if batched:
         _run_blocks(pls, particles, runs, early_stopper_patience, seed, ledger)
     else:

@@ -1566,8 +1566,11 @@ def test_batched_step_size_search_equals_the_sequential_oracle_search(P, cost_id
     pls = P.pkg.PLS(gb, gc)
     u0_dev = cu(u0)
     keep = u0_dev.clone()
+    from projected_langevin_sampling_amd.runners import _step_is_launch_bound
+
+    assert _step_is_launch_bound(pls, u0_dev.shape[1])  # (a step this small takes the column-block launch by default)
     got_u, got_lr, got_n = train_pls_runner(pls=pls, particle_name="t", x_train=pr["x"], y_train=pr["y"], particles=u0_dev,
-                                            metric_to_optimise="loss", **kw)
+                                            metric_to_optimise="loss", batched=True, **kw)
     assert torch.equal(u0_dev, keep)  # the initial particles are cloned, never modified
     assert got_lr == want_lr and got_n == want_n, (got_lr, want_lr, got_n, want_n)
     assert relerr(got_u, want_u) < 1e-9
@@ -1585,6 +1588,10 @@ def test_batched_step_size_search_equals_the_sequential_oracle_search(P, cost_id
     again_u, again_lr, again_n = train_pls_runner(pls=pls, particle_name="t", x_train=pr["x"], y_train=pr["y"], particles=u0_dev,
                                                   metric_to_optimise="loss", **kw)
     assert again_lr == got_lr and again_n == got_n and torch.equal(again_u, got_u)
+    # and the one-at-a-time route (what a step that is not launch-bound takes) selects the same run
+    seq_u, seq_lr, seq_n = train_pls_runner(pls=pls, particle_name="t", x_train=pr["x"], y_train=pr["y"], particles=u0_dev,
+                                            metric_to_optimise="loss", batched=False, **kw)
+    assert seq_lr == got_lr and seq_n == got_n and relerr(seq_u, got_u) < 1e-12
 
 
 def test_batched_search_blocks_equal_stand_alone_runs(P):
