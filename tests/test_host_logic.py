@@ -301,3 +301,24 @@ def test_whitened_route_and_inverse_factor_products_are_as_accurate_as_substitut
         assert moved < cond * 1e-15
     finally:
         torch.set_default_dtype(prev)
+
+
+def test_eigh_device_resolution():
+    """samplers.resolve_eigh_device: an explicit request wins, then the module default; "auto" = where the matrix lives
+    (the reference's torch.linalg.eigh(matrix) semantics).  conftest pins the default to "cpu" for the parity tests."""
+    from projected_langevin_sampling_amd import samplers
+
+    m = torch.eye(3, dtype=torch.float64)
+    assert samplers.DEFAULT_EIGH_DEVICE == "cpu"  # (the autouse fixture of tests/conftest.py)
+    assert samplers.resolve_eigh_device(None, m) == "cpu"
+    assert samplers.resolve_eigh_device("auto", m) == "cpu"  # a host matrix
+    assert samplers.resolve_eigh_device("cuda", m) == "cuda"
+    prev = samplers.DEFAULT_EIGH_DEVICE
+    try:
+        samplers.DEFAULT_EIGH_DEVICE = "auto"
+        assert samplers.resolve_eigh_device(None, m) == "cpu"
+        assert samplers.resolve_eigh_device("cpu", m) == "cpu"
+    finally:
+        samplers.DEFAULT_EIGH_DEVICE = prev
+    with pytest.raises(AssertionError):
+        samplers.resolve_eigh_device("tpu", m)
