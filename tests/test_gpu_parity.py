@@ -1494,6 +1494,50 @@ def test_conditional_variance_selector_matches_oracle(P, n, m, d):
         assert di[got[t]] >= di[rest].max() * (1 - 1e-9), f"pick {t} is not the largest residual variance"
 
 
+def test_reference_goldens_inducing_point_selectors(P, G):
+    """The reference's own selections (tests/test_inducing_point_selectors.py:11-120: MockKernel = linear kernel, float32
+    inputs, set_seed(seed)) through the HIP selector: identical rows and indices -- index work, no tolerance."""
+    from projected_langevin_sampling_amd.inducing_point_selectors import (
+        ConditionalVarianceInducingPointSelector, RandomInducingPointSelector)
+    from projected_langevin_sampling_amd.utils import set_seed
+
+    for c in G["inducing_point_selectors"]["conditional_variance"]:
+        x = torch.tensor(c["x"], dtype=torch.float32)
+        set_seed(c["seed"])
+        z, idx = ConditionalVarianceInducingPointSelector(threshold=c["threshold"])(x, c["m"], P.pkg.LinearKernel())
+        assert torch.equal(z, torch.tensor(c["z"], dtype=torch.float32)), (z, c["z"])
+        assert torch.equal(x[idx], z)
+    for c in G["inducing_point_selectors"]["random"]:
+        x = torch.tensor(c["x"], dtype=torch.float32)
+        set_seed(c["seed"])
+        z, idx = RandomInducingPointSelector()(x, c["m"], P.pkg.LinearKernel())
+        assert torch.equal(z, torch.tensor(c["z"], dtype=torch.float32)) and torch.equal(x[idx], z)
+
+
+def test_reference_goldens_temper_scale(P, G):
+    """tests/test_temper.py:232-300 through the drop-in TemperPLS with the reference's test doubles on the device
+    (mockers/basis.py:83-97, mockers/cost.py:21-30: the predictive distribution is the standard normal)."""
+    from projected_langevin_sampling_amd.temper import TemperPLS
+
+    c = G["temper"]
+    u = cu(torch.tensor(c["particles"]))
+    xc, yc = torch.tensor(c["x_calibration"]), torch.tensor(c["y_calibration"])
+
+    class MockCost:
+        def predict(self, prediction_samples, **kw):
+            return torch.distributions.MultivariateNormal(torch.zeros(1, device="cuda"), torch.eye(1, device="cuda"))
+
+    class MockPLS:
+        cost = MockCost()
+
+        def predict_samples(self, particles, x, predictive_noise=None, observation_noise=None):
+            return cu(x) @ torch.ones((x.shape[1], particles.shape[0]), dtype=torch.float64, device="cuda") @ particles
+
+    t = TemperPLS(xc, yc, MockPLS(), u, debug=True)
+    assert np.allclose(t.scale, c["scale"])
+    assert isinstance(t(xc), torch.distributions.MultivariateNormal)
+
+
 def test_conditional_variance_selector_threshold_and_errors(P):
     from projected_langevin_sampling_amd.inducing_point_selectors import (
         ConditionalVarianceInducingPointSelector, RandomInducingPointSelector)

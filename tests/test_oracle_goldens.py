@@ -295,6 +295,40 @@ def test_conformalise_goldens(G):
     assert np.allclose(torch.mean(up - lo).item(), c["average_interval_width_095"])
 
 
+# ---- inducing-point selection and tempering, pinned by the reference's own vectors -----------------
+
+
+def test_inducing_point_selector_goldens(G):
+    """tests/test_inducing_point_selectors.py:11-120: MockKernel (linear), float32 inputs, set_seed(seed) -> numpy seed for
+    the conditional-variance permutation (conditional_variance.py:58-61), torch seed for randperm (random.py:9-18).  Index
+    work: the selected ROWS must be the reference's, exactly."""
+    from oracle import selectors_oracle as SO
+
+    linear = lambda a, b: a @ b.T  # mockers/kernel.py:13-23
+    for c in G["inducing_point_selectors"]["conditional_variance"]:
+        x = np.asarray(c["x"], dtype=np.float32)
+        np.random.seed(c["seed"])  # src/utils.py:14
+        z, idx, _, _ = SO.conditional_variance_select(x, c["m"], linear, threshold=c["threshold"])
+        assert np.array_equal(z, np.asarray(c["z"], dtype=np.float32)), (z, c["z"])
+        assert np.array_equal(x[idx], z)
+    for c in G["inducing_point_selectors"]["random"]:
+        x = t32(c["x"])
+        torch.manual_seed(c["seed"])  # src/utils.py:16
+        assert torch.equal(x[torch.randperm(x.shape[0])[: c["m"]]], t32(c["z"]))  # random.py:16-18
+
+
+def test_temper_scale_golden(G):
+    """tests/test_temper.py:232-300: scale 84.18800354 of TemperPLS over the test doubles; MockCost.predict is the
+    standard normal (mean 0, variance 1) whatever the samples are, so the golden pins temper/base.py:38-46 itself."""
+    c = G["temper"]
+    y = t32(c["y_calibration"])
+    got = O.temper_scale(y, torch.zeros(1), torch.ones(1))
+    assert np.allclose(got, c["scale"])
+    # the samples the wrapper would have predicted from (mockers/basis.py:83-97) do not enter the scale
+    u, xc = t32(c["particles"]), t32(c["x_calibration"])
+    assert (xc @ torch.ones((xc.shape[1], u.shape[0])) @ u).shape == (5, 3)
+
+
 # Random123 known-answer vectors of Philox4x32-10 (Salmon et al., SC'11; kat_vectors of the Random123 distribution):
 # (counter words, key words) -> output words.  They pin oracle/philox_ref.py, which in turn pins csrc/philox.h through
 # tests/test_gpu_parity.py::test_philox_stream_matches_numpy_restatement.
