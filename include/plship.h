@@ -197,11 +197,13 @@ typedef struct {
 typedef struct {
   int64_t block_cols;
   const double *eta; /* device, cdiv(j, block_cols) entries */
-  /* Optional output (ABI 3), Gaussian/identity fast paths with energy_in != NULL only: cdiv(j, 256) doubles, entry i = the
-   * sum of the per-particle energies of columns [256 i, 256 (i + 1)) in the library's fixed order (pls_chunk_sums), written
-   * by the launch that finishes the energy by-product.  The mean energy of a block of columns that starts at a multiple of
-   * 256 is then a few host additions over these entries (ascending order: the value pls_block_means returns, bit for bit)
-   * -- no second launch per training iteration.  May point to pinned host memory mapped into the device.  NULL: not written. */
+  /* Optional output (ABI 3), steps with energy_in != NULL only: cdiv(j, 256) doubles, entry i = the sum of the per-particle
+   * energies of columns [256 i, 256 (i + 1)) in the library's fixed order (pls_chunk_sums).  On the Gaussian/identity fast
+   * paths the launch that finishes the energy by-product writes them (no second launch per training iteration); every
+   * other route appends one pls_chunk_sums launch, so the field is honoured whatever the descriptor and the options
+   * select.  The mean energy of a block of columns that starts at a multiple of 256 is then a few host additions over
+   * these entries (ascending order: the value pls_block_means returns, bit for bit).  May point to pinned host memory
+   * mapped into the device.  NULL: not written. */
   double *energy_sums;
 } pls_block_desc;
 

@@ -13,6 +13,11 @@ from ..kernel import _dev
 DEFAULT_WORKSPACE_BYTES = 2 << 30
 
 
+#: bit pattern a consumer writes into a slot of BlockSpec.energy_sums before it queues the launch that fills it: a quiet NaN
+#: with a payload no computation produces (a diverged run's NaN / inf energies are ordinary values next to it)
+UNWRITTEN_ENERGY_BITS = 0x7FF8DEADBEEF0001
+
+
 class NoiseSpec:
     """How one Langevin step gets its noise.
     injected: a (M, J) device tensor used as-is (parity runs inject the oracle's noise);

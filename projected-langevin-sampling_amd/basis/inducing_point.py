@@ -110,7 +110,11 @@ class InducingPointBasis(PLSBasis):
                 "pls_ipb_build_gaussian",
             )
             self._gauss_key = key
+            # the whitened operator was built from the previous y: drop it, or a later call without observation_noise would
+            # leave a stale Q in the descriptor (the C side only compares q_inv_noise with the cost's 1 / sigma2)
             self._white_key = None
+            self._Q = self._ct = None
+            self._q_inv_noise = 0.0
         if observation_noise is None or not self.whitened:
             return
         inv_noise = 1.0 / float(observation_noise)

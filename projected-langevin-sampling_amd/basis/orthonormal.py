@@ -32,6 +32,8 @@ class OrthonormalBasis(PLSBasis):
         verbose: bool = True,
         eigh_device: str | None = None,
         setup_times: dict | None = None,
+        group=None,
+        canonical_signs: bool | None = None,
     ):
         super().__init__(additional_predictive_noise_distribution=additional_predictive_noise_distribution)
         import time
@@ -58,13 +60,15 @@ class OrthonormalBasis(PLSBasis):
             # :46-48, torch.linalg.eigh where the matrix lives unless told otherwise (samplers.DEFAULT_EIGH_DEVICE).  "cpu"
             # is the reference's CPU path (host LAPACK: 0.9 s at M = 1024, 21 s at 4096 on a GPU box's host share; the
             # whole setup otherwise takes 0.1 s); on the GPU the same factorisation takes 0.03 / 0.15 s -- another,
-            # equally valid, eigenvector gauge, and eigenvalues that differ in the last bits (a threshold that cuts
-            # through a cluster of rounding-level eigenvalues may keep a different count)
+            # equally valid, eigenvector gauge (signs made canonical, basis/spectrum.py), and eigenvalues that differ in
+            # the last bits.  ONE process decides: under torch.distributed rank 0 of ``group`` factorises and broadcasts
+            # (lambda, V), so every rank of a J-sharded run keeps the same count and the same gauge, bit for bit.
             from ..samplers import resolve_eigh_device
+            from .spectrum import shared_spectrum
 
             g = (1 / m) * self.base_gram_induce
-            eigenvalues, eigenvectors = torch.linalg.eigh(g.cpu() if resolve_eigh_device(eigh_device, g) == "cpu" else g)
-            eigenvalues, eigenvectors = eigenvalues.cpu(), eigenvectors.cpu()
+            eigenvalues, eigenvectors = shared_spectrum(g, resolve_eigh_device(eigh_device, g), group=group,
+                                                        canonical_signs=canonical_signs)
         else:
             eigenvalues, eigenvectors = (t.detach().cpu().to(torch.float64) for t in spectrum)
         t_lap = lap("eigh_s", t_lap)
@@ -74,6 +78,9 @@ class OrthonormalBasis(PLSBasis):
         if verbose:
             print(f"Number of eigenvalues kept: {eigenvalues.shape[0]} out of {m}")  # :58-60
         mk = eigenvalues.shape[0]
+        from .spectrum import assert_same_count
+
+        assert_same_count(mk, group)  # (also with spectrum=: gather_particles / predictive_moments need one M_k)
         scaled = torch.multiply(torch.reciprocal(torch.sqrt(mk * eigenvalues))[None, :], eigenvectors)  # :63-68
         self.eigenvalues = _dev(eigenvalues)
         self.eigenvectors = _dev(eigenvectors)
@@ -135,6 +142,18 @@ class OrthonormalBasis(PLSBasis):
     @property
     def approximation_dimension(self) -> int:
         return self.eigenvalues.shape[0]  # :70-76
+
+    def spectrum_fingerprint(self) -> dict | None:
+        """What a checkpoint records about the eigenvector gauge its particles are coordinates in (basis/spectrum.py);
+        None for a basis without eigenvectors (from_projection)."""
+        if self.eigenvectors is None:
+            return None
+        fp = self.__dict__.get("_fingerprint")
+        if fp is None:
+            from .spectrum import spectrum_fingerprint
+
+            fp = self._fingerprint = spectrum_fingerprint(self.eigenvalues, self.eigenvectors)
+        return fp
 
     # ---- descriptors ---------------------------------------------------------------------------------------------
     def _desc(self, with_gaussian: bool = False) -> L.OnbDesc:

@@ -1869,6 +1869,15 @@ size_t pls_onb_step_workspace_bytes(const pls_onb_desc *basis, int64_t j, int64_
          onb_energy_partial_bytes(n_chunk, j) + (size_t)n_chunk * j * sizeof(double);
 }
 
+// pls_block_desc.energy_sums on the routes whose kernels do not leave them as a by-product (the generic N x M x J step, the
+// inducing-point step outside whitened coordinates): one small launch over the finished per-particle energies, so that a
+// caller who asked for the sums gets them whatever route the descriptor and the options select.
+static int finish_energy_sums(const pls_block_desc *blocks, const double *energy_in, int64_t j, hipStream_t st) {
+  if (!blocks || !blocks->energy_sums || !energy_in) return PLS_OK;
+  hipLaunchKernelGGL(chunk_sums_kernel, dim3((unsigned)cdiv(j, 256)), dim3(256), 0, st, energy_in, j, blocks->energy_sums);
+  return check_launch("chunk_sums");
+}
+
 static int validate_blocks(const pls_block_desc *b, int64_t j) {
   if (!b) return PLS_OK;
   PLS_REQUIRE(b->block_cols > 0 && b->eta != nullptr, "step_blocks: block_cols must be > 0 and eta set");
@@ -1938,7 +1947,9 @@ static int onb_step_impl(const pls_onb_desc *basis, const pls_cost_desc *cost, c
                        st, out, ldo, U, ldu, D, j, (int)nslab, (int64_t)(d_bytes / sizeof(double)), U, ldu, basis->lam, 0.0,
                        basis->mk, j, etap, out_mode, nz);
   }
-  return check_launch("langevin_update");
+  rc = check_launch("langevin_update");
+  if (rc) return rc;
+  return finish_energy_sums(blocks, energy_in, j, st);
 }
 
 int pls_onb_step(const pls_onb_desc *basis, const pls_cost_desc *cost, const double *y, double *U, int64_t ldu,
@@ -2207,8 +2218,10 @@ static int ipb_step_impl(const pls_ipb_desc *basis, const pls_cost_desc *cost, c
       rc = check_launch("ipb_gaussian_energy");
       if (rc) return rc;
     }
-    return ipb_finish(basis, U, ldu, D, 1, (int64_t)0, V, j, eta, noise, out, ldo, out_mode, xi, e, st, basis->c, inv_noise,
-                      blocks);
+    rc = ipb_finish(basis, U, ldu, D, 1, (int64_t)0, V, j, eta, noise, out, ldo, out_mode, xi, e, st, basis->c, inv_noise,
+                    blocks);
+    if (rc) return rc;
+    return finish_energy_sums(blocks, energy_in, j, st);
   }
   EnergySink sink;
   if (energy_in) {  // e_j = cost_j(F(U)) + (M/2) ||K^-1 U_j||^2 of the INPUT particles (inducing_point.py:95-115)
@@ -2225,8 +2238,10 @@ static int ipb_step_impl(const pls_ipb_desc *basis, const pls_cost_desc *cost, c
   rc = stream_drift(basis->Kzx, basis->ldkzx, basis->Kxz, basis->ldkxz, basis->m, basis->n, V, j, j, make_costp(cost), y,
                     D, j, max_slabs, (int64_t)(mj / sizeof(double)), &nslab, Gbuf, n_chunk, st, energy_in ? &sink : nullptr);
   if (rc) return rc;
-  return ipb_finish(basis, U, ldu, D, (int)nslab, (int64_t)(mj / sizeof(double)), V, j, eta, noise, out, ldo, out_mode, xi, e,
-                    st, nullptr, 0.0, blocks);
+  rc = ipb_finish(basis, U, ldu, D, (int)nslab, (int64_t)(mj / sizeof(double)), V, j, eta, noise, out, ldo, out_mode, xi, e,
+                  st, nullptr, 0.0, blocks);
+  if (rc) return rc;
+  return finish_energy_sums(blocks, energy_in, j, st);
 }
 
 int pls_ipb_step(const pls_ipb_desc *basis, const pls_cost_desc *cost, const double *y, double *U, int64_t ldu, int64_t j,

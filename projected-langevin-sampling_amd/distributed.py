@@ -119,8 +119,11 @@ def sharded_row_quantiles(local_samples: torch.Tensor, q, group=None) -> torch.T
     ops = []
     for peer in range(world):
         if peer != rank:
-            ops.append(dist.P2POp(dist.isend, send[peer], peer, group))
-            ops.append(dist.P2POp(dist.irecv, recv[peer], peer, group))
+            # P2POp addresses its peer by GLOBAL rank; inside a sub-group (ConformalisePLS forwards the caller's group) rank r
+            # of the group is some other process of the job
+            to = dist.get_global_rank(group, peer) if group is not None else peer
+            ops.append(dist.P2POp(dist.isend, send[peer], to, group))
+            ops.append(dist.P2POp(dist.irecv, recv[peer], to, group))
     for req in dist.batch_isend_irecv(ops) if ops else []:
         req.wait()
     mine = quantiles(torch.cat(recv, dim=1).contiguous()) if r1 > r0 else torch.empty((0, len(qs)), dtype=local_samples.dtype,

@@ -12,6 +12,7 @@ import torch
 
 from . import _lib as L
 from . import _ops
+from .basis.base import UNWRITTEN_ENERGY_BITS as UNWRITTEN
 from .basis.base import NoiseSpec
 from .projected_langevin_sampling import PLS
 
@@ -120,6 +121,11 @@ class CapturedTraining:
 
         def body():
             self._start.copy_(self.particles)
+            if self._fused_sums:
+                # one fill per replay: a step route that does not deliver its chunk sums leaves the sentinel behind and
+                # replay() raises instead of handing zeros to the early stop (trainers.UNWRITTEN: a NaN payload no
+                # computation produces; a diverged run's NaN / inf energies are ordinary values)
+                self._sums.view(torch.int64).fill_(UNWRITTEN)
             cur, nxt = self.particles, self._pong
             for s in range(self.k):
                 spec = NoiseSpec(seed=self.seed, step=s, j_offset=basis.j_offset, step_base=self.counter)
@@ -174,7 +180,10 @@ class CapturedTraining:
         if self._fused_sums:
             from .trainers import mean_from_chunk_sums
 
-            rows = self._sums.cpu().tolist()
+            host = self._sums.cpu()
+            if bool((host.view(torch.int64) == UNWRITTEN).any()):
+                raise RuntimeError("CapturedTraining: a captured step did not deliver its energy sums")
+            rows = host.tolist()
             return torch.tensor([mean_from_chunk_sums(r, self.particles.shape[1]) for r in rows], dtype=torch.float64)
         return self.means.cpu()
 

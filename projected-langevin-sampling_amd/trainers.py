@@ -1,6 +1,7 @@
 """Caller of the hot path (drop-in for experiments/trainers.py:139-162 and experiments/early_stopper.py:4-24)."""
 from __future__ import annotations
 
+import time
 from typing import List, Tuple
 
 import numpy as np
@@ -197,7 +198,7 @@ def _train_pls_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs: in
     # every entry has been overwritten (each chunk sum is ONE 8-byte store by the finishing launch into coherent pinned
     # memory; a diverged run's NaN / inf energies are ordinary values here)
     host_bits = host.view(torch.int64)
-    UNWRITTEN = 0x7FF8DEADBEEF0001
+    from .basis.base import UNWRITTEN_ENERGY_BITS as UNWRITTEN
     eta_dev = torch.full((1,), float(step_size), dtype=torch.float64, device=particles.device) if fused_sums else None
     events = [torch.cuda.Event() for _ in range(NB)]
     rng_states = {}
@@ -234,31 +235,37 @@ def _train_pls_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs: in
         spins = 0
         while bool((bits == UNWRITTEN).any()):
             spins += 1
+            if spins > 1024:  # far beyond a fast-path step (tens to hundreds of microseconds): stop burning the core
+                time.sleep(1e-4)
             if spins % 4096 == 0 and torch.cuda.current_stream().query():  # the queue has drained and the slot is still
                 if bool((bits == UNWRITTEN).any()):                       # unwritten: a failed launch, not a slow one
                     raise RuntimeError("train_pls: the step launch did not deliver its energy sums")
 
     energy_potentials: List[float] = []
     final = None
-    for t in range(T):  # iteration t of the plain loop: update t done (U_{t+1}), its energy E(U_{t+1}) wanted
-        # launch t+1 carries E(U_{t+1}); t+2 .. t+depth keep the queue non-empty.  Launch k writes slot (k+1) % NB and the
-        # stop below may return slot (t+1) % NB: k + 1 - (t + 1) <= depth < NB, so that slot is never overwritten
-        while launched < T and launched <= t + depth:
-            launch()
-        if t + 1 < T:
-            wait_for((t + 1) % NB)
-            energy_potential = read_energy((t + 1) % NB)
-        else:  # the energy after the last update has no following launch to ride on
-            energy_potential = _mean_energy(space.energy(bufs[T % NB]))
-        if early_stopper.should_stop(loss=energy_potential, step_size=step_size):
-            if launched > t + 1:
-                torch.set_rng_state(rng_states[t + 1])
-            final = bufs[(t + 1) % NB]
-            break
-        energy_potentials.append(energy_potential)
+    try:
+        for t in range(T):  # iteration t of the plain loop: update t done (U_{t+1}), its energy E(U_{t+1}) wanted
+            # launch t+1 carries E(U_{t+1}); t+2 .. t+depth keep the queue non-empty.  Launch k writes slot (k+1) % NB and
+            # the stop below may return slot (t+1) % NB: k + 1 - (t + 1) <= depth < NB, so that slot is never overwritten
+            while launched < T and launched <= t + depth:
+                launch()
+            if t + 1 < T:
+                wait_for((t + 1) % NB)
+                energy_potential = read_energy((t + 1) % NB)
+            else:  # the energy after the last update has no following launch to ride on
+                energy_potential = _mean_energy(space.energy(bufs[T % NB]))
+            if early_stopper.should_stop(loss=energy_potential, step_size=step_size):
+                if launched > t + 1:
+                    torch.set_rng_state(rng_states[t + 1])
+                final = bufs[(t + 1) % NB]
+                break
+            energy_potentials.append(energy_potential)
+    finally:
+        # up to `depth` launches are still queued: they write the pinned slots and the rotating buffers, which must not go
+        # back to torch's allocators (on ANY exit: a raising early stopper, a failed launch) before they have drained
+        torch.cuda.current_stream().synchronize()
     if final is None:
         final = bufs[T % NB]
-    torch.cuda.current_stream().synchronize()  # speculative launches still read / write the rotating buffers
     space.leave(final, particles)
     return particles, energy_potentials
 

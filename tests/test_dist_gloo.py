@@ -80,3 +80,85 @@ def test_four_ranks_ragged_shards(tmp_path):
 def test_three_ranks_fewer_particles_than_some_shards_expect(tmp_path):
     """a shard may be a single column (J = 4 over 3 ranks: 2, 1, 1)"""
     _run(3, 4, tmp_path)
+
+
+def _spectrum_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from projected_langevin_sampling_amd.basis import spectrum as S
+
+    g = torch.Generator().manual_seed(11)
+    a = torch.randn(40, 40, generator=g, dtype=torch.float64)
+    gram = a @ a.T / 40
+    if rank == 1:  # this rank's Gram matrix rounded differently: one ulp in one entry
+        gram[3, 3] = torch.nextafter(gram[3, 3], torch.tensor(float("inf"), dtype=torch.float64))
+    own = torch.linalg.eigh(gram)
+    for canonical in (None, True):
+        lam, vec = S.shared_spectrum(gram, "cpu", canonical_signs=canonical)
+        both = [torch.empty(41, 40, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(both, torch.cat([lam[None, :], vec], dim=0))
+        assert all(torch.equal(b, both[0]) for b in both), "ranks hold different spectra"
+        if rank == 0:  # rank 0's own decomposition, signs as asked
+            assert torch.equal(lam, own[0]) and torch.equal(vec, S.canonicalise_signs(own[1]) if canonical else own[1])
+        # the same count on every rank at a threshold that sits ON an eigenvalue of rank 0's spectrum
+        mk = int((lam > lam[7]).sum())
+        S.assert_same_count(mk)
+    # opt-out: a basis one rank builds on its own must not enter a collective
+    lam_own, vec_own = S.shared_spectrum(gram, "cpu", group=False)
+    assert torch.equal(lam_own, own[0]) and torch.equal(vec_own, own[1])
+    S.assert_same_count(rank, group=False)
+    # ranks that disagree are told so (every rank raises: the reduction is symmetric)
+    try:
+        S.assert_same_count(30 + rank)
+        raise SystemExit("assert_same_count accepted different counts")
+    except RuntimeError as e:
+        assert "disagree" in str(e)
+    dist.barrier()
+    dist.destroy_process_group()
+    open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+
+
+def test_one_spectrum_for_all_ranks(tmp_path):
+    """OrthonormalBasis under torch.distributed (basis/spectrum.py): rank 0 factorises k(Z,Z)/M and broadcasts, so a rank
+    whose eigh input differs by one ulp still ends with the same eigenvalues, eigenvectors and count, bit for bit
+    (reference: ONE process, ONE torch.linalg.eigh, orthonormal.py:46-68)."""
+    port = _free_port()
+    mp.spawn(_spectrum_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(2))
+
+
+def _subgroup_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from projected_langevin_sampling_amd import distributed as D
+    from projected_langevin_sampling_amd.basis import spectrum as S
+
+    members = [1, 3]  # a sub-group whose group ranks (0, 1) are NOT its global ranks
+    sub = dist.new_group(ranks=members)
+    if rank in members:
+        r, j = members.index(rank), 23
+        pred_full = torch.randn(5, j, generator=torch.Generator().manual_seed(2), dtype=torch.float64)
+        j0, j1 = D.shard_bounds(j, r, 2)
+        qs = [0.1, 0.5, 0.9]
+        want = torch.quantile(pred_full, torch.tensor(qs, dtype=torch.float64), dim=1).T
+        got = D.sharded_row_quantiles(pred_full[:, j0:j1].contiguous(), qs, group=sub)
+        assert torch.equal(got, want), rank
+        a = torch.randn(9, 9, generator=torch.Generator().manual_seed(3 + rank), dtype=torch.float64)  # different per rank
+        lam, vec = S.shared_spectrum(a @ a.T, "cpu", group=sub)
+        both = [torch.empty(10, 9, dtype=torch.float64) for _ in range(2)]
+        dist.all_gather(both, torch.cat([lam[None, :], vec], dim=0), group=sub)
+        assert torch.equal(both[0], both[1])  # group rank 0 (global rank 1) decided
+        S.assert_same_count(4, group=sub)
+    dist.barrier()
+    dist.destroy_process_group()
+    open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+
+
+def test_reductions_inside_a_sub_group(tmp_path):
+    """ConformalisePLS / OrthonormalBasis forward a caller's process group: peers of the point-to-point exchange and the
+    broadcast source are GROUP ranks and must be mapped to global ranks (4 processes, group = global ranks 1 and 3)."""
+    port = _free_port()
+    mp.spawn(_subgroup_worker, args=(4, port, str(tmp_path)), nprocs=4, join=True)
+    assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(4))

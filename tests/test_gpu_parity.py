@@ -727,6 +727,59 @@ def test_captured_training_matches_the_eager_loop(P, cost_idx, epochs, k, patien
     assert torch.equal(got_u, u)
 
 
+def test_energy_sums_are_delivered_on_every_step_route(P):
+    """pls_block_desc.energy_sums (the chunk sums the training loops read instead of a mean launch): the Python side asks
+    for them whenever the basis / cost pair has a Gaussian fast path, while the C side may still take another route -- the
+    inducing-point step outside whitened coordinates under PLS_OPT_IPB_EXPLICIT_INVERSE, the generic N x M x J step under
+    force_generic.  Every route must deliver them: captured and pipelined training equal the plain loop."""
+    from projected_langevin_sampling_amd.basis.base import BlockSpec, UNWRITTEN_ENERGY_BITS
+
+    pr = make_problem(500, 24, 300, 2, seed=17)
+    pr["ls"] = pr["ls"] * 0.5
+    gk = P.pkg.ARDKernel(pr["ls"], 1.3)
+    ipb = P.basis.InducingPointBasis(P.pkg.PLSKernel(gk, pr["z"]), pr["z"], pr["y"][:24], pr["x"], explicit_inverse=True)
+    gc = P.costs.GaussianCost(0.3, pr["y"], P.links.IdentityLinkFunction())
+    pls = P.pkg.PLS(ipb, gc)
+    assert ipb.supports_energy_sums(gc)
+    lib, L = P.pkg._lib.load(), P.pkg._lib
+    eta, seed, epochs = 1e-4, 99, 11
+    u0 = cu(pr["u"])
+
+    def plain():
+        u, nxt, es = u0.clone(), torch.empty_like(u0), []
+        for t in range(epochs):
+            ipb.fused_step(gc, u, eta, out=nxt, new_state=True, noise=P.basis.NoiseSpec(seed=seed, step=t))
+            u, nxt = nxt, u
+            es.append(pls.particle_energy_potential(u).mean().item())
+        return u, es
+
+    L.check(lib.pls_set_option(L.OPT_IPB_EXPLICIT_INVERSE, 1), "pls_set_option")
+    try:
+        want_u, want_e = plain()
+        got_u, got_e = P.pkg.train_pls_captured(pls, u0.clone(), epochs, eta, 1e9, steps_per_replay=4, seed=seed)
+        assert torch.equal(got_u, want_u) and np.allclose(got_e, want_e, rtol=1e-12)
+        # the pipelined loop with injected (already coloured) noise stays in the original coordinates: same route
+        noises = [cu(torch.randn(24, 300, generator=pr["gen"])) for _ in range(epochs)]
+        a_u, a_e = P.pkg.train_pls(pls, u0.clone(), epochs, eta, 1e9, noises=noises)
+        u, es = u0.clone(), []
+        for t in range(epochs):
+            u = u + ipb.fused_step(gc, u, eta, noise=P.basis.NoiseSpec(injected=noises[t]))
+            es.append(pls.particle_energy_potential(u).mean().item())
+        assert relerr(a_u, u) < 1e-12 and np.allclose(a_e, es, rtol=1e-11)
+    finally:
+        L.check(lib.pls_set_option(L.OPT_IPB_EXPLICIT_INVERSE, 0), "pls_set_option")
+    # orthonormal basis, generic route forced: the sums follow the per-particle energies of the same launch
+    ob, gb = build_onb(P, pr)
+    mk = gb.approximation_dimension
+    u = cu(pr["u"][:mk].contiguous())
+    e = torch.empty(300, dtype=torch.float64, device="cuda")
+    sums = torch.empty(2, dtype=torch.float64, device="cuda")
+    sums.view(torch.int64).fill_(UNWRITTEN_ENERGY_BITS)
+    blocks = BlockSpec(300, cu(torch.tensor([eta])), energy_sums=sums.data_ptr())
+    gb.fused_step(gc, u, eta, noise=P.basis.NoiseSpec(seed=1, step=0), input_energy=e, blocks=blocks, force_generic=True)
+    assert relerr(sums, torch.stack([e[:256].sum(), e[256:].sum()])) < 1e-13
+
+
 @pytest.mark.parametrize("mk", [129, 144, 150, 165, 192, 200, 224, 241, 257, 300])
 def test_ranks_just_above_a_tile_multiple(P, mk):
     """Ranks a little above a multiple of 128 take the back-projection in row blocks (csrc/gemm_tn_f64_rows.h: 129 rows
@@ -1879,6 +1932,93 @@ def test_checkpoint_round_trip_resumes_a_sharded_run_exactly(P, tmp_path):
         resumed = run(restored, j0, raw["noise_step"], 5)
         assert torch.equal(resumed, run(shard, j0, 0, 10)), "resume != uninterrupted shard"
         assert relerr(resumed, whole[:, j0:j1]) < 1e-13, "shard != unsharded run"
+
+
+def test_checkpoint_resume_under_the_device_eigh_gauge(P, tmp_path):
+    """The library default outside this suite: eigh on the device (rocSOLVER through torch), signs made canonical.  A run
+    saved under that gauge, a basis REBUILT from the data (a new process would do the same) and a resume: the rebuilt basis has
+    the same fingerprint, the resumed run equals the uninterrupted one bit for bit; a basis in LAPACK's gauge is refused
+    unless its eigenvectors happen to carry the canonical signs already."""
+    from projected_langevin_sampling_amd import checkpoint
+    from projected_langevin_sampling_amd.basis.spectrum import canonicalise_signs
+
+    pr = make_problem(1500, 64, 48, 2, seed=23)
+    gk = P.pkg.ARDKernel(pr["ls"], 1.3)
+
+    def build(dev):
+        return P.basis.OrthonormalBasis(P.pkg.PLSKernel(gk, pr["z"]), pr["z"], pr["x"], 1e-9, verbose=False, eigh_device=dev)
+
+    gb = build("cuda")
+    mk = gb.approximation_dimension
+    assert torch.equal(gb.eigenvectors.cpu(), canonicalise_signs(gb.eigenvectors.cpu()))
+    gc = P.costs.GaussianCost(0.3, pr["y"], P.links.IdentityLinkFunction())
+    eta, seed, j = 1e-4, 77, 48
+    u0 = cu(torch.randn(mk, j, generator=pr["gen"]))
+
+    def run(basis, u, first, count):
+        cur, nxt = u.clone(), torch.empty_like(u)
+        for t in range(first, first + count):
+            basis.fused_step(gc, cur, eta, out=nxt, new_state=True, noise=P.basis.NoiseSpec(seed=seed, step=t))
+            cur, nxt = nxt, cur
+        return cur
+
+    mid = run(gb, u0, 0, 4)
+    path = str(tmp_path / "pls-cuda-gauge.pth")
+    checkpoint.save_pls(P.pkg.PLS(gb, gc), mid, path, noise_step=4)
+    assert torch.load(path)["spectrum_fingerprint"]["mk"] == mk
+    rebuilt = build("cuda")
+    assert rebuilt.spectrum_fingerprint()["sha256"] == gb.spectrum_fingerprint()["sha256"]  # rocSOLVER is run-to-run deterministic
+    _, restored, _, _ = checkpoint.load_pls(P.pkg.PLS(rebuilt, gc), path)
+    assert torch.equal(run(rebuilt, restored, 4, 4), run(gb, u0, 0, 8))
+    host = build("cpu")
+    host_vec = host.eigenvectors.cpu()
+    if torch.equal(host_vec, canonicalise_signs(host_vec)) and host.approximation_dimension == mk:
+        checkpoint.load_pls(P.pkg.PLS(host, gc), path)  # (same gauge by coincidence: accepted)
+    else:
+        with pytest.raises(ValueError, match="gauge|eigen-directions"):
+            checkpoint.load_pls(P.pkg.PLS(host, gc), path)
+        # ... and the canonical form of LAPACK's vectors IS the device gauge (to rounding): accepted
+        canon = P.basis.OrthonormalBasis(P.pkg.PLSKernel(gk, pr["z"]), pr["z"], pr["x"], 1e-9, verbose=False, eigh_device="cpu",
+                                         canonical_signs=True)
+        if canon.approximation_dimension == mk:
+            checkpoint.load_pls(P.pkg.PLS(canon, gc), path)
+
+
+def test_device_eigh_gauge_at_m_1024(P):
+    """bench.py's route (eigh_device="cuda") at the size it runs at: the gauge-invariant operator A^T diag(lam) A and the
+    F-space image A^T dU of one fused Gaussian step from a gauge-covariant start U = A W agree with the host-LAPACK gauge
+    to 1e-8 (north_star's tolerance).  The threshold sits in a gap of the spectrum so that both routes keep one count."""
+    n, m, d, j = 4096, 1024, 8, 256
+    g = torch.Generator().manual_seed(29)
+    x = torch.rand(n, d, generator=g) * 2 - 1
+    z = x[torch.randperm(n, generator=g)[:m]].clone()
+    w = torch.randn(d, generator=g)
+    y = torch.sin(2.0 * (x @ w)) + 0.1 * torch.randn(n, generator=g)
+    ls = 0.5 + torch.rand(d, generator=g)
+    gk = P.pkg.ARDKernel(ls, 1.0)
+    kzz = gk(z, z).cpu()
+    lam_host = torch.linalg.eigvalsh(kzz / m)
+    cand = torch.where((lam_host[1:] > 5e-5) & (lam_host[:-1] < 2e-4))[0]  # (this kernel's spectrum spans 1.5e-5 .. 4e-2)
+    gaps = lam_host[cand + 1] / lam_host[cand].clamp_min(1e-300)
+    k = int(cand[gaps.argmax()])
+    assert gaps.max() > 1.0 + 1e-3, "no usable gap in the spectrum between 5e-5 and 2e-4"
+    threshold = float(torch.sqrt(lam_host[k] * lam_host[k + 1]))
+    bases = [P.basis.OrthonormalBasis(P.pkg.PLSKernel(gk, z), z, x, threshold, verbose=False, eigh_device=dev)
+             for dev in ("cpu", "cuda")]
+    mk = bases[0].approximation_dimension
+    assert mk == bases[1].approximation_dimension == m - 1 - k and mk > 128
+    assert relerr(bases[1].eigenvalues, bases[0].eigenvalues) < 1e-10
+    ops = [(b._A.T * b.eigenvalues[None, :]) @ b._A for b in bases]
+    assert relerr(ops[1], ops[0]) < 1e-8
+    gc = P.costs.GaussianCost(0.3, y, P.links.IdentityLinkFunction())
+    wmat = cu(torch.randn(n, j, generator=g)) / n
+    images = []
+    for b in bases:
+        u = (b._A @ wmat).contiguous()  # covariant start: V -> V S turns A into S A and U into S U
+        eta = 0.5 * float(b.eigenvalues.min())  # eta / lambda_min < 2 (SURVEY H5)
+        du = b.fused_step(gc, u, eta, noise=P.basis.NoiseSpec(none=True))
+        images.append(b.calculate_untransformed_train_prediction_samples(du))
+    assert relerr(images[1], images[0]) < 1e-8
 
 
 def test_user_defined_basis_with_the_reference_signature(P):

@@ -1,5 +1,7 @@
 """CPU: host-side logic of the drop-in layer that needs no GPU (sharding math, stop rule, descriptors,
 argument validation in the C ABI, loud failure without a device)."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -322,3 +324,71 @@ def test_eigh_device_resolution():
         samplers.DEFAULT_EIGH_DEVICE = prev
     with pytest.raises(AssertionError):
         samplers.resolve_eigh_device("tpu", m)
+
+
+def test_sign_canonicalisation_and_spectrum_fingerprint(tmp_path, monkeypatch):
+    """basis/spectrum.py: two eigensolvers that agree up to the sign of every eigenvector give ONE canonical matrix; the
+    fingerprint a checkpoint carries tells a flipped sign, a rotation inside a cluster, another count and another kernel
+    apart from rounding noise; load_pls refuses particles of another gauge (experiments/loaders.py:10-28 would restore them
+    into whatever basis the caller rebuilt)."""
+    from projected_langevin_sampling_amd import checkpoint
+    from projected_langevin_sampling_amd.basis import spectrum as S
+
+    g = torch.Generator().manual_seed(4)
+    a = torch.randn(12, 12, generator=g, dtype=torch.float64)
+    lam, vec = torch.linalg.eigh(a @ a.T / 12)
+    flips = torch.tensor([1.0, -1.0] * 6, dtype=torch.float64)
+    c0, c1 = S.canonicalise_signs(vec), S.canonicalise_signs(vec * flips[None, :])
+    assert torch.equal(c0, c1)
+    assert bool((c0.gather(0, c0.abs().argmax(dim=0)[None, :]) > 0).all())
+    assert torch.allclose(c0 @ torch.diag(lam) @ c0.T, a @ a.T / 12, atol=1e-12)  # still the same decomposition
+    assert S.canonicalise_signs(torch.zeros(3, 0)).shape == (3, 0)
+
+    fp = S.spectrum_fingerprint(lam, vec)
+    assert fp["m"] == 12 and fp["mk"] == 12 and fp["probe"].shape == (12,)
+    assert S.compare_fingerprints(fp, S.spectrum_fingerprint(lam, vec.clone())) is None  # same bits
+    noisy = vec + 1e-13 * torch.randn(12, 12, generator=g, dtype=torch.float64)
+    assert S.compare_fingerprints(fp, S.spectrum_fingerprint(lam * (1 + 1e-14), noisy)) is None  # rounding noise
+    assert "opposite sign" in S.compare_fingerprints(fp, S.spectrum_fingerprint(lam, vec * flips[None, :]))
+    th = 0.3
+    rot = vec.clone()
+    rot[:, 3], rot[:, 4] = math.cos(th) * vec[:, 3] - math.sin(th) * vec[:, 4], math.sin(th) * vec[:, 3] + math.cos(th) * vec[:, 4]
+    assert "rotation" in S.compare_fingerprints(fp, S.spectrum_fingerprint(lam, rot))
+    assert "eigen-directions" in S.compare_fingerprints(fp, S.spectrum_fingerprint(lam[1:], vec[:, 1:]))
+    assert "eigenvalues differ" in S.compare_fingerprints(fp, S.spectrum_fingerprint(lam * 1.01, vec))
+
+    class FakeBasis:
+        def __init__(self, lam, vec):
+            self.lam, self.vec = lam, vec
+
+        def spectrum_fingerprint(self):
+            return S.spectrum_fingerprint(self.lam, self.vec)
+
+    class FakePLS:
+        observation_noise = 0.25
+
+        def __init__(self, basis):
+            self.basis = basis
+
+    monkeypatch.setattr(checkpoint, "_dev", lambda t: t.double())  # CPU-only box: skip the device move
+    u = torch.randn(12, 5, generator=g, dtype=torch.float64)
+    path = str(tmp_path / "pls.pth")
+    checkpoint.save_pls(FakePLS(FakeBasis(lam, vec)), u, path)
+    assert set(torch.load(path)) >= {"particles", "observation_noise", "best_lr", "number_of_epochs", "spectrum_fingerprint"}
+    _, got, _, _ = checkpoint.load_pls(FakePLS(FakeBasis(lam, vec.clone())), path)
+    assert torch.equal(got, u)
+    other = FakePLS(FakeBasis(lam, vec * flips[None, :]))
+    with pytest.raises(ValueError, match="opposite sign"):
+        checkpoint.load_pls(other, path)
+    with pytest.warns(UserWarning, match="opposite sign"):
+        checkpoint.load_pls(other, path, on_gauge_mismatch="warn")
+    checkpoint.load_pls(other, path, on_gauge_mismatch="ignore")
+
+    class NoGauge:  # inducing-point basis, user-defined bases: particles are not gauge dependent
+        observation_noise = 0.25
+        basis = object()
+
+    checkpoint.load_pls(NoGauge(), path)  # a basis without a fingerprint accepts any file ...
+    checkpoint.save_pls(NoGauge(), u, path)
+    assert "spectrum_fingerprint" not in torch.load(path)
+    checkpoint.load_pls(other, path)  # ... and a file without one (the reference's own) loads into any basis
