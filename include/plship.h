@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PLSHIP_ABI_VERSION 3
+#define PLSHIP_ABI_VERSION 4
 
 typedef enum {
   PLS_OK = 0,
@@ -148,6 +148,16 @@ typedef struct {
   int64_t ldlinv;
   const double *LinvT;
   int64_t ldlinvt;
+  /* Optional (ABI 4): scratch for BALANCED triangular products on few output tiles (pls_tri_scratch_bytes(M, J) bytes,
+   * 16-byte aligned).  A triangular operand gives tile row t of a product a contraction of (t + 1) * 64 rows; when every
+   * workgroup is resident at once (M = 1024, J = 1024: 256 tiles on 256 CUs) the launch lasts as long as its heaviest tile,
+   * i.e. as long as the full product.  With the scratch, tile rows t and nti - 1 - t are shared by two workgroups with equal
+   * loads; the heavy tile's two partial sums meet through a scratch slot and are added by whichever workgroup arrives
+   * second (deterministic: a + b == b + a; nobody waits).  Contract: the first 16 KB (flag words) are ZERO when the scratch
+   * is first handed in; every call leaves them zero; calls that may run concurrently (different streams) need different
+   * scratches.  NULL: one tile per workgroup. */
+  void *tri_scratch;
+  size_t tri_scratch_bytes;
 } pls_chol_desc;
 
 /* Inducing-point basis state (reference: basis/inducing_point.py:23-50).
@@ -187,6 +197,16 @@ typedef struct {
   int64_t ldq;
   const double *ct;
   double q_inv_noise;
+  /* Optional (ABI 4): scratch for balanced triangular products (see pls_chol_desc.tri_scratch): the forward solve and the
+   * product with Lc of pls_ipb_step's whitened route, pls_ipb_whiten / _unwhiten, the solves of the other routes. */
+  void *tri_scratch;
+  size_t tri_scratch_bytes;
+  /* Optional (ABI 4): Pt = Lc^-T Q (M x M; pls_ipb_build_step_operator), the whitened operator with the forward solve folded
+   * in: Q S = Q Lc^-1 U = P U, so pls_ipb_step computes dS from U itself and a call is TWO launches (P U with the fused
+   * update + noise, then Lc dS) and 3 M^2 J flop instead of three and 4 M^2 J.  Built for the same observation noise as
+   * Q (q_inv_noise).  A call that asks for energy_in keeps the three-launch route (the energy is a quadratic form in S). */
+  const double *Pt;
+  int64_t ldpt;
 } pls_ipb_desc;
 
 /* Step-size search (experiments/runners.py:331-446): the S candidate step sizes run as S column blocks of ONE particle
@@ -238,7 +258,13 @@ typedef enum pls_option {
   /* Back-projection D = A G of a basis whose function count is above 128 and not a multiple of 128 (two-GEMM path):
    * 1 (default) = one launch of csrc/gemm_tn_f64_rows.h (equal-height tiles, the MFMA count follows the rank in steps of
    * 16, G read once); 0 = 128-row tiles plus 64- / 32- / 16-row remainder launches (round 2). */
-  PLS_OPT_ROW_BLOCKS = 8
+  PLS_OPT_ROW_BLOCKS = 8,
+  /* Triangular products on few output tiles with a scratch in the descriptor (pls_chol_desc.tri_scratch): 1 (default) =
+   * balanced (csrc/gemm_tn_f64_kg.h, gemm_tn_f64_kg_tri_kernel), 0 = one tile per workgroup (A/B runs, tests). */
+  PLS_OPT_TRI_BALANCE = 9,
+  /* pls_ipb_step, Gaussian/identity without energy_in: 1 (default) = dS = -eta (P U - ct) + noise straight from U when the
+   * descriptor carries Pt, 0 = forward solve, then Q S (A/B runs, tests). */
+  PLS_OPT_IPB_STEP_OPERATOR = 10
 } pls_option;
 /* Diagnostic: out[i] = op(x[i]) with the device exp (op 0) / log (op 1) the per-element kernels use (csrc/fmath.h),
  * so that their accuracy can be pinned against libm.  Not on the step path. */
@@ -363,6 +389,10 @@ int pls_chol_build_inverse(const pls_chol_desc *factor, double *Linv, int64_t ld
  * and PLS_OPT_SOLVE_MODE is 1, block forward substitution otherwise).  Y must not alias U. */
 int pls_chol_forward_solve(const pls_chol_desc *factor, const double *U, int64_t ldu, int64_t j, double *Y, int64_t ldy,
                            void *stream);
+
+/* Bytes of pls_chol_desc.tri_scratch / pls_ipb_desc.tri_scratch for products with M rows and up to J columns (16 KB of
+ * flag words, then two 32 KB partial-sum slots per pair of 64-row tile rows and 64-column tile). */
+size_t pls_tri_scratch_bytes(int64_t m, int64_t j);
 
 /* pls_chol_solve with a workspace of pls_chol_solve_workspace_bytes(M, J): with Linv / LinvT in the descriptor (and
  * PLS_OPT_SOLVE_MODE 1) the solve is two triangular products, Lc^-1 U into the workspace and Lc^-T of that into V; a
@@ -492,6 +522,9 @@ int pls_ipb_energy(const pls_ipb_desc *basis, const pls_cost_desc *cost, const d
 size_t pls_ipb_build_whitened_workspace_bytes(int64_t m);
 int pls_ipb_build_whitened(const pls_ipb_desc *basis, double inv_noise, double *Q, int64_t ldq, double *ct, void *workspace,
                            size_t workspace_bytes, void *stream);
+/* Pt (M x M, 16-byte aligned, ldpt even) = Lc^-T Q from the descriptor's Linv and Q (see pls_ipb_desc.Pt); rebuilt whenever
+ * Q is. */
+int pls_ipb_build_step_operator(const pls_ipb_desc *basis, double *Pt, int64_t ldpt, void *stream);
 /* S = Lc^-1 U and back, U = Lc S (neither may alias its input). */
 int pls_ipb_whiten(const pls_ipb_desc *basis, const double *U, int64_t ldu, int64_t j, double *S, int64_t lds, void *stream);
 int pls_ipb_unwhiten(const pls_ipb_desc *basis, const double *S, int64_t lds, int64_t j, double *U, int64_t ldu, void *stream);

@@ -29,6 +29,19 @@ class CholeskyFactor:
         self.Lc, self.LcT, self.Sf, self.Sb, self.jitter = lc, lct, sf, sb, jitter
         self.m = lc.shape[0]
         self.Linv = self.LinvT = None
+        self._tri_scratch = None
+
+    def tri_scratch(self) -> torch.Tensor | None:
+        """Scratch of the balanced triangular products (pls_chol_desc.tri_scratch): allocated ONCE, zeroed, at the size
+        the largest product that takes the few-tiles kernel needs (fewer than 256 tiles of 128 x 128: <= 32 MB whatever M
+        is), so that its address never changes under a captured graph; None when M has a single 64-row tile row (nothing
+        to balance).  The library leaves its flag words zero after every call."""
+        if self._tri_scratch is None and self.m > 64:
+            rows128 = (self.m + 127) // 128
+            j_max = 128 * max(1, -(-256 // rows128))
+            nbytes = int(L.load().pls_tri_scratch_bytes(self.m, j_max))
+            self._tri_scratch = torch.zeros((nbytes + 7) // 8, dtype=torch.float64, device=self.Lc.device)
+        return self._tri_scratch
 
     def build_inverse(self) -> "CholeskyFactor":
         """Linv = Lc^-1 and its transpose (pls_chol_build_inverse: the identity through the block forward substitution).
@@ -53,6 +66,9 @@ class CholeskyFactor:
         if self.Linv is not None:
             d.Linv, d.ldlinv = self.Linv.data_ptr(), L.ld(self.Linv)
             d.LinvT, d.ldlinvt = self.LinvT.data_ptr(), L.ld(self.LinvT)
+            sc = self.tri_scratch()
+            if sc is not None:
+                d.tri_scratch, d.tri_scratch_bytes = sc.data_ptr(), sc.numel() * 8
         return d
 
     def solve(self, rhs: torch.Tensor) -> torch.Tensor:

@@ -90,6 +90,10 @@ class IpbDesc(C.Structure):
         ("ldq", C.c_int64),
         ("ct", C.c_void_p),
         ("q_inv_noise", C.c_double),
+        ("tri_scratch", C.c_void_p),
+        ("tri_scratch_bytes", C.c_size_t),
+        ("Pt", C.c_void_p),
+        ("ldpt", C.c_int64),
     ]
 
 
@@ -108,6 +112,8 @@ class CholDesc(C.Structure):
         ("ldlinv", C.c_int64),
         ("LinvT", C.c_void_p),
         ("ldlinvt", C.c_int64),
+        ("tri_scratch", C.c_void_p),
+        ("tri_scratch_bytes", C.c_size_t),
     ]
 
 
@@ -166,9 +172,11 @@ SIGNATURES = {
     "pls_chol_build_inverse": (C.c_int, [_CHD, _P, _I64, _P, _I64, _P]),
     "pls_chol_forward_solve": (C.c_int, [_CHD, _P, _I64, _I64, _P, _I64, _P]),
     "pls_chol_solve_workspace_bytes": (_SZ, [_I64, _I64]),
+    "pls_tri_scratch_bytes": (_SZ, [_I64, _I64]),
     "pls_chol_solve_ws": (C.c_int, [_CHD, _P, _I64, _I64, _P, _I64, _P, _SZ, _P]),
     "pls_ipb_build_whitened_workspace_bytes": (_SZ, [_I64]),
     "pls_ipb_build_whitened": (C.c_int, [_ID, _D, _P, _I64, _P, _P, _SZ, _P]),
+    "pls_ipb_build_step_operator": (C.c_int, [_ID, _P, _I64, _P]),
     "pls_ipb_whiten": (C.c_int, [_ID, _P, _I64, _I64, _P, _I64, _P]),
     "pls_ipb_unwhiten": (C.c_int, [_ID, _P, _I64, _I64, _P, _I64, _P]),
     "pls_ipb_whitened_workspace_bytes": (_SZ, [_ID, _I64]),
@@ -179,7 +187,7 @@ SIGNATURES = {
     "pls_ipb_step_blocks": (C.c_int, [_ID, _CD, _P, _P, _I64, _I64, _BD, _ND, _P, _I64, _I32, _I32, _P, _P, _SZ, _P]),
 }
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 
@@ -213,6 +221,8 @@ OPT_SOLVE_MODE = 5
 OPT_SMALL_RANK2_MAX = 6
 OPT_SMALL_RANK2_MIN = 7
 OPT_ROW_BLOCKS = 8
+OPT_TRI_BALANCE = 9
+OPT_IPB_STEP_OPERATOR = 10
 TAG_NAMES = {1: "gemm_store", 2: "gemm_cost_deriv", 3: "gemm_cost_value", 4: "gemm_langevin_gaussian",
              5: "langevin_update", 6: "kernel_gram", 7: "other", 8: "small_rank_drift", 9: "small_rank_value",
              10: "tri_solve"}

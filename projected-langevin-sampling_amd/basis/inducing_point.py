@@ -63,6 +63,7 @@ class InducingPointBasis(PLSBasis):
         self._c = None
         self._gauss_key = None
         self._Q = None  # ... and the same operator in whitened coordinates, keyed by (y, observation noise)
+        self._Pt = None
         self._ct = None
         self._q_inv_noise = 0.0
         self._white_key = None
@@ -85,10 +86,15 @@ class InducingPointBasis(PLSBasis):
         if f.Linv is not None:
             d.Linv, d.ldlinv = f.Linv.data_ptr(), L.ld(f.Linv)
             d.LinvT, d.ldlinvt = f.LinvT.data_ptr(), L.ld(f.LinvT)
+        sc = f.tri_scratch()  # balanced triangular products on narrow particle shards (pls_ipb_desc.tri_scratch)
+        if sc is not None:
+            d.tri_scratch, d.tri_scratch_bytes = sc.data_ptr(), sc.numel() * 8
         if with_gaussian and self._B is not None:
             d.B, d.ldb, d.c = self._B.data_ptr(), L.ld(self._B), self._c.data_ptr()
             if self._Q is not None and self.whitened:
                 d.Q, d.ldq, d.ct, d.q_inv_noise = self._Q.data_ptr(), L.ld(self._Q), self._ct.data_ptr(), self._q_inv_noise
+                if self._Pt is not None:
+                    d.Pt, d.ldpt = self._Pt.data_ptr(), L.ld(self._Pt)
         return d
 
     #: take the Gaussian/identity step in whitened coordinates (pls_ipb_build_whitened); False: the round-2 route
@@ -113,7 +119,7 @@ class InducingPointBasis(PLSBasis):
             # the whitened operator was built from the previous y: drop it, or a later call without observation_noise would
             # leave a stale Q in the descriptor (the C side only compares q_inv_noise with the cost's 1 / sigma2)
             self._white_key = None
-            self._Q = self._ct = None
+            self._Q = self._ct = self._Pt = None
             self._q_inv_noise = 0.0
         if observation_noise is None or not self.whitened:
             return
@@ -125,13 +131,20 @@ class InducingPointBasis(PLSBasis):
         ct = torch.empty(m + 1, dtype=torch.float64, device=y_dev.device)
         ws_bytes = lib.pls_ipb_build_whitened_workspace_bytes(m)
         ws = torch.empty(ws_bytes // 8 + 1, dtype=torch.float64, device=y_dev.device)
-        self._Q = None  # (the descriptor of the build call must not carry a stale operator)
+        self._Q = self._Pt = None  # (the descriptor of the build call must not carry a stale operator)
         L.check(
             lib.pls_ipb_build_whitened(self._desc(with_gaussian=True), inv_noise, q.data_ptr(), L.ld(q), ct.data_ptr(),
                                        ws.data_ptr(), ws_bytes, L.stream_ptr()),
             "pls_ipb_build_whitened",
         )
         self._Q, self._ct, self._q_inv_noise, self._white_key = q, ct, inv_noise, wkey
+        # ... and with the forward solve folded in: P^T = Lc^-T Q, so the per-call step computes dS from U itself
+        self._Pt = None
+        if self._chol.Linv is not None:
+            pt = alloc_matrix(m, m, y_dev.device)
+            L.check(lib.pls_ipb_build_step_operator(self._desc(with_gaussian=True), pt.data_ptr(), L.ld(pt), L.stream_ptr()),
+                    "pls_ipb_build_step_operator")
+            self._Pt = pt
 
     def _prepare_for(self, cost) -> None:
         self.prepare_gaussian(cost.y_device(), float(cost.desc().p[0]))

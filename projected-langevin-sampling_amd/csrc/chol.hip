@@ -565,7 +565,7 @@ int chol_solve_launch(const pls_chol_desc *f, const double *U, int64_t ldu, int6
 // kernel cdiv(j, 32) workgroups for 256 CUs); otherwise block forward substitution (strip kernel).
 int chol_forward_solve(const pls_chol_desc *f, const double *U, int64_t ldu, int64_t j, double *Y, int64_t ldy, hipStream_t st) {
   if (f->LinvT && solve_mode() != 0)
-    return gemm_tn_ex(f->LinvT, f->ldlinvt, U, ldu, Y, ldy, f->m, j, f->m, 1.0, 0.0, 1, st);
+    return gemm_tn_ex(f->LinvT, f->ldlinvt, U, ldu, Y, ldy, f->m, j, f->m, 1.0, 0.0, 1, st, f->tri_scratch, f->tri_scratch_bytes);
   if (!f->Sf || !f->Sb) return fail(PLS_ERR_INVALID_ARGUMENT, "forward solve: the factor has neither substitution operators nor its inverse");
   return chol_solve_launch(f, U, ldu, j, Y, ldy, 1, st);
 }
@@ -574,9 +574,11 @@ int chol_forward_solve(const pls_chol_desc *f, const double *U, int64_t ldu, int
 int chol_full_solve(const pls_chol_desc *f, const double *U, int64_t ldu, int64_t j, double *V, int64_t ldv, double *tmp,
                     hipStream_t st) {
   if (tmp && f->Linv && f->LinvT && solve_mode() != 0) {
-    int rc = gemm_tn_ex(f->LinvT, f->ldlinvt, U, ldu, tmp, j, f->m, j, f->m, 1.0, 0.0, 1, st);  // y = Linv u: k <= row
+    int rc = gemm_tn_ex(f->LinvT, f->ldlinvt, U, ldu, tmp, j, f->m, j, f->m, 1.0, 0.0, 1, st, f->tri_scratch,
+                        f->tri_scratch_bytes);  // y = Linv u: k <= row
     if (rc) return rc;
-    return gemm_tn_ex(f->Linv, f->ldlinv, tmp, j, V, ldv, f->m, j, f->m, 1.0, 0.0, 2, st);  // v = Linv^T y: k >= row
+    return gemm_tn_ex(f->Linv, f->ldlinv, tmp, j, V, ldv, f->m, j, f->m, 1.0, 0.0, 2, st, f->tri_scratch,
+                      f->tri_scratch_bytes);  // v = Linv^T y: k >= row
   }
   if (!f->Sf || !f->Sb) return fail(PLS_ERR_INVALID_ARGUMENT, "solve: the factor has neither substitution operators nor its inverse");
   return chol_solve_launch(f, U, ldu, j, V, ldv, 0, st);

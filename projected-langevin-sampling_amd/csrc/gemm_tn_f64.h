@@ -38,6 +38,8 @@ struct GemmShape {
   int64_t kchunk;  // split-K: block (x, y) contracts k in [y * kchunk, min(K, (y + 1) * kchunk)); gridDim.y slabs
   int tri;         // 1: L[k][i] == 0 for k > i (upper-triangular k-major operand), a tile contracts k < i0 + BI only;
                    // 2: L[k][i] == 0 for k < i (lower-triangular), a tile contracts k >= i0 only
+  double *tri_part;     // balanced triangular products (gemm_tn_f64_kg_tri_kernel): partial-sum slots and flag words of
+  unsigned *tri_flags;  // the caller's scratch; NULL elsewhere
 #ifdef PLS_STAMP
   unsigned long long *stamps;  // diagnostic build only: 4 s_memtime stamps per workgroup (never read by the kernel)
 #endif

@@ -38,26 +38,23 @@ struct KgGeom {
   static constexpr int LDS_DOUBLES = (M1 > EXCH) ? M1 : EXCH;
 };
 
-template <int KG, class Epilogue>
-__global__ __launch_bounds__(256 * KG, 4) void gemm_tn_f64_kg_kernel(GemmShape g, Epilogue epi) {
-  static_assert(KG == 1 || KG == 2, "epilogue hand-over is written for one or two k-groups");
+struct KgNoHook {
+  __device__ __forceinline__ void operator()() const {}
+};
+
+// Rows [kbeg, kend) of both operands contracted into the wave's 32 x 32 block `acc` of its k-group's partial sum of the
+// tile at (i0, j0).  acc is accumulated in place (the caller zeroes it); every wave of the workgroup must call this.
+// hook(): called once by every thread right behind the FIRST workgroup barrier of the contraction, in front of which every
+// wave has drained its vector-memory operations (s_waitcnt vmcnt(0): the first operand rows have landed -- and whatever the
+// wave stored before the call has been performed).  The balanced triangular kernel signals a published partial sum from
+// there, so that the store drain rides on the wait the first k-step needs anyway.
+template <int KG, class Hook = KgNoHook>
+__device__ __forceinline__ void kg_contract(const GemmShape &g, int64_t i0, int64_t j0, int64_t kbeg, int64_t kend, double *lds,
+                                            AccFrag<2, 2> &acc, Hook hook = Hook{}) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using G = KgGeom<KG>;
   constexpr int NW = G::NW, NT = G::NT, SROWS = G::SROWS, TILE = G::TILE, BUF = G::BUF;
-  extern __shared__ __attribute__((aligned(16))) double lds[];
   typedef __attribute__((address_space(3))) void *lds_ptr_t;
-
-  int tile_i, tile_j;
-  gemm_tile_coords(blockIdx.x, g.nti, g.ntj, tile_i, tile_j);
-  const int64_t i0 = (int64_t)tile_i * 64, j0 = (int64_t)tile_j * 64;
-  const int split = blockIdx.y;
-  int64_t kbeg = 0, kend = g.K;
-  if (gridDim.y > 1) {
-    kbeg = (int64_t)split * g.kchunk;
-    kend = (kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K;
-  }
-  if (g.tri == 1 && i0 + 64 < kend) kend = i0 + 64;
-  if (g.tri == 2 && i0 > kbeg) kbeg = i0;
   const int64_t klen = kend > kbeg ? kend - kbeg : 0;
   const int nS = (int)(klen / SROWS);           // super-steps copied by DMA
   const int rem = (int)(klen - (int64_t)nS * SROWS);
@@ -99,12 +96,6 @@ __global__ __launch_bounds__(256 * KG, 4) void gemm_tn_f64_kg_kernel(GemmShape g
     rnext += rstep;
   };
 
-  AccFrag<2, 2> acc;
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) acc.v[a][b] = double4_t{0.0, 0.0, 0.0, 0.0};
-
   // K tail (fewer than SROWS rows): through registers with a zero fill, requested NOW so that the whole k-loop hides the
   // latency; thread t stages pairs t and t + NT of each tile.  It is contracted after the loop, in code of its own.
   double2_t tl[2], tr[2];
@@ -145,10 +136,14 @@ __global__ __launch_bounds__(256 * KG, 4) void gemm_tn_f64_kg_kernel(GemmShape g
   // alternative loop bodies -- so there are none: an odd last step and the K tail are contracted after the loop by
   // straight-line code, the odd step still inside the pipeline (its rows are requested and its first fragments fetched by
   // the last pair).
+  bool hooked = false;
   if (nS > 0) {
     double fa[2], fb[2], ga[2], gb[2];
     dma_load(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (what the barrier needs anyway: the rows have landed)
     __syncthreads();
+    hook();
+    hooked = true;
     read_frag(0, 0, fa, fb);
     auto three_quads = [&](int buf) {  // quads 0 .. 2 of the step in `buf` (compile-time after inlining)
       read_frag(buf, 1, ga, gb);
@@ -188,7 +183,10 @@ __global__ __launch_bounds__(256 * KG, 4) void gemm_tn_f64_kg_kernel(GemmShape g
   }
   if (rem > 0) {
     // buffer nS & 1 is the one no step is using (every read of it precedes the loop's last barrier)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (!hooked) hook();
+    hooked = true;
     double *b = lds + (nS & 1) * BUF;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -212,10 +210,101 @@ __global__ __launch_bounds__(256 * KG, 4) void gemm_tn_f64_kg_kernel(GemmShape g
     for (int kq = 0; kq < 4; ++kq) mfma_block(ta[kq], tb[kq]);
     __builtin_amdgcn_sched_barrier(0);
   }
+  if constexpr (!std::is_same<Hook, KgNoHook>::value) {
+    if (!hooked) {  // an empty k range
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      hook();
+    }
+  }
+#else
+  (void)g, (void)i0, (void)j0, (void)kbeg, (void)kend, (void)lds, (void)acc, (void)hook;
+#endif
+}
+
+// Two k-groups: wave (grp, w) keeps rows 16 grp .. + 16 of its 32 x 32 block (acc.v[grp]) and hands the other half to its
+// partner through LDS; afterwards every wave holds a 16 x 32 block `fin` of the SUM (group 0's partial sum first:
+// deterministic) and the workgroup looks like 4 x 2 waves of 16 x 32 to the epilogues.  Ends with a barrier (the epilogue
+// slabs overlap the exchange area).
+// word / value (optional): thread 0 leaves `value` in the LDS word `word` between the first two barriers, so that every
+// thread can read it behind the last one (the balanced triangular kernel passes on a flag it loaded before the call).
+__device__ __forceinline__ void kg_handover(const AccFrag<2, 2> &acc, double *lds, AccFrag<1, 2> &fin, unsigned *word = nullptr,
+                                            unsigned value = 0) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int grp = wave >> 2, w = wave & 3;
+  double *ex = lds + (grp * 4 + w) * 512;
+  __syncthreads();  // (every wave has left the operand tiles; the last step's barrier precedes its last fragment reads)
+#pragma unroll
+  for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ex[(tb * 4 + r) * 64 + lane] = grp ? acc.v[0][tb][r] : acc.v[1][tb][r];
+  if (word && threadIdx.x == 0) word[0] = value;
+  __syncthreads();
+  const double *ox = lds + ((grp ^ 1) * 4 + w) * 512;
+#pragma unroll
+  for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double mine = grp ? acc.v[1][tb][r] : acc.v[0][tb][r];
+      const double other = ox[(tb * 4 + r) * 64 + lane];
+      fin.v[0][tb][r] = grp ? other + mine : mine + other;  // group 0's partial sum first
+    }
+  __syncthreads();
+}
+
+// The epilogue of a two-group tile on the waves' 16 x 32 blocks of the sum.
+template <class Epilogue>
+__device__ __forceinline__ void kg_finish2(const GemmShape &g, const Epilogue &epi, const AccFrag<1, 2> &fin, int64_t i0,
+                                           int64_t j0, int tile_i, int split, double *lds) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int grp = wave >> 2, w = wave & 3, wr = w >> 1, wc = w & 1;
+  const bool edge = (i0 + 64 > g.I) || (j0 + 64 > g.J);
+  const int v = (2 * wr + grp) * 2 + wc;  // wave index in the 4 x 2 arrangement of 16 x 32 blocks
+  const int64_t iw = i0 + (2 * wr + grp) * 16, jw = j0 + wc * 32;
+  if constexpr (Epilogue::kDirect) {
+    if constexpr (Epilogue::template direct_tile<1, 2>()) {
+      if (!edge && epi.direct_ld() < kDirectMaxLd) {
+        epi.template apply_direct<1, 2>(fin, iw, jw, lane, split, lds + v * 128);
+        return;
+      }
+    }
+  }
+  epi.template apply<1, 2>(fin, iw, jw, lane, v, g.I, g.J, tile_i, split, lds);
+}
+
+template <int KG, class Epilogue>
+__global__ __launch_bounds__(256 * KG, 4) void gemm_tn_f64_kg_kernel(GemmShape g, Epilogue epi) {
+  static_assert(KG == 1 || KG == 2, "epilogue hand-over is written for one or two k-groups");
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+
+  int tile_i, tile_j;
+  gemm_tile_coords(blockIdx.x, g.nti, g.ntj, tile_i, tile_j);
+  const int64_t i0 = (int64_t)tile_i * 64, j0 = (int64_t)tile_j * 64;
+  const int split = blockIdx.y;
+  int64_t kbeg = 0, kend = g.K;
+  if (gridDim.y > 1) {
+    kbeg = (int64_t)split * g.kchunk;
+    kend = (kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K;
+  }
+  if (g.tri == 1 && i0 + 64 < kend) kend = i0 + 64;
+  if (g.tri == 2 && i0 > kbeg) kbeg = i0;
+
+  AccFrag<2, 2> acc;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc.v[a][b] = double4_t{0.0, 0.0, 0.0, 0.0};
+  kg_contract<KG>(g, i0, j0, kbeg, kend, lds, acc);
 
   // ---- hand-over between the k-groups, then the epilogue on the sum ----
-  const bool edge = (i0 + 64 > g.I) || (j0 + 64 > g.J);
   if constexpr (KG == 1) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wr = (wave & 3) >> 1, wc = wave & 1;
+    const bool edge = (i0 + 64 > g.I) || (j0 + 64 > g.J);
     const int64_t iw = i0 + wr * 32, jw = j0 + wc * 32;
     if constexpr (Epilogue::kDirect) {
       if constexpr (Epilogue::template direct_tile<2, 2>()) {
@@ -227,36 +316,208 @@ __global__ __launch_bounds__(256 * KG, 4) void gemm_tn_f64_kg_kernel(GemmShape g
     }
     epi.template apply<2, 2>(acc, iw, jw, lane, wave, g.I, g.J, tile_i, split, lds);
   } else {
-    // wave (grp, w) keeps rows 16 grp .. + 16 of its 32 x 32 block (acc.v[grp]) and hands the other half to its partner
-    double *ex = lds + (grp * 4 + w) * 512;
-    __syncthreads();  // (every wave has left the operand tiles; the last step's barrier precedes its last fragment reads)
-#pragma unroll
-    for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) ex[(tb * 4 + r) * 64 + lane] = grp ? acc.v[0][tb][r] : acc.v[1][tb][r];
-    __syncthreads();
-    const double *ox = lds + ((grp ^ 1) * 4 + w) * 512;
     AccFrag<1, 2> fin;
+    kg_handover(acc, lds, fin);
+    kg_finish2(g, epi, fin, i0, j0, tile_i, split, lds);
+  }
+#else
+  (void)g, (void)epi;
+#endif
+}
+
+// ---- balanced triangular products --------------------------------------------------------------------------------
+// A triangular k-major operand (tri = 1: L[k][i] == 0 for k > i; tri = 2: for k < i) gives tile row t a k range of
+// (t + 1) * 64 (resp. K - 64 t) rows: with one 64 x 64 tile per workgroup and every workgroup resident at once (M = 1024,
+// J = 1024: 256 tiles on 256 CUs), the launch lasts as long as its heaviest tile -- the FULL contraction, for half the
+// flops (34 us at 0.40 of peak against 34 us for the full product).  No assignment of whole tiles to workgroups balances
+// that (the heaviest tile alone is twice the average load), so the tile rows are paired (t, nti - 1 - t: together nti + 1
+// row blocks whatever t is) and every pair is contracted by TWO workgroups with equal loads:
+//     A: the first half of the pair's rows -- all of them rows of the heavy tile -- into a partial sum;
+//     B: the rest of the heavy tile into a second partial sum, then the light tile, complete, with its epilogue.
+// The heavy tile is finished by whichever of A and B arrives second: the first one leaves its 64 x 64 partial sum (32 KB, in
+// the register layout: coalesced 512-byte rows) in a scratch slot and bumps the tile's flag; the second one finds the flag
+// set, adds the other's partial sum to its own registers and runs the epilogue.  B reaches that point first by construction
+// (its share of the heavy tile is the smaller one), so A looks at the flag BEFORE writing anything and normally skips its
+// own write.  Nobody spins or waits, so the scheme needs no co-residency; the sum of two partial sums does not depend on
+// who adds them (a + b == b + a), so the result is deterministic; the finisher clears the flag, so the scratch arrives zero
+// at the next launch (captured graphs replay the same arguments).  Stream-K with a fixed two-way split, in short.
+//   scratch: GemmShape::tri_flags (one word per pair and column tile, zero on entry, zero on exit) and tri_part (two 4096-
+//   double slots per pair and column tile); kg_tri_scratch_bytes() below.  blockIdx -> (virtual row 2 pair + role, column
+//   tile) goes through the usual XCD remap, which keeps A and B of a tile on ONE XCD (their ids are neighbours), so the
+//   partial sum normally travels through that XCD's L2.
+constexpr int kKgTriFlagBytes = 16384;  // 4096 flag words in front of the partial slots
+
+__host__ __device__ inline size_t kg_tri_scratch_bytes(int64_t I, int64_t J) {
+  const int64_t pairs = ((I + 63) / 64 + 1) / 2, ntj = (J + 63) / 64;
+  return (size_t)kKgTriFlagBytes + (size_t)pairs * ntj * 2 * 4096 * sizeof(double);
+}
+
+// The partial sums of a heavy tile that two workgroups share.
+//
+// Visibility (per-XCD L2s are not coherent with each other, a CU's L1 is never refreshed by another CU's stores): an
+// agent-scope release / acquire pair -- __threadfence() -- writes back and invalidates whole caches (buffer_wbl2 /
+// buffer_inv), and with 256 workgroups doing that in the middle of their k-loops the launch took 99 us instead of 35 (the
+// operand panels of every other workgroup on the XCD went with it).  Instead every byte of a partial sum is stored
+// write-through (sc1, 16 bytes per lane: a wave instruction writes eight whole 128-byte lines), every storing wave drains
+// its stores (s_waitcnt vmcnt(0)), the workgroup's barrier collects the waves, and ONE lane bumps the flag with an
+// agent-scope atomic; the reader learns of the partial sum from the value its own atomic add returned (or from an sc1 load
+// of the flag) and loads every byte of it with sc1 loads, which are served past the L1: no cache-wide operation anywhere.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+constexpr int kKgSc1 = 16;  // aux bit of the raw buffer instructions: sc1
+
+// slot layout: [register pair 0 .. 3][thread 0 .. 511] of 16 bytes
+__device__ __forceinline__ void kg_tri_publish(const AccFrag<1, 2> &fin, double *mine) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(mine, 0, 4096 * 8, 0x00020000);
+  const int voff = threadIdx.x * 16;
 #pragma unroll
-    for (int tb = 0; tb < 2; ++tb)
+  for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const double mine = grp ? acc.v[1][tb][r] : acc.v[0][tb][r];
-        const double other = ox[(tb * 4 + r) * 64 + lane];
-        fin.v[0][tb][r] = grp ? other + mine : mine + other;  // group 0's partial sum first
-      }
-    __syncthreads();  // the epilogue slabs overlap the exchange area
-    const int v = (2 * wr + grp) * 2 + wc;  // wave index in the 4 x 2 arrangement of 16 x 32 blocks
-    const int64_t iw = i0 + (2 * wr + grp) * 16, jw = j0 + wc * 32;
-    if constexpr (Epilogue::kDirect) {
-      if constexpr (Epilogue::template direct_tile<1, 2>()) {
-        if (!edge && epi.direct_ld() < kDirectMaxLd) {
-          epi.template apply_direct<1, 2>(fin, iw, jw, lane, split, lds + v * 128);
-          return;
-        }
+    for (int h = 0; h < 2; ++h) {
+      const double2_t v{fin.v[0][tb][2 * h], fin.v[0][tb][2 * h + 1]};
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs, voff, (tb * 2 + h) * 8192, kKgSc1);
+    }
+#else
+  (void)fin, (void)mine;
+#endif
+}
+
+// fin (+)= the partial sum in `slot` (every byte by an sc1 load)
+template <bool ADD>
+__device__ __forceinline__ void kg_tri_fetch(AccFrag<1, 2> &fin, const double *slot) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(slot), 0, 4096 * 8, 0x00020000);
+  const int voff = threadIdx.x * 16;
+  double2_t o[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) o[p] = __builtin_bit_cast(double2_t, __builtin_amdgcn_raw_buffer_load_b128(rt, voff, p * 8192, kKgSc1));
+#pragma unroll
+  for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if constexpr (ADD) {
+        fin.v[0][tb][2 * h] += o[tb * 2 + h][0];
+        fin.v[0][tb][2 * h + 1] += o[tb * 2 + h][1];
+      } else {
+        fin.v[0][tb][2 * h] = o[tb * 2 + h][0];
+        fin.v[0][tb][2 * h + 1] = o[tb * 2 + h][1];
       }
     }
-    epi.template apply<1, 2>(fin, iw, jw, lane, v, g.I, g.J, tile_i, split, lds);
+#else
+  (void)fin, (void)slot;
+#endif
+}
+
+// drain this wave's stores, collect the workgroup, bump the flag (one lane); returns the flag's previous value to every thread
+__device__ __forceinline__ unsigned kg_tri_signal_and_wait(unsigned *flag, unsigned *word) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave: its write-through stores have been performed
+  __syncthreads();
+  if (threadIdx.x == 0) word[0] = __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const unsigned seen = word[0];
+  __syncthreads();
+  return seen;
+#else
+  (void)flag, (void)word;
+  return 0;
+#endif
+}
+
+template <class Epilogue>
+__global__ __launch_bounds__(512, 4) void gemm_tn_f64_kg_tri_kernel(GemmShape g, Epilogue epi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  __shared__ unsigned word[1];  // thread 0's view of the tile's flag for the whole workgroup
+  const int tid = threadIdx.x;
+  const int pairs = (g.nti + 1) >> 1;
+  int vrow, tile_j;
+  gemm_tile_coords(blockIdx.x, 2 * pairs, g.ntj, vrow, tile_j);
+  const int pair = vrow >> 1, role = vrow & 1;
+  const int64_t j0 = (int64_t)tile_j * 64;
+  // the pair's tile rows and their k ranges; "heavy" has the longer range
+  const int t_lo = pair, t_hi = g.nti - 1 - pair;
+  const int heavy = (g.tri == 1) ? t_hi : t_lo, light = (g.tri == 1) ? t_lo : t_hi;
+  auto k_range = [&](int t, int64_t &kb, int64_t &ke) {
+    kb = 0;
+    ke = g.K;
+    const int64_t i0 = (int64_t)t * 64;
+    if (g.tri == 1 && i0 + 64 < ke) ke = i0 + 64;
+    if (g.tri == 2) kb = i0 < g.K ? i0 : g.K;
+  };
+  int64_t hb, he, lb, le;
+  k_range(heavy, hb, he);
+  k_range(light, lb, le);
+  const bool have_light = light != heavy;
+  const int64_t len_h = he - hb, len_l = have_light ? le - lb : 0;
+  int64_t a_len = ((len_h + len_l + 1) / 2 + 31) / 32 * 32;  // A's share: half of the pair's rows, whole super-steps
+  if (a_len > len_h) a_len = len_h;
+  const bool shared = a_len < len_h;  // B holds a part of the heavy tile
+  unsigned *flag = g.tri_flags + ((int64_t)pair * g.ntj + tile_j);
+  double *slot_a = g.tri_part + ((int64_t)pair * g.ntj + tile_j) * 2 * 4096, *slot_b = slot_a + 4096;
+  const int64_t ih = (int64_t)heavy * 64, il = (int64_t)light * 64;
+
+  AccFrag<2, 2> acc;
+  AccFrag<1, 2> fin;
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc.v[a][b] = double4_t{0.0, 0.0, 0.0, 0.0};
+  };
+  auto finish_heavy_with = [&](const double *theirs) {  // fin += the other partial sum; epilogue; flag back to zero
+    kg_tri_fetch<true>(fin, theirs);
+    if (tid == 0) __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    kg_finish2(g, epi, fin, ih, j0, heavy, 0, lds);
+  };
+
+  if (role == 0) {
+    // ---- A: the first a_len rows of the heavy tile ----
+    zero_acc();
+    kg_contract<2>(g, ih, j0, hb, hb + a_len, lds, acc);
+    unsigned pre = 0;
+    if (shared && tid == 0) pre = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (flies under the hand-over)
+    kg_handover(acc, lds, fin, word, pre);
+    if (!shared) {
+      kg_finish2(g, epi, fin, ih, j0, heavy, 0, lds);
+      return;
+    }
+    if (word[0]) {  // the usual case: B's partial sum is there (its share of the heavy tile is the smaller one)
+      finish_heavy_with(slot_b);
+      return;
+    }
+    __syncthreads();  // (everybody has read the word)
+    kg_tri_publish(fin, slot_a);
+    if (kg_tri_signal_and_wait(flag, word)) finish_heavy_with(slot_b);  // B arrived in between
+    return;
+  }
+
+  // ---- B: the rest of the heavy tile, then the light tile ----
+  if (shared) {
+    zero_acc();
+    kg_contract<2>(g, ih, j0, hb + a_len, he, lds, acc);
+    kg_handover(acc, lds, fin);
+    kg_tri_publish(fin, slot_b);
+    if (!have_light) {  // (the middle row of an odd count pairs with itself)
+      if (kg_tri_signal_and_wait(flag, word)) finish_heavy_with(slot_a);
+      return;
+    }
+  }
+  if (have_light) {
+    unsigned before = 0;  // thread 0: what the flag held before this workgroup's add
+    zero_acc();
+    // the flag moves behind the light tile's first barrier: every wave has drained the stores of its partial sum there, and
+    // nobody waits for the atomic's answer until the light tile is done
+    kg_contract<2>(g, il, j0, lb, le, lds, acc, [&]() {
+      if (shared && tid == 0) before = __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    });
+    kg_handover(acc, lds, fin, word, before);
+    kg_finish2(g, epi, fin, il, j0, light, 0, lds);
+    if (shared && word[0]) {  // A had been there first (rare): its partial sum waits in its slot, this one's in slot_b
+      __syncthreads();  // (the light tile's epilogue slabs)
+      kg_tri_fetch<false>(fin, slot_b);
+      finish_heavy_with(slot_a);
+    }
   }
 #else
   (void)g, (void)epi;

@@ -439,14 +439,52 @@ static int launch_gemm_kg(GemmShape g, const Epi &epi, hipStream_t st) {
   return check_launch("gemm_tn_f64_kg");
 }
 
+// Balanced triangular product (gemm_tn_f64_kg_tri_kernel): tile rows paired, every pair shared by two workgroups with equal
+// loads, the heavy tile finished by whichever arrives second.  scratch: the caller's, zero flag words on entry and on exit.
+static std::atomic<int64_t> g_tri_balance{1};  // pls_set_option(PLS_OPT_TRI_BALANCE): 0 off (one tile per workgroup), 1 on
+
+struct TriScratch {
+  void *ptr = nullptr;
+  size_t bytes = 0;
+};
+
+static bool tri_balanced_ok(int64_t I, int64_t J, int64_t K, int tri, const TriScratch &sc) {
+  if (!tri || g_tri_balance.load() == 0 || !sc.ptr || (reinterpret_cast<uintptr_t>(sc.ptr) & 15) != 0) return false;
+  const int64_t pairs = (cdiv(I, 64) + 1) / 2, ntj = cdiv(J, 64);
+  // two or more tile rows (a single row has nothing to balance), flags within their 16 KB, the slots within the scratch
+  return cdiv(I, 64) >= 2 && K >= 64 && pairs * ntj <= kKgTriFlagBytes / 4 && sc.bytes >= kg_tri_scratch_bytes(I, J);
+}
+
+template <class Epi>
+static int launch_gemm_kg_tri(GemmShape g, const Epi &epi, const TriScratch &sc, hipStream_t st) {
+  using G = KgGeom<2>;
+  constexpr size_t lds_bytes = (size_t)G::LDS_DOUBLES * sizeof(double);
+  auto kern = gemm_tn_f64_kg_tri_kernel<Epi>;
+  static std::atomic<uint64_t> lds_ready{0};
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds_bytes, lds_ready)) return rc;
+  g.nti = (int)cdiv(g.I, 64);
+  g.ntj = (int)cdiv(g.J, 64);
+  g.tri_flags = static_cast<unsigned *>(sc.ptr);
+  g.tri_part = reinterpret_cast<double *>(static_cast<char *>(sc.ptr) + kKgTriFlagBytes);
+  const int64_t nwg = (int64_t)2 * ((g.nti + 1) / 2) * g.ntj;
+  {
+    LaunchScope scope(Epi::kTag, st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg, 1), dim3(G::NT), lds_bytes, st, g, epi);
+  }
+  return check_launch("gemm_tn_f64_kg_tri");
+}
+
 // launch_gemm of gemm_launch.h plus the k-split configurations (this translation unit's epilogues only)
 template <class Epi>
 static int launch_gemm_any(const double *L, int64_t ldl, const double *R, int64_t ldr, int64_t I, int64_t J, int64_t K,
-                           const Epi &epi, hipStream_t st, int64_t kchunk = 0, int tri = 0) {
+                           const Epi &epi, hipStream_t st, int64_t kchunk = 0, int tri = 0, TriScratch scratch = TriScratch{}) {
   const int64_t nsplit = (kchunk > 0 && kchunk < K) ? cdiv(K, kchunk) : 1;
   const GemmCfg cfg = pick_gemm_cfg(L, ldl, R, ldr, I, J, K, nsplit);
   if (cfg == CFG_KG2 || cfg == CFG_KG1) {
     GemmShape g{L, ldl, R, ldr, I, J, K, 0, 0, 0, tri};
+    if constexpr (Epi::kTag == PLS_TAG_GEMM_STORE) {  // (only the storing epilogues are ever launched with a triangular operand)
+      if (cfg == CFG_KG2 && tri_balanced_ok(I, J, K, tri, scratch)) return launch_gemm_kg_tri(g, epi, scratch, st);
+    }
     return cfg == CFG_KG2 ? launch_gemm_kg<2>(g, epi, st) : launch_gemm_kg<1>(g, epi, st);
   }
   return launch_gemm(L, ldl, R, ldr, I, J, K, epi, st, kchunk, tri);
@@ -1222,6 +1260,7 @@ static int validate_noise(const pls_noise_desc *n, int64_t rows) {
 // ---- small projection ranks: fused kernels (small_rank.h) -------------------------------------------------------
 static std::atomic<int64_t> g_small_rank_max{128};  // pls_set_option(PLS_OPT_SMALL_RANK_MAX)
 static std::atomic<int64_t> g_ipb_explicit_inverse{0};  // pls_set_option(PLS_OPT_IPB_EXPLICIT_INVERSE)
+static std::atomic<int64_t> g_ipb_step_operator{1};     // pls_set_option(PLS_OPT_IPB_STEP_OPERATOR): 1 = Pt route when the descriptor has it
 static std::atomic<int64_t> g_solve_mode{1};  // pls_set_option(PLS_OPT_SOLVE_MODE): 0 block substitution, 1 inverse-factor products where available
 int64_t solve_mode() { return g_solve_mode.load(); }
 
@@ -1389,7 +1428,7 @@ static int stream_cost(const double *Lf, int64_t ldlf, const double *Lb, int64_t
 }
 
 int gemm_tn_ex(const double *L, int64_t ldl, const double *R, int64_t ldr, double *C, int64_t ldc, int64_t I, int64_t J,
-               int64_t K, double alpha, double beta, int tri, hipStream_t st) {
+               int64_t K, double alpha, double beta, int tri, hipStream_t st, void *tri_scratch, size_t tri_scratch_bytes) {
   PLS_REQUIRE(L && R && C, "gemm_tn: NULL pointer");
   PLS_REQUIRE(I >= 0 && J >= 0 && K >= 0, "gemm_tn: negative size");
   PLS_REQUIRE(ldl >= I && ldr >= J && ldc >= J, "gemm_tn: leading dimension too small (ldl=%lld I=%lld ldr=%lld J=%lld ldc=%lld)",
@@ -1398,7 +1437,7 @@ int gemm_tn_ex(const double *L, int64_t ldl, const double *R, int64_t ldr, doubl
   EpiStore e{C, ldc, alpha, beta, 0};
   // many tiles and a row count off the 128-row grid (the projection A = V~^T k(Z,X) of a thresholded basis): row blocks
   if (tri == 0 && gemm_rows_ok(L, ldl, R, ldr, I, J, K, ldc, 1)) return launch_gemm_rows(L, ldl, R, ldr, I, J, K, e, st, 0);
-  return launch_gemm_any(L, ldl, R, ldr, I, J, K, e, st, 0, tri);
+  return launch_gemm_any(L, ldl, R, ldr, I, J, K, e, st, 0, tri, TriScratch{tri_scratch, tri_scratch_bytes});
 }
 
 // out[b] = mean of e[b * bc, min(j, (b + 1) * bc)): one workgroup per column block; chunk sums of 256 consecutive entries
@@ -1511,6 +1550,8 @@ extern "C" {
 const char *pls_last_error(void) { return g_last_error.c_str(); }
 int pls_abi_version(void) { return PLSHIP_ABI_VERSION; }
 
+size_t pls_tri_scratch_bytes(int64_t m, int64_t j) { return (m > 0 && j > 0) ? kg_tri_scratch_bytes(m, j) : 0; }
+
 int pls_set_option(int32_t option, int64_t value) {
   switch (option) {
     case PLS_OPT_SMALL_RANK_MAX:
@@ -1545,6 +1586,14 @@ int pls_set_option(int32_t option, int64_t value) {
       PLS_REQUIRE(value == 0 || value == 1, "set_option: row-block mode must be 0 or 1");
       g_row_blocks_mode.store(value);
       return PLS_OK;
+    case PLS_OPT_TRI_BALANCE:
+      PLS_REQUIRE(value == 0 || value == 1, "set_option: triangular balance must be 0 or 1");
+      g_tri_balance.store(value);
+      return PLS_OK;
+    case PLS_OPT_IPB_STEP_OPERATOR:
+      PLS_REQUIRE(value == 0 || value == 1, "set_option: step operator mode must be 0 or 1");
+      g_ipb_step_operator.store(value);
+      return PLS_OK;
     default: return fail(PLS_ERR_INVALID_ARGUMENT, "set_option: unknown option %d", (int)option);
   }
 }
@@ -1567,6 +1616,8 @@ int64_t pls_get_option(int32_t option) {
     case PLS_OPT_KSPLIT_MODE: return g_ksplit_mode.load();
     case PLS_OPT_KSPLIT_MAX_TILES: return g_ksplit_max_tiles.load();
     case PLS_OPT_ROW_BLOCKS: return g_row_blocks_mode.load();
+    case PLS_OPT_TRI_BALANCE: return g_tri_balance.load();
+    case PLS_OPT_IPB_STEP_OPERATOR: return g_ipb_step_operator.load();
     default: return -1;
   }
 }
@@ -2033,7 +2084,8 @@ static int validate_ipb(const pls_ipb_desc *b) {
 }
 
 static pls_chol_desc ipb_factor(const pls_ipb_desc *b) {
-  return pls_chol_desc{b->m, nullptr, 0, b->LcT, b->ldlct, b->Sf, b->ldsf, b->Sb, b->ldsb, b->Linv, b->ldlinv, b->LinvT, b->ldlinvt};
+  return pls_chol_desc{b->m, nullptr, 0, b->LcT, b->ldlct, b->Sf, b->ldsf, b->Sb, b->ldsb, b->Linv, b->ldlinv, b->LinvT, b->ldlinvt,
+                       b->tri_scratch, b->tri_scratch_bytes};
 }
 
 // V (m x j, ld j) = k(Z,Z)^-1 U = Lc^-T Lc^-1 U.  Two triangular products with the inverse factor when the descriptor
@@ -2093,7 +2145,8 @@ static int ipb_finish(const pls_ipb_desc *basis, const double *U, int64_t ldu, c
     int rc = check_launch("normal_fill");
     if (rc) return rc;
     // e = Lc xi :  L[k][i] = LcT[k][i] = Lc[i][k], zero for k > i: a triangular product (half the contraction)
-    rc = gemm_tn_ex(basis->LcT, basis->ldlct, xi_buf, j, e_buf, j, basis->m, j, basis->m, 1.0, 0.0, 1, st);
+    rc = gemm_tn_ex(basis->LcT, basis->ldlct, xi_buf, j, e_buf, j, basis->m, j, basis->m, 1.0, 0.0, 1, st, basis->tri_scratch,
+                    basis->tri_scratch_bytes);
     if (rc) return rc;
     nz.kind = PLS_NOISE_INJECTED;
     nz.xi = e_buf;
@@ -2192,19 +2245,30 @@ static int ipb_step_impl(const pls_ipb_desc *basis, const pls_cost_desc *cost, c
   if (ipb_fast_path(basis, cost, force_generic) && ipb_whitened_ok(basis, cost)) {
     // whitened route: S = Lc^-1 U -> dS (fused kernel, energy by-product) -> out = [U +] Lc dS
     double *Sw = V, *Wd = xi, *epart = e;  // (m x j each; the partial rows of the energy fit: 2 cdiv(m, 128) <= m + 1)
-    const pls_chol_desc f = ipb_factor(basis);
-    rc = chol_forward_solve(&f, U, ldu, j, Sw, j, st);
-    if (rc) return rc;
     NoiseP nz = make_noisep(noise, blocks);
     const bool injected = nz.kind == PLS_NOISE_INJECTED;
     const double *e_inj = injected ? nz.xi : nullptr;
     const int64_t ld_inj = nz.ldxi;
     if (injected) nz.kind = PLS_NOISE_NONE;  // (the injected noise is already coloured: it enters after the product with Lc)
-    rc = fast_step_launch(ipb_whitened_op(basis), Sw, j, j, make_etap(eta, blocks), nz, Wd, j, 0, energy_in, epart,
-                          2 * mj, st, "ipb_step", blocks ? blocks->energy_sums : nullptr);
+    if (basis->Pt && !energy_in && g_ipb_step_operator.load() != 0) {
+      // dS straight from U: Q S = Q Lc^-1 U = P U with P^T = Lc^-T Q in the descriptor (pls_ipb_build_step_operator), so
+      // the forward solve is folded into the operator -- two launches and 3 M^2 J flop per call instead of three and 4 M^2 J.
+      // (The energy by-product is a quadratic form in S, so a call that wants it keeps the route below.)
+      FastOp op = ipb_whitened_op(basis);
+      op.B = basis->Pt;
+      op.ldb = basis->ldpt;
+      rc = fast_step_launch(op, U, ldu, j, make_etap(eta, blocks), nz, Wd, j, 0, nullptr, nullptr, 0, st, "ipb_step");
+    } else {
+      const pls_chol_desc f = ipb_factor(basis);
+      rc = chol_forward_solve(&f, U, ldu, j, Sw, j, st);
+      if (rc) return rc;
+      rc = fast_step_launch(ipb_whitened_op(basis), Sw, j, j, make_etap(eta, blocks), nz, Wd, j, 0, energy_in, epart,
+                            2 * mj, st, "ipb_step", blocks ? blocks->energy_sums : nullptr);
+    }
     if (rc) return rc;
     EpiIpbFinish fin{out, ldo, U, ldu, out_mode, make_etap(eta, blocks), e_inj, ld_inj};
-    return launch_gemm_any(basis->LcT, basis->ldlct, Wd, j, basis->m, j, basis->m, fin, st, 0, 1);
+    return launch_gemm_any(basis->LcT, basis->ldlct, Wd, j, basis->m, j, basis->m, fin, st, 0, 1,
+                           TriScratch{basis->tri_scratch, basis->tri_scratch_bytes});
   }
   rc = ipb_apply_kinv(basis, U, ldu, j, V, stream, xi);  // (xi is free until the noise is drawn)
   if (rc) return rc;
@@ -2370,6 +2434,16 @@ int pls_ipb_build_whitened(const pls_ipb_desc *basis, double inv_noise, double *
   return check_launch("scale_copy");
 }
 
+int pls_ipb_build_step_operator(const pls_ipb_desc *basis, double *Pt, int64_t ldpt, void *stream) {
+  int rc = validate_ipb(basis);
+  if (rc) return rc;
+  PLS_REQUIRE(basis->Q && basis->Linv, "ipb_build_step_operator: the descriptor needs Q (pls_ipb_build_whitened) and Linv");
+  PLS_REQUIRE(Pt && ldpt >= basis->m && (ldpt & 1) == 0 && (reinterpret_cast<uintptr_t>(Pt) & 15) == 0,
+              "ipb_build_step_operator: Pt must be 16-byte aligned with an even leading dimension >= M");
+  // Pt[i][j] = sum_k Linv[k][i] Q[k][j]  (Linv lower triangular: only k >= i)
+  return gemm_tn_ex(basis->Linv, basis->ldlinv, basis->Q, basis->ldq, Pt, ldpt, basis->m, basis->m, basis->m, 1.0, 0.0, 2, S(stream));
+}
+
 int pls_ipb_whiten(const pls_ipb_desc *basis, const double *U, int64_t ldu, int64_t j, double *Sw, int64_t lds, void *stream) {
   int rc = validate_ipb(basis);
   if (rc) return rc;
@@ -2385,7 +2459,8 @@ int pls_ipb_unwhiten(const pls_ipb_desc *basis, const double *Sw, int64_t lds, i
   PLS_REQUIRE(basis->LcT, "ipb_unwhiten: the descriptor needs LcT");
   PLS_REQUIRE(U && Sw && U != Sw && j >= 0 && ldu >= j && lds >= j, "ipb_unwhiten: bad arguments");
   if (j == 0) return PLS_OK;
-  return gemm_tn_ex(basis->LcT, basis->ldlct, Sw, lds, U, ldu, basis->m, j, basis->m, 1.0, 0.0, 1, S(stream));
+  return gemm_tn_ex(basis->LcT, basis->ldlct, Sw, lds, U, ldu, basis->m, j, basis->m, 1.0, 0.0, 1, S(stream), basis->tri_scratch,
+                    basis->tri_scratch_bytes);
 }
 
 size_t pls_ipb_whitened_workspace_bytes(const pls_ipb_desc *basis, int64_t j) {
