@@ -225,6 +225,12 @@ typedef struct {
    * these entries (ascending order: the value pls_block_means returns, bit for bit).  May point to pinned host memory
    * mapped into the device.  NULL: not written. */
   double *energy_sums;
+  /* Optional (ABI 4), Gaussian/identity fast paths with energy_in != NULL: cdiv(j, 256) 32-bit counters (device), ZERO when
+   * first handed in; every call leaves them zero.  With them the step launch FINISHES the energies itself -- the workgroup
+   * that arrives last at a 256-column chunk adds the partial rows of that chunk in their fixed order, writes energy_in and
+   * energy_sums (the values the finishing launch computes, bit for bit) -- so a training iteration is ONE launch.  Calls
+   * that may run concurrently need different counters.  NULL (or any other route): a finishing launch follows. */
+  uint32_t *energy_sync;
 } pls_block_desc;
 
 const char *pls_last_error(void);
@@ -264,7 +270,10 @@ typedef enum pls_option {
   PLS_OPT_TRI_BALANCE = 9,
   /* pls_ipb_step, Gaussian/identity without energy_in: 1 (default) = dS = -eta (P U - ct) + noise straight from U when the
    * descriptor carries Pt, 0 = forward solve, then Q S (A/B runs, tests). */
-  PLS_OPT_IPB_STEP_OPERATOR = 10
+  PLS_OPT_IPB_STEP_OPERATOR = 10,
+  /* 1 (default): pls_block_desc.energy_sync is honoured (the step launch finishes the energies); 0: always a finishing
+   * launch (A/B runs, tests). */
+  PLS_OPT_ENERGY_FUSED_FINISH = 11
 } pls_option;
 /* Diagnostic: out[i] = op(x[i]) with the device exp (op 0) / log (op 1) the per-element kernels use (csrc/fmath.h),
  * so that their accuracy can be pinned against libm.  Not on the step path. */

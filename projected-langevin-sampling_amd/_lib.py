@@ -118,7 +118,7 @@ class CholDesc(C.Structure):
 
 
 class BlockDesc(C.Structure):
-    _fields_ = [("block_cols", C.c_int64), ("eta", C.c_void_p), ("energy_sums", C.c_void_p)]
+    _fields_ = [("block_cols", C.c_int64), ("eta", C.c_void_p), ("energy_sums", C.c_void_p), ("energy_sync", C.c_void_p)]
 
 
 _P, _I64, _I32, _U64, _D, _SZ = C.c_void_p, C.c_int64, C.c_int32, C.c_uint64, C.c_double, C.c_size_t
@@ -223,6 +223,7 @@ OPT_SMALL_RANK2_MIN = 7
 OPT_ROW_BLOCKS = 8
 OPT_TRI_BALANCE = 9
 OPT_IPB_STEP_OPERATOR = 10
+OPT_ENERGY_FUSED_FINISH = 11
 TAG_NAMES = {1: "gemm_store", 2: "gemm_cost_deriv", 3: "gemm_cost_value", 4: "gemm_langevin_gaussian",
              5: "langevin_update", 6: "kernel_gram", 7: "other", 8: "small_rank_drift", 9: "small_rank_value",
              10: "tri_solve"}

@@ -50,7 +50,8 @@ class BlockSpec:
     run as S blocks of ``block_cols`` columns.  ``eta`` is a device float64 vector, one entry per block; writing 0
     freezes a block."""
 
-    def __init__(self, block_cols: int, eta: torch.Tensor, energy_sums: int | None = None):
+    def __init__(self, block_cols: int, eta: torch.Tensor, energy_sums: int | None = None,
+                 energy_sync: torch.Tensor | None = None):
         """``energy_sums`` (optional): raw address (device, or pinned host memory) of cdiv(J, 256) doubles that receive the
         256-column chunk sums of the per-particle energies from the launch that finishes the step's energy by-product
         (Gaussian/identity fast paths; see pls_block_desc)."""
@@ -58,11 +59,17 @@ class BlockSpec:
         L.require_gpu_tensor(eta, "eta")
         assert eta.dim() == 1 and eta.is_contiguous()
         self.block_cols, self.eta, self.energy_sums = int(block_cols), eta, energy_sums
+        #: optional: device int32 counters, one per 256 columns, zeroed once by the owner (pls_block_desc.energy_sync): the step
+        #: launch then finishes the energies itself and leaves the counters zero
+        if energy_sync is not None:
+            assert energy_sync.device.type == "cuda" and energy_sync.dtype == torch.int32 and energy_sync.is_contiguous()
+        self.energy_sync = energy_sync
 
     def desc(self) -> L.BlockDesc:
         d = L.BlockDesc()
         d.block_cols, d.eta = self.block_cols, self.eta.data_ptr()
         d.energy_sums = self.energy_sums
+        d.energy_sync = None if self.energy_sync is None else self.energy_sync.data_ptr()
         return d
 
 

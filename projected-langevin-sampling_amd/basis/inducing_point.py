@@ -355,19 +355,25 @@ class InducingPointBasis(PLSBasis):
 
     # ---- prediction ---------------------------------------------------------------------------------
     def sample_predictive_noise(self, particles: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
-        """G([Z, x]) ~ N(0, r([Z,x],[Z,x]))  (:152-202)."""
-        gram_x = self.kernel.forward(x1=x, x2=x, additional_approximation_samples=x)
-        gram_induce_x = self.kernel.forward(x1=self.x_induce, x2=x, additional_approximation_samples=x)
-        noise_covariance = torch.cat(
-            [torch.cat([self.gram_induce, gram_induce_x], dim=1), torch.cat([gram_induce_x.T, gram_x], dim=1)], dim=0
-        )
+        """G([Z, x]) ~ N(0, r([Z,x],[Z,x]))  (:152-202); device normals keyed by the global particle column, the sampler's
+        eigh remembered per test-point tensor (see OrthonormalBasis.sample_predictive_noise)."""
+        from .orthonormal import _cached_factor
+
+        lt = _cached_factor(self, x, self._predictive_covariance)
         predictive_noise = sample_multivariate_normal(
-            mean=torch.zeros(noise_covariance.shape[0]), cov=noise_covariance, size=(particles.shape[1],)
+            mean=torch.zeros(lt.shape[0]), cov=None, size=(particles.shape[1],), factor=lt, j_offset=self.j_offset
         ).T
         if self.additional_predictive_noise_distribution is not None:
             extra = self.additional_predictive_noise_distribution.sample(predictive_noise.shape).reshape(predictive_noise.shape)
             predictive_noise = predictive_noise + _dev(extra)
         return predictive_noise.contiguous()
+
+    def _predictive_covariance(self, x: torch.Tensor) -> torch.Tensor:
+        gram_x = self.kernel.forward(x1=x, x2=x, additional_approximation_samples=x)
+        gram_induce_x = self.kernel.forward(x1=self.x_induce, x2=x, additional_approximation_samples=x)
+        return torch.cat(
+            [torch.cat([self.gram_induce, gram_induce_x], dim=1), torch.cat([gram_induce_x.T, gram_x], dim=1)], dim=0
+        )
 
     def predict_untransformed_samples(self, particles: torch.Tensor, x: torch.Tensor,
                                       noise: torch.Tensor | None = None) -> torch.Tensor:

@@ -341,23 +341,29 @@ class OrthonormalBasis(PLSBasis):
 
     # ---- prediction (one-time, not on the step path) -----------------------------------------------
     def sample_predictive_noise(self, particles: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
-        """(M_k + N*, J) joint Gaussian noise G([Z, x]) (:161-214).  Gram blocks and the products are libplship
-        kernels; the (M_k + N*) eigh of the sampler runs on the host LAPACK exactly like the reference (samplers.py:27)."""
-        gram_x = self.kernel.forward(x1=x, x2=x, additional_approximation_samples=x)  # r(x,x)  :174-178
-        base_gram_induce_x = self.kernel.base_kernel(x1=self.x_induce, x2=x)  # k(Z,x) (M, N*): k-major operand
-        # off_diagonal_block = k(x,Z) V~ diag(lambda)  (N*, M_k)  :183-185 -- the column scale is folded into the operand
-        off = _ops.gemm_tn(base_gram_induce_x, self._scaled_eigenvectors_lam)
-        lam_diag = torch.diag(self.eigenvalues)
-        noise_covariance = torch.cat(
-            [torch.cat([lam_diag, off.T], dim=1), torch.cat([off, gram_x], dim=1)], dim=0
-        )  # (M_k+N*, M_k+N*)  :186-204
+        """(M_k + N*, J) joint Gaussian noise G([Z, x]) (:161-214).  Gram blocks and the products are libplship kernels, the
+        normals come from the device generator keyed by the global particle column (samplers.DEFAULT_NORMAL_STREAM), and
+        the (M_k + N*) eigh of the sampler (samplers.py:27) is remembered per test-point tensor: tempering and conformal
+        calibration predict at the same points again and again (temper/base.py:30-59, conformalise/base.py:58-114)."""
+        lt = self._predictive_factor(x)
         predictive_noise = sample_multivariate_normal(
-            mean=torch.zeros(noise_covariance.shape[0]), cov=noise_covariance, size=(particles.shape[1],)
+            mean=torch.zeros(lt.shape[0]), cov=None, size=(particles.shape[1],), factor=lt, j_offset=self.j_offset
         ).T  # :205-209
         if self.additional_predictive_noise_distribution is not None:
             extra = self.additional_predictive_noise_distribution.sample(predictive_noise.shape).reshape(predictive_noise.shape)
             predictive_noise = predictive_noise + _dev(extra)  # :210-213
         return predictive_noise.contiguous()
+
+    def _predictive_covariance(self, x: torch.Tensor) -> torch.Tensor:
+        gram_x = self.kernel.forward(x1=x, x2=x, additional_approximation_samples=x)  # r(x,x)  :174-178
+        base_gram_induce_x = self.kernel.base_kernel(x1=self.x_induce, x2=x)  # k(Z,x) (M, N*): k-major operand
+        # off_diagonal_block = k(x,Z) V~ diag(lambda)  (N*, M_k)  :183-185 -- the column scale is folded into the operand
+        off = _ops.gemm_tn(base_gram_induce_x, self._scaled_eigenvectors_lam)
+        lam_diag = torch.diag(self.eigenvalues)
+        return torch.cat([torch.cat([lam_diag, off.T], dim=1), torch.cat([off, gram_x], dim=1)], dim=0)  # :186-204
+
+    def _predictive_factor(self, x: torch.Tensor) -> torch.Tensor:
+        return _cached_factor(self, x, self._predictive_covariance)
 
     def predict_untransformed_samples(self, particles: torch.Tensor, x: torch.Tensor,
                                       noise: torch.Tensor | None = None) -> torch.Tensor:
@@ -373,6 +379,21 @@ class OrthonormalBasis(PLSBasis):
         _ops.gemm_tn(pt, u, 1.0, 1.0, out=out)
         _ops.gemm_tn(pt, noise[:mk, :].contiguous(), -1.0, 1.0, out=out)
         return out
+
+
+def _cached_factor(basis, x: torch.Tensor, covariance) -> torch.Tensor:
+    """spectral_factor(covariance(x)), remembered for the LAST test-point tensor: the cache holds a reference to ``x`` (its
+    storage cannot be handed to another tensor meanwhile) and its version counter (an in-place change rebuilds), and the
+    eigh device / module defaults in force when it was built."""
+    from .. import samplers
+
+    key = (x._version, tuple(x.shape), samplers.DEFAULT_EIGH_DEVICE)
+    cached = basis.__dict__.get("_pred_factor_cache")
+    if cached is not None and cached[0] is x and cached[1] == key:
+        return cached[2]
+    lt = samplers.spectral_factor(covariance(x))
+    basis._pred_factor_cache = (x, key, lt)
+    return lt
 
 
 def _rows_contiguous(t: torch.Tensor) -> torch.Tensor:

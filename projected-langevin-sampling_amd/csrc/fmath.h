@@ -85,7 +85,10 @@ __device__ __forceinline__ double fast_div(double a, double b) {
 
 // log(x) after fdlibm's e_log.c: x = 2^k (1 + f) with 1 + f in [sqrt(1/2), sqrt(2)), s = f / (2 + f),
 // log(1 + f) = f - (f^2/2 - s (f^2/2 + R(s^2))), R the degree-7 minimax polynomial (error < 2^-58.45).
-__device__ __forceinline__ double fast_log(double x) {
+// fast_log_unit: any positive finite argument (subnormals included) -- in particular the uniform deviates of the noise
+// generator, (n + 1/2) 2^-53 with 0 <= n < 2^53, strictly inside (0, 1).  fast_log adds the three special cases (zero,
+// infinity, negative: a compare and two 32-bit selects each, 9 vector instructions such an argument can never take).
+__device__ __forceinline__ double fast_log_unit(double x) {
   double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1) (subnormals included)
   int k = __builtin_amdgcn_frexp_exp(x);
   const bool low = m < 0.70710678118654752440;
@@ -101,7 +104,11 @@ __device__ __forceinline__ double fast_log(double x) {
                 6.666666666666735130e-01);
   const double R = t2 + t1;
   const double hfsq = 0.5 * f * f;
-  double v = dk * 6.93147180369123816490e-01 - ((hfsq - fma(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f);
+  return dk * 6.93147180369123816490e-01 - ((hfsq - fma(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f);
+}
+
+__device__ __forceinline__ double fast_log(double x) {
+  double v = fast_log_unit(x);
   v = (x == 0.0) ? -__builtin_huge_val() : v;
   v = (x == __builtin_huge_val()) ? x : v;
   v = (x < 0.0) ? __builtin_nan("") : v;

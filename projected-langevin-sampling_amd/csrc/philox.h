@@ -108,7 +108,7 @@ __device__ __forceinline__ void normal_pair(uint64_t seed, uint64_t step, int64_
   // u1 = ((x0:x1 >> 11) + 0.5) * 2^-53: the 53-bit integer is x0 * 2^21 + (x1 >> 11), both parts exact in a double
   const double n1 = fma((double)x[0], 2097152.0, (double)(x[1] >> 11));
   const double u1 = fma(n1, 1.1102230246251565e-16, 5.5511151231257827e-17);
-  const double rad = sqrt_normal(-2.0 * fast_log(u1));
+  const double rad = sqrt_normal(-2.0 * fast_log_unit(u1));  // (u1 in [2^-54, 1 - 2^-54]: no special cases)
   // 2 pi u2 = (pi / 4) (o + t), o = top 3 bits of x2, t = ((next 50 bits) + 0.5) * 2^-50 in (0, 1)
 #if defined(__HIP_DEVICE_COMPILE__)
   const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)x[2], 29, 1);  // all ones in odd octants: t -> 1 - t

@@ -241,8 +241,9 @@ struct EpiLangevinGaussian {
         double t = es[tb];
         t += __shfl_xor(t, 16);
         t += __shfl_xor(t, 32);
-        if (lane < 16) epart[(iw >> 6) * ldp + jw + tb * 16 + lane] = t;
+        if (lane < 16) store_partial(epart + (iw >> 6) * ldp + jw + tb * 16 + lane, t);
       }
+      finish_energies(jw & ~(int64_t)127);  // (the 128 x 128 configuration: the tile starts at jw rounded down to 128)
     }
 #else
     (void)acc, (void)iw, (void)jw, (void)lane, (void)wlds;
@@ -262,6 +263,78 @@ struct EpiLangevinGaussian {
   double *epart;
   int64_t ldp;
   int nwj, bj;  // tile geometry of the launch (waves along j, tile width), set by the launcher
+  // Optional (pls_block_desc.energy_sync): the energies are FINISHED by this launch -- no second kernel.  Every workgroup
+  // leaves its partial rows write-through (sc1), drains them, and bumps the counter of its 256-column chunk (one agent-scope
+  // atomic by one lane); the workgroup whose add comes last for a chunk -- it knows from the value the add returned -- reads
+  // all partial rows of the chunk's columns (sc1 loads), adds them in ascending row order, writes the energies and the
+  // chunk's sum in the library's fixed order, and puts the counter back to zero.  What the finishing kernel computed, bit for
+  // bit, whoever comes last; nobody waits.  (Visibility rules: csrc/gemm_tn_f64_kg.h, kg_tri_publish.)
+  struct Finish {
+    unsigned *sync;     // cdiv(J, 256) counters, zero on entry and on exit; NULL: gaussian_energy_finish_kernel follows
+    double *e;          // (J) energies
+    double *sums;       // cdiv(J, 256) chunk sums, may be NULL / pinned host memory
+    double yscale;
+    const double *yty;
+    int nparts, nti;    // partial rows in epart; tile rows of the launch (arrivals per column tile)
+  } fin;
+
+  __device__ __forceinline__ void store_partial(double *p, double v) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (fin.sync)
+      __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through: read by another workgroup
+    else
+      *p = v;
+#else
+    (void)p, (void)v;
+#endif
+  }
+
+  // called by every thread of the workgroup after its partial rows are stored; j_tile = first column of the tile
+  // (the partial rows are J long: ldp == J)
+  __device__ __forceinline__ void finish_energies(int64_t j_tile) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (!fin.sync) return;  // (launch-uniform)
+    __shared__ unsigned arrived;
+    __shared__ double ws[4];
+    const int tid = threadIdx.x;
+    const int64_t J = ldp;
+    const int64_t chunk = j_tile >> 8, c0 = chunk << 8, c1 = (c0 + 256 < J) ? c0 + 256 : J;
+    const unsigned expect = (unsigned)fin.nti * (unsigned)((c1 - c0 + bj - 1) / bj);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave: its write-through stores have been performed
+    __syncthreads();
+    if (tid == 0) arrived = __hip_atomic_fetch_add(fin.sync + chunk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (arrived + 1 != expect) return;  // (workgroup-uniform)
+    double v = 0.0;
+    const int64_t col = c0 + tid;
+    if (tid < 256 && col < J) {
+      double s = 0.0;
+      for (int p0 = 0; p0 < fin.nparts; p0 += 8) {  // eight loads in flight, added in ascending row order
+        double t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          t[k] = (p0 + k < fin.nparts)
+                     ? __hip_atomic_load(epart + (int64_t)(p0 + k) * ldp + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                     : 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (p0 + k < fin.nparts) s += t[k];
+      }
+      v = s + fin.yscale * (*fin.yty);
+      fin.e[col] = v;
+    }
+    if (fin.sums) {  // chunk256_sum's order: xor butterfly inside each of the four waves, then (w0 + w1) + (w2 + w3)
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+      if (tid < 256 && (tid & 63) == 0) ws[tid >> 6] = v;
+      __syncthreads();
+      if (tid == 0) fin.sums[chunk] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+    }
+    if (tid == 0) __hip_atomic_store(fin.sync + chunk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    (void)j_tile;
+#endif
+  }
   template <int TI, int TJ>
   __device__ void apply(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int wave, int64_t I, int64_t J,
                         int tile_i, int, double *lds) const {
@@ -315,13 +388,14 @@ struct EpiLangevinGaussian {
         const int64_t j = (jw - wcol * WJ) + t;
         if (j < J) {
           if (bj == 128) {  // big configuration: partial rows are per 64 data rows (the direct path writes one per wave row)
-            epart[(int64_t)(2 * tile_i) * ldp + j] = tot;
-            epart[(int64_t)(2 * tile_i + 1) * ldp + j] = 0.0;
+            store_partial(epart + (int64_t)(2 * tile_i) * ldp + j, tot);
+            store_partial(epart + (int64_t)(2 * tile_i + 1) * ldp + j, 0.0);
           } else {
-            epart[(int64_t)tile_i * ldp + j] = tot;
+            store_partial(epart + (int64_t)tile_i * ldp + j, tot);
           }
         }
       }
+      finish_energies(jw - wcol * WJ);
     }
   }
 };
@@ -1260,6 +1334,7 @@ static int validate_noise(const pls_noise_desc *n, int64_t rows) {
 // ---- small projection ranks: fused kernels (small_rank.h) -------------------------------------------------------
 static std::atomic<int64_t> g_small_rank_max{128};  // pls_set_option(PLS_OPT_SMALL_RANK_MAX)
 static std::atomic<int64_t> g_ipb_explicit_inverse{0};  // pls_set_option(PLS_OPT_IPB_EXPLICIT_INVERSE)
+static std::atomic<int64_t> g_energy_fused_finish{1};   // pls_set_option(PLS_OPT_ENERGY_FUSED_FINISH): honour pls_block_desc.energy_sync
 static std::atomic<int64_t> g_ipb_step_operator{1};     // pls_set_option(PLS_OPT_IPB_STEP_OPERATOR): 1 = Pt route when the descriptor has it
 static std::atomic<int64_t> g_solve_mode{1};  // pls_set_option(PLS_OPT_SOLVE_MODE): 0 block substitution, 1 inverse-factor products where available
 int64_t solve_mode() { return g_solve_mode.load(); }
@@ -1492,7 +1567,8 @@ struct FastOp {
 
 static int fast_step_launch(const FastOp &op, const double *U, int64_t ldu, int64_t j, const EtaP &etap, const NoiseP &nz,
                             double *out, int64_t ldo, int out_mode, double *energy_in, void *workspace,
-                            size_t workspace_bytes, hipStream_t st, const char *who, double *esums = nullptr) {
+                            size_t workspace_bytes, hipStream_t st, const char *who, double *esums = nullptr,
+                            uint32_t *esync = nullptr) {
   const bool big = pick_gemm_cfg(op.B, op.ldb, U, ldu, op.mk, j, op.mk) == CFG_BIG;
   const int64_t parts = big ? 2 * cdiv(op.mk, 128) : cdiv(op.mk, 64);
   double *epart = nullptr;
@@ -1502,9 +1578,12 @@ static int fast_step_launch(const FastOp &op, const double *U, int64_t ldu, int6
                   (size_t)parts * j * sizeof(double));
     epart = static_cast<double *>(workspace);
   }
-  EpiLangevinGaussian e{out, ldo, U, ldu, op.c, op.lam, etap, op.inv_noise, out_mode, nz, epart, j, 2, big ? 128 : 64};
+  EpiLangevinGaussian e{out, ldo, U, ldu, op.c, op.lam, etap, op.inv_noise, out_mode, nz, epart, j, 2, big ? 128 : 64, {}};
+  const bool fused_finish = energy_in && esync && g_energy_fused_finish.load() != 0;
+  if (fused_finish)  // the step launch finishes the energies itself (pls_block_desc.energy_sync)
+    e.fin = EpiLangevinGaussian::Finish{esync, energy_in, esums, op.yscale, op.yty, (int)parts, (int)cdiv(op.mk, big ? 128 : 64)};
   int rc = launch_gemm_any(op.B, op.ldb, U, ldu, op.mk, j, op.mk, e, st);
-  if (rc || !energy_in) return rc;
+  if (rc || !energy_in || fused_finish) return rc;
   hipLaunchKernelGGL(gaussian_energy_finish_kernel, dim3((unsigned)cdiv(j, 256)), dim3(256), 0, st, epart, j, parts, j,
                      energy_in, op.yscale, op.yty, esums);
   return check_launch("gaussian_energy_finish");
@@ -1594,6 +1673,10 @@ int pls_set_option(int32_t option, int64_t value) {
       PLS_REQUIRE(value == 0 || value == 1, "set_option: step operator mode must be 0 or 1");
       g_ipb_step_operator.store(value);
       return PLS_OK;
+    case PLS_OPT_ENERGY_FUSED_FINISH:
+      PLS_REQUIRE(value == 0 || value == 1, "set_option: fused energy finish must be 0 or 1");
+      g_energy_fused_finish.store(value);
+      return PLS_OK;
     default: return fail(PLS_ERR_INVALID_ARGUMENT, "set_option: unknown option %d", (int)option);
   }
 }
@@ -1618,6 +1701,7 @@ int64_t pls_get_option(int32_t option) {
     case PLS_OPT_ROW_BLOCKS: return g_row_blocks_mode.load();
     case PLS_OPT_TRI_BALANCE: return g_tri_balance.load();
     case PLS_OPT_IPB_STEP_OPERATOR: return g_ipb_step_operator.load();
+    case PLS_OPT_ENERGY_FUSED_FINISH: return g_energy_fused_finish.load();
     default: return -1;
   }
 }
@@ -1961,7 +2045,7 @@ static int onb_step_impl(const pls_onb_desc *basis, const pls_cost_desc *cost, c
   if (onb_fast_path(basis, cost, force_generic)) {
     const FastOp op{basis->B, basis->ldb, basis->c, basis->lam, basis->mk, 1.0 / cost->p[0], 0.5 / cost->p[0], basis->c + basis->mk};
     return fast_step_launch(op, U, ldu, j, etap, nz, out, ldo, out_mode, energy_in, workspace, workspace_bytes, st, "onb_step",
-                            blocks ? blocks->energy_sums : nullptr);
+                            blocks ? blocks->energy_sums : nullptr, blocks ? blocks->energy_sync : nullptr);
   }
   // workspace: [D slabs][cost partial rows (energy by-product)][G chunk]; the chunk length follows from what is left
   const size_t d_bytes = align_up((size_t)basis->mk * j * sizeof(double), 256);
@@ -2263,7 +2347,7 @@ static int ipb_step_impl(const pls_ipb_desc *basis, const pls_cost_desc *cost, c
       rc = chol_forward_solve(&f, U, ldu, j, Sw, j, st);
       if (rc) return rc;
       rc = fast_step_launch(ipb_whitened_op(basis), Sw, j, j, make_etap(eta, blocks), nz, Wd, j, 0, energy_in, epart,
-                            2 * mj, st, "ipb_step", blocks ? blocks->energy_sums : nullptr);
+                            2 * mj, st, "ipb_step", blocks ? blocks->energy_sums : nullptr, blocks ? blocks->energy_sync : nullptr);
     }
     if (rc) return rc;
     EpiIpbFinish fin{out, ldo, U, ldu, out_mode, make_etap(eta, blocks), e_inj, ld_inj};
@@ -2487,7 +2571,7 @@ static int ipb_whitened_step_impl(const pls_ipb_desc *basis, const pls_cost_desc
   if (j == 0) return PLS_OK;
   return fast_step_launch(ipb_whitened_op(basis), Sw, lds, j, make_etap(eta, blocks), make_noisep(noise, blocks), out, ldo,
                           out_mode, energy_in, workspace, workspace_bytes, S(stream), "ipb_whitened_step",
-                          blocks ? blocks->energy_sums : nullptr);
+                          blocks ? blocks->energy_sums : nullptr, blocks ? blocks->energy_sync : nullptr);
 }
 
 int pls_ipb_whitened_step(const pls_ipb_desc *basis, const pls_cost_desc *cost, const double *Sw, int64_t lds, int64_t j,

@@ -114,6 +114,7 @@ class CapturedTraining:
         self._fused_sums = bool(getattr(pls.basis, "supports_energy_sums", lambda c: False)(pls.cost))
         self._nchunk = (j + 255) // 256
         self._sums = torch.zeros(steps_per_replay, self._nchunk, dtype=torch.float64, device=particles.device)
+        self._sync = torch.zeros(self._nchunk, dtype=torch.int32, device=particles.device)  # (pls_block_desc.energy_sync)
         self._eta = torch.full((1,), float(step_size), dtype=torch.float64, device=particles.device)
         self.counter = torch.zeros(1, dtype=torch.int64, device=particles.device)
         basis, cost = pls.basis, pls.cost
@@ -132,7 +133,7 @@ class CapturedTraining:
                 if self._fused_sums:
                     from .basis.base import BlockSpec
 
-                    blocks = BlockSpec(cur.shape[1], self._eta, energy_sums=self._sums[s].data_ptr())
+                    blocks = BlockSpec(cur.shape[1], self._eta, energy_sums=self._sums[s].data_ptr(), energy_sync=self._sync)
                     basis.fused_step(cost, cur, self.step_size, out=nxt, new_state=True, noise=spec, input_energy=self._e,
                                      workspace=self._ws, blocks=blocks)
                 else:

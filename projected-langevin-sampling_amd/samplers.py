@@ -1,10 +1,10 @@
 """Samplers (drop-in for src/samplers.py:6-44).
 
-``sample_multivariate_normal`` keeps the reference's stream: torch.normal on the CPU generator, coloured by
-eigh(cov).  It is setup / prediction code (the per-step Langevin noise uses the in-kernel Philox stream
-instead, see basis/); the eigh is torch.linalg.eigh on the device the covariance lives on, exactly as
-`torch.linalg.eigh(cov)` of the reference (samplers.py:27) resolves, and the product is done by libplship on
-the device."""
+``sample_multivariate_normal`` colours standard normals by the spectral factor Q sqrt(max(Lambda, 0)) of the covariance,
+as the reference does.  It is setup / prediction code (the per-step Langevin noise is generated inside the step kernels,
+see basis/); the eigh is torch.linalg.eigh on the device the covariance lives on, exactly as `torch.linalg.eigh(cov)` of
+the reference (samplers.py:27) resolves; the normals come from libplship's generator on the device (or, on request, from
+the reference's host stream), and the product is libplship's contraction."""
 from __future__ import annotations
 
 from typing import Tuple
@@ -34,30 +34,82 @@ def resolve_eigh_device(requested: str | None, matrix: torch.Tensor) -> str:
     return where
 
 
+#: where the standard normals that sample_multivariate_normal colours come from.
+#:   "device" (default): libplship's counter-based generator on the GPU (pls_normal_fill: Philox4x32-10 + Box-Muller), keyed
+#:       by ``seed`` -- or, with ``seed=None``, by ONE 63-bit draw from torch's global CPU generator, so that the
+#:       reference's reproducibility contract (set_seed before a run) holds -- and by the GLOBAL particle column, so the
+#:       ranks of a J-sharded prediction draw different columns of one matrix and the result does not depend on the GPU
+#:       count.  (With the host stream every rank seeded alike would draw the SAME normals for different particles.)
+#:   "reference": torch.normal on the host generator and a host -> device copy, the reference's stream, sample for sample
+#:       (samplers.py:30-40) -- what the parity tests pin; 0.3 s of host time for 2 000 test points x 8 192 particles.
+#: Same law either way: N(mean, Q max(Lambda, 0) Q^T).
+DEFAULT_NORMAL_STREAM = "device"
+
+
+def spectral_factor(cov: torch.Tensor, eigh_device: str | None = None) -> torch.Tensor:
+    """(Q sqrt(max(Lambda, 0)))^T of the symmetric ``cov`` as an (n, n) device matrix: the k-major operand that colours
+    standard normals (samplers.py:27-28, :37-44).  The eigendecomposition is not optional: the reference's predictive
+    covariances are INDEFINITE (orthonormal.py:186-204 mixes r over Z u x with the spectrum of k(Z,Z)/M: a hundred negative
+    eigenvalues at M = 128, N* = 300, tests/test_oracle_goldens.py), its law is the one of the clipped spectrum, and no
+    Cholesky factor -- with whatever jitter -- has that law."""
+    where = resolve_eigh_device(eigh_device, cov)
+    c64 = cov.detach().to(torch.float64)
+    eigenvalues, eigenvectors = torch.linalg.eigh(c64.cpu() if where == "cpu" else _dev(c64))  # samplers.py:27
+    eigenvalues = torch.clip(eigenvalues, 0, None)
+    # (Q sqrt(Lambda))^T stored k-major: L[k][i] = Q[i][k] * sqrt(lam_k)
+    return _dev((eigenvectors * torch.sqrt(eigenvalues)[None, :]).T)
+
+
+def standard_normals(n: int, size: Tuple[int], seed: int | None = None, normal_stream: str | None = None,
+                     j_offset: int = 0) -> torch.Tensor:
+    """(n, prod(size)) standard normals on the device from the chosen stream (DEFAULT_NORMAL_STREAM)."""
+    stream = normal_stream or DEFAULT_NORMAL_STREAM
+    assert stream in ("device", "reference"), "normal_stream must be 'device' or 'reference'"
+    j = 1
+    for v in size:
+        j *= int(v)
+    if stream == "reference":
+        generator = torch.Generator().manual_seed(seed) if seed is not None else None
+        normal_sample = torch.normal(mean=0.0, std=1.0, size=(n, *size), generator=generator)  # samplers.py:30-35
+        return _dev(normal_sample.reshape(n, j))
+    key = int(seed) if seed is not None else int(torch.randint(0, 2**63 - 1, (1,)).item())
+    xi = torch.empty((n, j), dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()))
+    if n and j:
+        L.check(L.load().pls_normal_fill(xi.data_ptr(), j, n, j, key & (2**64 - 1), 0, int(j_offset), L.stream_ptr()),
+                "pls_normal_fill")
+    return xi
+
+
+def colour(factor_t: torch.Tensor, xi: torch.Tensor) -> torch.Tensor:
+    """(Q sqrt(Lambda)) xi on the device (pls_gemm_tn)."""
+    n, j = xi.shape
+    out = torch.empty((n, j), dtype=torch.float64, device=xi.device)
+    if n and j:
+        L.check(
+            L.load().pls_gemm_tn(factor_t.data_ptr(), L.ld(factor_t), xi.data_ptr(), L.ld(xi), out.data_ptr(), j, n, j, n, 1.0, 0.0,
+                                 L.stream_ptr()),
+            "pls_gemm_tn",
+        )
+    return out
+
+
 def sample_multivariate_normal(
     mean: torch.Tensor,
     cov: torch.Tensor,
     size: Tuple[int] | None = None,
     seed: int | None = None,
     eigh_device: str | None = None,
+    normal_stream: str | None = None,
+    j_offset: int = 0,
+    factor: torch.Tensor | None = None,
 ) -> torch.Tensor:
-    """samplers.py:6-44.  Returns a (size..., n) float64 device tensor."""
-    generator = torch.Generator().manual_seed(seed) if seed is not None else None
+    """samplers.py:6-44.  Returns a (size..., n) float64 device tensor.  ``factor`` (extension): spectral_factor(cov) computed
+    earlier -- repeated predictions at the same test points pay the eigh once; ``j_offset``: global index of the first
+    sample (device stream)."""
     size = (1,) if not size else size
-    where = resolve_eigh_device(eigh_device, cov)
-    c64 = cov.detach().to(torch.float64)
-    eigenvalues, eigenvectors = torch.linalg.eigh(c64.cpu() if where == "cpu" else _dev(c64))  # samplers.py:27
-    eigenvalues = torch.clip(eigenvalues, 0, None)
-    n = eigenvalues.shape[0]
-    normal_sample = torch.normal(mean=0.0, std=1.0, size=(n, *size), generator=generator)  # samplers.py:30-35
-    j = int(normal_sample.numel() // n)
-    xi = _dev(normal_sample.reshape(n, j))
-    # (Q sqrt(Lambda))^T stored k-major: L[k][i] = Q[i][k] * sqrt(lam_k)
-    lt = _dev((eigenvectors * torch.sqrt(eigenvalues)[None, :]).T)
-    out = torch.empty((n, j), dtype=torch.float64, device=xi.device)
-    L.check(
-        L.load().pls_gemm_tn(lt.data_ptr(), n, xi.data_ptr(), j, out.data_ptr(), j, n, j, n, 1.0, 0.0, L.stream_ptr()),
-        "pls_gemm_tn",
-    )
+    lt = spectral_factor(cov, eigh_device) if factor is None else factor
+    n = lt.shape[0]
+    xi = standard_normals(n, size, seed=seed, normal_stream=normal_stream, j_offset=j_offset)
+    out = colour(lt, xi)
     out = out + _dev(mean)[:, None]
     return out.reshape(n, *size).movedim(0, -1) if len(size) > 1 else out.T

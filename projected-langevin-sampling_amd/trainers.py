@@ -200,6 +200,9 @@ def _train_pls_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs: in
     host_bits = host.view(torch.int64)
     from .basis.base import UNWRITTEN_ENERGY_BITS as UNWRITTEN
     eta_dev = torch.full((1,), float(step_size), dtype=torch.float64, device=particles.device) if fused_sums else None
+    # ... and, with one zeroed counter per chunk (pls_block_desc.energy_sync), the step launch finishes the energies itself:
+    # an iteration is ONE launch (the finishing launch was 5-6 us of a 47 us iteration on the shard of an 8-GPU run)
+    sync = torch.zeros(nchunk, dtype=torch.int32, device=particles.device) if fused_sums else None
     events = [torch.cuda.Event() for _ in range(NB)]
     rng_states = {}
     launched = 0
@@ -211,7 +214,7 @@ def _train_pls_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs: in
         spec = NoiseSpec(injected=noises[k]) if noises is not None else None
         if fused_sums:  # one column block = all particles, its step size from a device word, chunk sums to the host slot
             host_bits[(k % NB) * nchunk:(k % NB + 1) * nchunk] = UNWRITTEN
-            blocks = BlockSpec(j, eta_dev, energy_sums=host_ptr + 8 * nchunk * (k % NB))
+            blocks = BlockSpec(j, eta_dev, energy_sums=host_ptr + 8 * nchunk * (k % NB), energy_sync=sync)
             space.step(bufs[k % NB], step_size, bufs[(k + 1) % NB], spec, e_dev[k % NB], blocks=blocks)
         else:
             space.step(bufs[k % NB], step_size, bufs[(k + 1) % NB], spec, e_dev[k % NB])

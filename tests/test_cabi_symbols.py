@@ -63,6 +63,7 @@ def test_options_validate_without_touching_the_gpu():
     assert lib.pls_set_option(L.OPT_SOLVE_MODE, 0) == 0 and lib.pls_set_option(L.OPT_SOLVE_MODE, 1) == 0
     assert lib.pls_get_option(L.OPT_TRI_BALANCE) == 1 and lib.pls_set_option(L.OPT_TRI_BALANCE, 2) != 0
     assert lib.pls_set_option(L.OPT_TRI_BALANCE, 0) == 0 and lib.pls_set_option(L.OPT_TRI_BALANCE, 1) == 0
+    assert lib.pls_get_option(L.OPT_ENERGY_FUSED_FINISH) == 1 and lib.pls_set_option(L.OPT_ENERGY_FUSED_FINISH, 2) != 0
     assert lib.pls_get_option(L.OPT_IPB_STEP_OPERATOR) == 1 and lib.pls_set_option(L.OPT_IPB_STEP_OPERATOR, 3) != 0
     assert lib.pls_set_option(L.OPT_IPB_STEP_OPERATOR, 0) == 0 and lib.pls_set_option(L.OPT_IPB_STEP_OPERATOR, 1) == 0
     assert lib.pls_tri_scratch_bytes(1024, 1024) == 16384 + 8 * 16 * 2 * 4096 * 8 and lib.pls_tri_scratch_bytes(0, 5) == 0
@@ -78,7 +79,7 @@ def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(L.OnbDesc) == 10 * 8
     assert ctypes.sizeof(L.IpbDesc) == 29 * 8  # (ABI 4: + tri_scratch, tri_scratch_bytes, Pt, ldpt)
     assert ctypes.sizeof(L.CholDesc) == 15 * 8
-    assert ctypes.sizeof(L.BlockDesc) == 3 * 8
+    assert ctypes.sizeof(L.BlockDesc) == 4 * 8
     assert L.CostDesc.p.offset == 16 and L.CostDesc.jitter.offset == 48
 
 

@@ -780,6 +780,51 @@ def test_energy_sums_are_delivered_on_every_step_route(P):
     assert relerr(sums, torch.stack([e[:256].sum(), e[256:].sum()])) < 1e-13
 
 
+@pytest.mark.parametrize("mk,j", [(40, 300), (130, 1000), (256, 1024), (200, 2048), (512, 4096), (1024, 8192), (1000, 8000)])
+def test_fused_energy_finish_equals_the_finishing_launch(P, mk, j):
+    """pls_block_desc.energy_sync: the step launch finishes the energy by-product itself (the workgroup that arrives last at a
+    256-column chunk adds the partial rows in their fixed order) -- energies, chunk sums and the step's output equal the
+    finishing launch's, bit for bit, on every tile configuration (64 x 64 register-staged, k-split, 128 x 128 with the direct
+    epilogue; ragged J and ranks), again and again on the same counters, which come back zero."""
+    from projected_langevin_sampling_amd.basis.base import BlockSpec, UNWRITTEN_ENERGY_BITS
+
+    g = torch.Generator().manual_seed(900 + mk + j)
+    n = 700
+    a = cu(torch.randn(mk, n, generator=g) / math.sqrt(n))
+    lam = cu(torch.rand(mk, generator=g) + 0.5)
+    gb = P.basis.OrthonormalBasis.from_projection(a, lam)
+    y = torch.randn(n, generator=g)
+    gc = P.costs.GaussianCost(0.4, y, P.links.IdentityLinkFunction())
+    u = cu(torch.randn(mk, j, generator=g))
+    eta = cu(torch.tensor([1e-3]))
+    nchunk = (j + 255) // 256
+
+    def step(sync, seed_step):
+        e = torch.full((j,), float("nan"), dtype=torch.float64, device="cuda")
+        sums = torch.empty(nchunk, dtype=torch.float64, device="cuda")
+        sums.view(torch.int64).fill_(UNWRITTEN_ENERGY_BITS)
+        blocks = BlockSpec(j, eta, energy_sums=sums.data_ptr(), energy_sync=sync)
+        out = gb.fused_step(gc, u, 1e-3, new_state=True, noise=P.basis.NoiseSpec(seed=3, step=seed_step), input_energy=e, blocks=blocks)
+        return out, e, sums
+
+    sync = torch.zeros(nchunk, dtype=torch.int32, device="cuda")
+    for rep in range(3):
+        out0, e0, s0 = step(None, rep)
+        out1, e1, s1 = step(sync, rep)
+        assert torch.equal(out0, out1) and torch.equal(e0, e1) and torch.equal(s0, s1), (mk, j, rep)
+        assert int(sync.abs().sum()) == 0
+    assert relerr(e0, gb.fused_particle_energy(gc, u)) < 1e-12
+    want = torch.stack([e0[k * 256:(k + 1) * 256].sum() for k in range(nchunk)])
+    assert relerr(s0, want) < 1e-13
+    lib, L = P.pkg._lib.load(), P.pkg._lib
+    L.check(lib.pls_set_option(L.OPT_ENERGY_FUSED_FINISH, 0), "pls_set_option")  # the option: counters handed in, not used
+    try:
+        out2, e2, s2 = step(sync, 2)
+    finally:
+        L.check(lib.pls_set_option(L.OPT_ENERGY_FUSED_FINISH, 1), "pls_set_option")
+    assert torch.equal(out2, out1) and torch.equal(e2, e1) and torch.equal(s2, s1)
+
+
 @pytest.mark.parametrize("mk", [129, 144, 150, 165, 192, 200, 224, 241, 257, 300])
 def test_ranks_just_above_a_tile_multiple(P, mk):
     """Ranks a little above a multiple of 128 take the back-projection in row blocks (csrc/gemm_tn_f64_rows.h: 129 rows
@@ -1276,6 +1321,71 @@ def test_prediction_vs_oracle(P):
     assert relerr(dist.mean, m_want) < 1e-12 and relerr(torch.diag(dist.covariance_matrix), v_want) < 1e-11
     sig = P.costs.BernoulliCost((pr["y"] > 0).double(), P.links.SigmoidLinkFunction())
     assert relerr(sig.predict_samples(cu(f_want), cu(eps)), O.cost_predict_samples(O.SigmoidLink(), f_want, eps)) < 1e-13
+
+
+def test_device_normal_stream_of_the_predictive_sampler(P):
+    """samplers.DEFAULT_NORMAL_STREAM = "device" (the library default; this suite pins "reference"): the normals of the
+    predictive sampler come from libplship's generator on the GPU.  Same law as the reference's sampler -- mean and
+    covariance of the draws against the analytic Q max(Lambda, 0) Q^T of an INDEFINITE covariance --, reproducible under
+    set_seed, independent of how the particle columns are sharded over ranks (the host stream gives every rank seeded alike
+    the same normals for different particles), and the sampler's eigh is paid once per test-point tensor."""
+    from projected_langevin_sampling_amd import samplers
+    from projected_langevin_sampling_amd.utils import set_seed
+
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(14, 14, generator=g)
+    lam = torch.linspace(-0.6, 2.0, 14)  # four negative eigenvalues: what samplers.py:28 clips
+    q, _ = torch.linalg.qr(a)
+    cov = (q * lam) @ q.T
+    want_cov = (q * lam.clamp_min(0)) @ q.T
+    mean = torch.linspace(-1, 1, 14)
+    draws = samplers.sample_multivariate_normal(mean, cov, size=(200000,), seed=5, normal_stream="device").cpu()  # (200000, 14)
+    assert draws.shape == (200000, 14)
+    assert (draws.mean(dim=0) - mean).abs().max() < 0.02
+    assert (torch.cov(draws.T) - want_cov).abs().max() < 0.03
+    again = samplers.sample_multivariate_normal(mean, cov, size=(200000,), seed=5, normal_stream="device").cpu()
+    assert torch.equal(draws, again)
+    # columns [j0, j1) of the full draw = the shard's own draw with j_offset = j0: the GPU count does not matter
+    part = samplers.sample_multivariate_normal(mean, cov, size=(700,), seed=5, normal_stream="device", j_offset=1000).cpu()
+    assert torch.equal(part, draws[1000:1700])
+    # through the basis: default stream switched on for this block
+    pr = make_problem(300, 12, 40, 2, seed=31)
+    ob, gb = build_onb(P, pr)
+    mk = ob.approximation_dimension
+    u = cu(pr["u"][:mk].contiguous())
+    xs = torch.rand(9, 2, generator=pr["gen"]) * 2 - 1
+    prev = samplers.DEFAULT_NORMAL_STREAM
+    samplers.DEFAULT_NORMAL_STREAM = "device"
+    calls = []
+    real_eigh = torch.linalg.eigh
+    torch.linalg.eigh = lambda *a_, **k_: (calls.append(1), real_eigh(*a_, **k_))[1]
+    try:
+        set_seed(11)
+        n1 = gb.sample_predictive_noise(u, xs)
+        n2 = gb.sample_predictive_noise(u, xs)  # another draw from the generator: fresh noise, no second eigh
+        set_seed(11)
+        n3 = gb.sample_predictive_noise(u, xs)
+        assert len(calls) == 1 and n1.shape == (mk + 9, 40)
+        assert torch.equal(n1, n3) and not torch.equal(n1, n2)
+        gb.j_offset = 16
+        set_seed(11)
+        shard = gb.sample_predictive_noise(u[:, 16:30].contiguous(), xs)
+        gb.j_offset = 0
+        assert torch.equal(shard, n1[:, 16:30])
+        xs.mul_(1.0)  # an in-place touch bumps the version counter: the factor is rebuilt
+        gb.sample_predictive_noise(u, xs)
+        assert len(calls) == 2
+        # law of the joint noise through the basis: covariance of many columns against the clipped analytic matrix
+        big = cu(torch.zeros(mk, 60000))
+        set_seed(12)
+        noise = gb.sample_predictive_noise(big, xs).cpu()
+        cov_j = gb._predictive_covariance(xs).cpu()
+        l2, q2 = torch.linalg.eigh(cov_j)
+        want_j = (q2 * l2.clamp_min(0)) @ q2.T
+        assert (torch.cov(noise) - want_j).abs().max() < 0.05 * want_j.abs().max()
+    finally:
+        torch.linalg.eigh = real_eigh
+        samplers.DEFAULT_NORMAL_STREAM = prev
 
 
 def test_temper_scale_vs_oracle(P):

@@ -295,6 +295,34 @@ def test_conformalise_goldens(G):
     assert np.allclose(torch.mean(up - lo).item(), c["average_interval_width_095"])
 
 
+def test_the_predictive_noise_covariance_is_indefinite():
+    """orthonormal.py:186-204 assembles the joint covariance of G([Z, x]) from r(x, x) over the approximation samples Z u x
+    (normalised by |Z u x|) and the spectrum of k(Z,Z) / M (normalised by M): the two normalisations do not match, the
+    matrix is NOT positive semi-definite, and samplers.py:28 clips its negative eigenvalues.  The reference's predictive law
+    is therefore the law of the CLIPPED spectrum -- which only an eigendecomposition gives: the Schur complement
+    r(x,x) - P Lambda P^T that a Cholesky route would factorise is indefinite too, and its clipped version has another
+    covariance (here by a factor 1.4 .. 1.6 in the mean predictive variance).  Pinned so that nobody replaces the sampler's
+    eigh by a jittered Cholesky "with the same law"."""
+    g = torch.Generator().manual_seed(0)
+    n, m, d, ns = 2000, 128, 4, 300
+    x = torch.rand(n, d, generator=g, dtype=torch.float64) * 2 - 1
+    z, xs = x[:m].clone(), torch.rand(ns, d, generator=g, dtype=torch.float64) * 2 - 1
+    ob = O.OrthonormalBasis(O.RBFARDKernel(torch.full((d,), 0.8, dtype=torch.float64), 1.0), z, x, 1e-8)
+    p = ob.base_kernel(xs, ob.x_induce) @ ob.scaled_eigenvectors
+    off = p @ torch.diag(ob.eigenvalues)
+    cov = torch.cat([torch.cat([torch.diag(ob.eigenvalues), off.T], 1), torch.cat([off, ob.r_kernel(xs, xs, xs)], 1)], 0)
+    lam, q = torch.linalg.eigh(cov)
+    assert (lam < -1e-6 * lam.max()).sum() >= 30 and lam.min() < -1e-3 * lam.max()  # far beyond rounding (100 below -1e-12)
+    schur = ob.r_kernel(xs, xs, xs) - p @ torch.diag(ob.eigenvalues) @ p.T
+    ls, qs = torch.linalg.eigh(schur)
+    assert ls.min() < -0.1 * ls.max()
+    # Var(G(x) - P G(Z)) under the reference's law (clipped joint spectrum) vs the clipped Schur complement
+    t = torch.cat([-p, torch.eye(ns, dtype=torch.float64)], 1)
+    var_reference = (t @ ((q * lam.clamp_min(0)) @ q.T) @ t.T).diagonal().mean()
+    var_schur = ((qs * ls.clamp_min(0)) @ qs.T).diagonal().mean()
+    assert var_reference > 1.3 * var_schur
+
+
 # ---- inducing-point selection (SURVEY 8f row N3) and tempering, pinned by the reference's own vectors -----------------
 
 
