@@ -255,12 +255,8 @@ typedef enum pls_option {
   /* Solves with the Cholesky factor of k(Z,Z): 1 (default) = triangular products with the inverse factor wherever the
    * descriptor carries Linv / LinvT, 0 = block substitution (tri_solve_strip_kernel) always. */
   PLS_OPT_SOLVE_MODE = 5,
-  /* Bases with PLS_OPT_SMALL_RANK2_MIN .. PLS_OPT_SMALL_RANK2_MAX functions (MIN in 129..256, default 161; MAX in 129..256
-   * or 0 = off, the default) take the fused kernel of csrc/small_rank2.h: the one-pass F -> d cost / d f -> back-projection
-   * of PLS_OPT_SMALL_RANK_MAX with the rank split over wave pairs, so that the N x J matrices F and G are never written
-   * here either.  Off by default: with PLS_OPT_ROW_BLOCKS the two-GEMM path is faster at every rank 129 .. 256. */
-  PLS_OPT_SMALL_RANK2_MAX = 6,
-  PLS_OPT_SMALL_RANK2_MIN = 7,
+  /* (6, 7: the wave-pair fused kernel for 129 .. 256 functions of ABI 3; slower than the row-block back-projection at every
+   * rank and removed in ABI 4) */
   /* Back-projection D = A G of a basis whose function count is above 128 and not a multiple of 128 (two-GEMM path):
    * 1 (default) = one launch of csrc/gemm_tn_f64_rows.h (equal-height tiles, the MFMA count follows the rank in steps of
    * 16, G read once); 0 = 128-row tiles plus 64- / 32- / 16-row remainder launches (round 2). */
@@ -275,8 +271,9 @@ typedef enum pls_option {
    * launch (A/B runs, tests). */
   PLS_OPT_ENERGY_FUSED_FINISH = 11
 } pls_option;
-/* Diagnostic: out[i] = op(x[i]) with the device exp (op 0) / log (op 1) the per-element kernels use (csrc/fmath.h),
- * so that their accuracy can be pinned against libm.  Not on the step path. */
+/* Diagnostic: out[i] = op(x[i]) with the device exp (op 0) / log (op 1) the per-element kernels use (csrc/fmath.h), or
+ * out[i] = x[i] / x[n + i] with their division (op 2: fast_div, IEEE special cases restored; op 3: fast_div_normal), so
+ * that their accuracy can be pinned against libm.  Not on the step path. */
 int pls_debug_math(int32_t op, const double *x, double *out, int64_t n, void *stream);
 int pls_set_option(int32_t option, int64_t value);
 int64_t pls_get_option(int32_t option); /* -1 for an unknown option */

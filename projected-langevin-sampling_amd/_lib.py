@@ -218,8 +218,6 @@ OPT_IPB_EXPLICIT_INVERSE = 2
 OPT_KSPLIT_MODE = 3
 OPT_KSPLIT_MAX_TILES = 4
 OPT_SOLVE_MODE = 5
-OPT_SMALL_RANK2_MAX = 6
-OPT_SMALL_RANK2_MIN = 7
 OPT_ROW_BLOCKS = 8
 OPT_TRI_BALANCE = 9
 OPT_IPB_STEP_OPERATOR = 10

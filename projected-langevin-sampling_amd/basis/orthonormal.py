@@ -381,18 +381,27 @@ class OrthonormalBasis(PLSBasis):
         return out
 
 
+#: spectral factors a basis remembers (one per test-point tensor, least recently used out first): tempering and conformal
+#: calibration alternate between the calibration points and the test points; an entry is (M_k + N*)^2 doubles
+PREDICTIVE_FACTOR_CACHE_ENTRIES = 4
+
+
 def _cached_factor(basis, x: torch.Tensor, covariance) -> torch.Tensor:
-    """spectral_factor(covariance(x)), remembered for the LAST test-point tensor: the cache holds a reference to ``x`` (its
-    storage cannot be handed to another tensor meanwhile) and its version counter (an in-place change rebuilds), and the
-    eigh device / module defaults in force when it was built."""
+    """spectral_factor(covariance(x)), remembered per test-point tensor: an entry holds a reference to ``x`` (its storage
+    cannot be handed to another tensor meanwhile), its version counter (an in-place change rebuilds) and the eigh default in
+    force when it was built."""
     from .. import samplers
 
     key = (x._version, tuple(x.shape), samplers.DEFAULT_EIGH_DEVICE)
-    cached = basis.__dict__.get("_pred_factor_cache")
-    if cached is not None and cached[0] is x and cached[1] == key:
-        return cached[2]
+    cache = basis.__dict__.setdefault("_pred_factor_cache", [])
+    for i, (xr, k, lt) in enumerate(cache):
+        if xr is x and k == key:
+            cache.append(cache.pop(i))
+            return lt
+    cache[:] = [e for e in cache if e[0] is not x]  # (a stale entry of the same tensor)
     lt = samplers.spectral_factor(covariance(x))
-    basis._pred_factor_cache = (x, key, lt)
+    cache.append((x, key, lt))
+    del cache[:-PREDICTIVE_FACTOR_CACHE_ENTRIES]
     return lt
 
 

@@ -57,25 +57,38 @@ __device__ __forceinline__ double fast_exp(double x) {
   return v;
 }
 
-// a / b for b well inside the normal range (no scaling steps): reciprocal seed + two Newton steps + one residual
-// correction of the quotient; <= 1 ulp
+// Newton steps on the v_rcp_f64 seed before the quotient's residual correction.  The seed r0 has a relative error e0; one
+// step leaves e0^2 in r, the quotient q = a r inherits it, and the correction q + r (a - b q) squares it again: with the
+// ~2^-26 seed of gfx9 one step gives 2^-52 before and 2^-104 after the correction, i.e. the correctly rounded quotient up to
+// the rounding of the last fma.  Round 2 took two steps; tests/test_gpu_parity.py::test_device_math_matches_libm holds the
+// one-step form to the same <= 1 ulp over the whole normal range.
+#ifndef PLS_DIV_NEWTON_STEPS
+#define PLS_DIV_NEWTON_STEPS 1
+#endif
+
+// a / b for b well inside the normal range (no scaling steps): reciprocal seed + Newton + one residual correction of the
+// quotient; <= 1 ulp
 __device__ __forceinline__ double fast_div_normal(double a, double b) {
   double r = __builtin_amdgcn_rcp(b);
   r = fma(fma(-b, r, 1.0), r, r);
+#if PLS_DIV_NEWTON_STEPS >= 2
   r = fma(fma(-b, r, 1.0), r, r);
+#endif
   const double q = a * r;
   return fma(fma(-b, q, a), r, q);
 }
 
-// a / b for per-element cost code: reciprocal seed, two Newton steps, one residual correction of the quotient (<= 1 ulp
+// a / b for per-element cost code: reciprocal seed, Newton, one residual correction of the quotient (<= 1 ulp
 // for |b| and |a / b| inside the normal range), then v_div_fixup_f64, which puts the IEEE results of the special cases
-// back (b = 0, infinities, NaN).  9 vector instructions against the ~15 of the compiler's scaled division sequence;
+// back (b = 0, infinities, NaN).  7 vector instructions against the ~15 of the compiler's scaled division sequence;
 // what is given up is correct rounding and the rescaling of operands within a factor 2^-1022 .. 2^1022 of the limits.
 __device__ __forceinline__ double fast_div(double a, double b) {
 #if defined(__HIP_DEVICE_COMPILE__)
   double r = __builtin_amdgcn_rcp(b);
   r = fma(fma(-b, r, 1.0), r, r);
+#if PLS_DIV_NEWTON_STEPS >= 2
   r = fma(fma(-b, r, 1.0), r, r);
+#endif
   const double q = a * r;
   return __builtin_amdgcn_div_fixup(fma(fma(-b, q, a), r, q), b, a);
 #else

@@ -718,7 +718,11 @@ static void launch_gram(dim3 grid, hipStream_t st, const double *x1, int64_t row
 __global__ __launch_bounds__(256) void debug_math_kernel(int op, const double *__restrict__ x, double *__restrict__ out,
                                                          int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) out[i] = op == 0 ? fast_exp(x[i]) : fast_log(x[i]);
+  if (i >= n) return;
+  if (op == 0) out[i] = fast_exp(x[i]);
+  else if (op == 1) out[i] = fast_log(x[i]);
+  else if (op == 2) out[i] = fast_div(x[i], x[n + i]);         // numerators x[0 .. n), denominators x[n .. 2 n)
+  else out[i] = fast_div_normal(x[i], x[n + i]);
 }
 
 // elementwise cost derivative (un-fused entry point)
@@ -1339,18 +1343,6 @@ static std::atomic<int64_t> g_ipb_step_operator{1};     // pls_set_option(PLS_OP
 static std::atomic<int64_t> g_solve_mode{1};  // pls_set_option(PLS_OPT_SOLVE_MODE): 0 block substitution, 1 inverse-factor products where available
 int64_t solve_mode() { return g_solve_mode.load(); }
 
-// Ranks [MIN, MAX] take small_rank2.h (pls_set_option(PLS_OPT_SMALL_RANK2_MIN / _MAX)); MAX = 0 (the default): none.
-// profiles/r03_rank2_probe.txt (N = 1e5, J = 8192): against the round-2 two-GEMM path the wave-pair kernel won from ~170
-// functions (Gaussian +1 %, Poisson +2 % at 176) to 240 (+8 / +9 %).  With the back-projection in row blocks
-// (gemm_tn_f64_rows.h) the two-GEMM path is ahead at every rank 129 .. 256 (profiles/r03_step_sweep_ranks.txt: by
-// 6 .. 14 %), so the fused kernel is kept as an option (no N x J workspace for G) and is no longer a default.
-static std::atomic<int64_t> g_small_rank2_min{161}, g_small_rank2_max{0};
-
-static bool small_rank2_ok(const double *Lb, int64_t ldlb, int64_t kdim) {
-  return kdim > 128 && kdim <= 256 && kdim >= g_small_rank2_min.load() && kdim <= g_small_rank2_max.load() &&
-         (ldlb & 1) == 0 && (reinterpret_cast<uintptr_t>(Lb) & 15) == 0;
-}
-
 static bool small_rank_ok(const double *Lb, int64_t ldlb, int64_t kdim) {
   return kdim >= 1 && kdim <= g_small_rank_max.load() && (ldlb & 1) == 0 && (reinterpret_cast<uintptr_t>(Lb) & 15) == 0;
 }
@@ -1391,17 +1383,6 @@ static int stream_drift(const double *Lf, int64_t ldlf, const double *Lb, int64_
       SmallRankP p{Lb, ldlb, V, ldv, y, n, j, (int)kdim, rows_per_split, D, ldd, slab_stride, cp, es ? es->partial : nullptr, j};
       *slabs_used = ns;
       int rc = es ? launch_small_rank_drift_value(p, ns, st) : launch_small_rank_drift(p, ns, st);
-      if (rc || !es) return rc;
-      return reduce_partials(ns, 0, true);
-    }
-  }
-  if (small_rank2_ok(Lb, ldlb, kdim)) {  // 129 .. 256 basis functions: the same fusion with the rank split over wave pairs
-    int64_t rows_per_split = 0;
-    const int64_t ns = small_rank_splits(j, n, &rows_per_split);
-    if (ns <= max_slabs && (!es || ns <= es->rows_cap)) {
-      SmallRankP p{Lb, ldlb, V, ldv, y, n, j, (int)kdim, rows_per_split, D, ldd, slab_stride, cp, es ? es->partial : nullptr, j};
-      *slabs_used = ns;
-      int rc = es ? launch_small_rank2_drift_value(p, ns, st) : launch_small_rank2_drift(p, ns, st);
       if (rc || !es) return rc;
       return reduce_partials(ns, 0, true);
     }
@@ -1641,14 +1622,6 @@ int pls_set_option(int32_t option, int64_t value) {
       PLS_REQUIRE(value == 0 || value == 1, "set_option: ipb explicit inverse must be 0 or 1");
       g_ipb_explicit_inverse.store(value);
       return PLS_OK;
-    case PLS_OPT_SMALL_RANK2_MAX:
-      PLS_REQUIRE(value == 0 || (value >= 129 && value <= 256), "set_option: the wave-pair kernel's upper rank limit must be 0 or 129..256");
-      g_small_rank2_max.store(value);
-      return PLS_OK;
-    case PLS_OPT_SMALL_RANK2_MIN:
-      PLS_REQUIRE(value >= 129 && value <= 256, "set_option: the wave-pair kernel's lower rank limit must be 129..256");
-      g_small_rank2_min.store(value);
-      return PLS_OK;
     case PLS_OPT_SOLVE_MODE:
       PLS_REQUIRE(value == 0 || value == 1, "set_option: solve mode must be 0 or 1");
       g_solve_mode.store(value);
@@ -1682,7 +1655,7 @@ int pls_set_option(int32_t option, int64_t value) {
 }
 
 int pls_debug_math(int32_t op, const double *x, double *out, int64_t n, void *stream) {
-  PLS_REQUIRE(op == 0 || op == 1, "debug_math: op must be 0 (exp) or 1 (log)");
+  PLS_REQUIRE(op >= 0 && op <= 3, "debug_math: op must be 0 (exp), 1 (log), 2 (fast_div) or 3 (fast_div_normal)");
   PLS_REQUIRE(x && out && n >= 0, "debug_math: bad arguments");
   if (n == 0) return PLS_OK;
   hipLaunchKernelGGL(debug_math_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, S(stream), op, x, out, n);
@@ -1693,8 +1666,6 @@ int64_t pls_get_option(int32_t option) {
   switch (option) {
     case PLS_OPT_SMALL_RANK_MAX: return g_small_rank_max.load();
     case PLS_OPT_IPB_EXPLICIT_INVERSE: return g_ipb_explicit_inverse.load();
-    case PLS_OPT_SMALL_RANK2_MAX: return g_small_rank2_max.load();
-    case PLS_OPT_SMALL_RANK2_MIN: return g_small_rank2_min.load();
     case PLS_OPT_SOLVE_MODE: return g_solve_mode.load();
     case PLS_OPT_KSPLIT_MODE: return g_ksplit_mode.load();
     case PLS_OPT_KSPLIT_MAX_TILES: return g_ksplit_max_tiles.load();

@@ -54,9 +54,7 @@ def test_options_validate_without_touching_the_gpu():
     assert lib.pls_set_option(L.OPT_KSPLIT_MODE, 4) != 0 and lib.pls_set_option(L.OPT_KSPLIT_MAX_TILES, -1) != 0
     assert lib.pls_set_option(L.OPT_KSPLIT_MODE, 0) == 0 and lib.pls_get_option(L.OPT_KSPLIT_MODE) == 0
     assert lib.pls_set_option(L.OPT_KSPLIT_MODE, 1) == 0
-    assert (lib.pls_get_option(L.OPT_SMALL_RANK2_MIN), lib.pls_get_option(L.OPT_SMALL_RANK2_MAX)) == (161, 0)
-    assert lib.pls_set_option(L.OPT_SMALL_RANK2_MAX, 100) != 0 and lib.pls_set_option(L.OPT_SMALL_RANK2_MIN, 0) != 0
-    assert lib.pls_set_option(L.OPT_SMALL_RANK2_MAX, 240) == 0 and lib.pls_set_option(L.OPT_SMALL_RANK2_MAX, 0) == 0
+    assert lib.pls_get_option(6) == -1 and lib.pls_set_option(7, 200) != 0  # (ABI 3's wave-pair kernel options: gone)
     assert lib.pls_get_option(L.OPT_ROW_BLOCKS) == 1 and lib.pls_set_option(L.OPT_ROW_BLOCKS, 2) != 0
     assert lib.pls_set_option(L.OPT_ROW_BLOCKS, 0) == 0 and lib.pls_set_option(L.OPT_ROW_BLOCKS, 1) == 0
     assert lib.pls_get_option(L.OPT_SOLVE_MODE) == 1 and lib.pls_set_option(L.OPT_SOLVE_MODE, 2) != 0

@@ -408,6 +408,26 @@ def test_device_math_matches_libm(P):
     assert ulps(got[nz], want[nz]).max() <= 2.0 and np.all(got[~nz] == 0.0)
     sp = run(1, np.array([0.0, -0.0, np.inf, np.nan, -1.0]))
     assert sp[0] == -np.inf and sp[1] == -np.inf and sp[2] == np.inf and np.isnan(sp[3]) and np.isnan(sp[4])
+    # division (reciprocal seed + ONE Newton step + residual correction): quotients of operands all over the normal range,
+    # near-equal operands, the -2 y / f of the Poisson derivative (integer counts over O(1) function values)
+    def run2(op, a, b):
+        xd = torch.from_numpy(np.concatenate([a, b])).cuda()
+        out = torch.empty(a.shape[0], dtype=torch.float64, device="cuda")
+        L.check(L.load().pls_debug_math(op, xd.data_ptr(), out.data_ptr(), a.shape[0], L.stream_ptr()), "pls_debug_math")
+        return out.cpu().numpy()
+
+    a = np.concatenate([rng.normal(0, 1, 300000) * np.exp(rng.uniform(-300, 300, 300000)), rng.normal(0, 1, 200000),
+                        -2.0 * rng.poisson(3.0, 200000).astype(np.float64), 1.0 + rng.normal(0, 1e-9, 50000)])
+    b = np.concatenate([rng.normal(0, 1, 300000) * np.exp(rng.uniform(-300, 300, 300000)), rng.normal(0, 1, 200000),
+                        rng.normal(0, 1.5, 200000), 1.0 + rng.normal(0, 1e-9, 50000)])
+    with np.errstate(over="ignore", under="ignore", divide="ignore", invalid="ignore"):
+        want = a / b
+    ok = np.isfinite(want) & (np.abs(want) > 1e-290) & (np.abs(want) < 1e290) & (np.abs(b) > 1e-290) & (np.abs(b) < 1e290)
+    for op in (2, 3):
+        got = run2(op, a, b)
+        assert ulps(got[ok], want[ok]).max() <= 1.0, op
+    sp = run2(2, np.array([1.0, -1.0, 0.0, 1.0, np.inf, np.nan, 3.0]), np.array([0.0, 0.0, 0.0, np.inf, 2.0, 1.0, np.nan]))
+    assert sp[0] == np.inf and sp[1] == -np.inf and np.isnan(sp[2]) and sp[3] == 0.0 and sp[4] == np.inf and np.isnan(sp[5]) and np.isnan(sp[6])
 
 
 def test_costs_vs_oracle_all_pairs(P):

@@ -9,7 +9,7 @@ from projected_langevin_sampling_amd.costs import GaussianCost
 from projected_langevin_sampling_amd.link_functions import IdentityLinkFunction
 
 lib = L.load()
-L.check(lib.pls_set_option(L.OPT_SMALL_RANK2_MAX, 0))
+
 ranks = [int(a) for a in sys.argv[1].split(",")] if len(sys.argv) > 1 else [129, 144, 160, 176, 192, 208, 224, 240, 272, 288, 300, 320, 352, 400, 500, 1000]
 n, j = 100000, 8192
 for mk in ranks:

@@ -2,7 +2,7 @@
 four s_memtime stamps per workgroup: start, after the prologue barrier, after the k-loop, after the epilogue, plus
 HW_ID / XCC_ID so the per-CU timeline (residency, launch gaps, tail) can be rebuilt).
 Build:  (cd projected-langevin-sampling_amd/csrc && hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DPLS_STAMP -shared \
-         -o ../../tools/libplship_stamp.so plship.hip gemm_cost.hip gemm_cost_value.hip small_rank_drift.hip small_rank_value.hip small_rank_drift_value.hip small_rank2_drift.hip small_rank2_drift_value.hip chol.hip)
+         -o ../../tools/libplship_stamp.so plship.hip gemm_cost.hip gemm_cost_value.hip small_rank_drift.hip small_rank_value.hip small_rank_drift_value.hip chol.hip)
 Read the SHARES, not the lengths: the stamps serialise what the real kernel overlaps."""
 import ctypes as C, os, sys, torch
 HERE = os.path.dirname(os.path.abspath(__file__))
