@@ -110,22 +110,34 @@ class PLSCost(ABC):
         )
         return g
 
-    def sample_observation_noise(self, number_of_particles: int, seed: int | None = None) -> torch.Tensor:
-        """costs/base.py:86-115 (CPU generator stream kept, then moved to the device)."""
+    def sample_observation_noise(self, number_of_particles: int, seed: int | None = None, j_offset: int = 0,
+                                 normal_stream: str | None = None) -> torch.Tensor:
+        """costs/base.py:86-115: one N(0, observation_noise^2) draw per particle (observation_noise is a STD here, SURVEY
+        H6).  The normals come from samplers.DEFAULT_NORMAL_STREAM: "device" = libplship's generator keyed by ``seed`` (or
+        one draw from torch's global generator) and the GLOBAL particle index ``j_offset`` + column, so a J-sharded
+        prediction gives every particle its own draw whatever the GPU count; "reference" = torch.normal on the host
+        generator, the reference's stream."""
         if self.observation_noise is None:
             return torch.zeros(number_of_particles, dtype=torch.float64, device="cuda")
-        generator = torch.Generator().manual_seed(seed) if seed is not None else None
-        noise = torch.normal(
-            mean=0.0, std=self.observation_noise, size=(number_of_particles,), generator=generator
-        ).flatten()
-        return _dev(noise)
+        from .. import samplers
+
+        stream = normal_stream or samplers.DEFAULT_NORMAL_STREAM
+        if stream == "reference":
+            generator = torch.Generator().manual_seed(seed) if seed is not None else None
+            noise = torch.normal(
+                mean=0.0, std=self.observation_noise, size=(number_of_particles,), generator=generator
+            ).flatten()
+            return _dev(noise)
+        z = samplers.standard_normals(1, (number_of_particles,), seed=seed, normal_stream="device", j_offset=j_offset)
+        return (z.reshape(-1) * float(self.observation_noise)).contiguous()
 
     def predict_samples(
-        self, untransformed_samples: torch.Tensor, observation_noise: torch.Tensor | None = None
+        self, untransformed_samples: torch.Tensor, observation_noise: torch.Tensor | None = None, j_offset: int = 0
     ) -> torch.Tensor:
-        """costs/base.py:117-133."""
+        """costs/base.py:117-133.  ``j_offset`` (extension): global index of the first particle column (J-sharded runs)."""
         if observation_noise is None:
-            observation_noise = self.sample_observation_noise(number_of_particles=untransformed_samples.shape[1])
+            observation_noise = self.sample_observation_noise(number_of_particles=untransformed_samples.shape[1],
+                                                              j_offset=j_offset)
         if getattr(self.link_function, "kind", None) is not None:  # one kernel: link(f + eps_j)
             return self.link_function._native_transform(untransformed_samples, col_offset=_dev(observation_noise))
         return self.link_function(untransformed_samples + observation_noise[None, :])

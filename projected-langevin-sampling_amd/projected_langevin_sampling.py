@@ -109,6 +109,11 @@ class PLS:
     def predict_samples(self, particles: torch.Tensor, x: torch.Tensor, predictive_noise: torch.Tensor | None = None,
                         observation_noise: torch.Tensor | None = None) -> torch.Tensor:
         untransformed_samples = self.predict_untransformed_samples(particles=particles, x=x, noise=predictive_noise)
+        j_offset = getattr(self.basis, "j_offset", 0)
+        if observation_noise is None and j_offset and getattr(self.cost, "is_native", lambda: False)():
+            # (a J-sharded run: the library's costs key their per-particle draw by the GLOBAL particle column)
+            return self.cost.predict_samples(untransformed_samples=untransformed_samples, observation_noise=None,
+                                             j_offset=j_offset)
         return self.cost.predict_samples(untransformed_samples=untransformed_samples, observation_noise=observation_noise)
 
     def predict_untransformed_samples(self, particles: torch.Tensor, x: torch.Tensor,

@@ -109,7 +109,7 @@ def _products(P, d, u, guard=3):
 # (M, J): two tile rows .. sixteen; odd counts (a middle row that pairs with itself); ragged last tile rows and columns;
 # a single column; M a little above one tile (the second row holds one line)
 SHAPES = [(128, 64), (65, 100), (130, 1), (192, 192), (200, 130), (320, 64), (511, 77), (512, 256), (1000, 200),
-          (1024, 1024), (1024, 1000), (1088, 320)]
+          (1024, 1024), (1024, 1000), (1088, 320), (2048, 1024), (4096, 512)]
 
 
 @pytest.mark.parametrize("m,j", SHAPES)

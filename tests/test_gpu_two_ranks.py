@@ -1,0 +1,140 @@
+"""GPU, two processes on ONE card over gloo: the J-sharded run end to end through the drop-in classes.
+
+No multi-GPU node is reachable from here, so RCCL with more than one rank cannot run; what CAN run is every line of the
+sharded control flow with real device kernels: both ranks build the orthonormal basis under an initialised process group
+(rank 0's eigh, broadcast: basis/spectrum.py), attach their column shards, step with the library's noise keyed by GLOBAL
+column indices, reduce the energy and the predictive moments across ranks, and save / resume a checkpoint -- and the parent
+process holds the concatenated shards to the unsharded run, bit for bit."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _relerr(a, b):
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-300)).item()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _problem():
+    g = torch.Generator().manual_seed(77)
+    n, m, d, j = 3000, 200, 3, 330
+    x = torch.rand(n, d, generator=g, dtype=torch.float64) * 2 - 1
+    z = x[torch.randperm(n, generator=g)[:m]].clone()
+    w = torch.randn(d, generator=g, dtype=torch.float64)
+    y = torch.sin(2.0 * (x @ w)) + 0.1 * torch.randn(n, generator=g, dtype=torch.float64)
+    ls = 0.3 + 0.3 * torch.rand(d, generator=g, dtype=torch.float64)
+    xs = torch.rand(11, d, generator=g, dtype=torch.float64) * 2 - 1
+    return x, z, y, ls, xs, j
+
+
+def _build(eigh_device, group=None):
+    import projected_langevin_sampling_amd as pkg
+    from projected_langevin_sampling_amd.basis import OrthonormalBasis
+    from projected_langevin_sampling_amd.costs import GaussianCost
+    from projected_langevin_sampling_amd.link_functions import IdentityLinkFunction
+
+    x, z, y, ls, xs, j = _problem()
+    basis = OrthonormalBasis(pkg.PLSKernel(pkg.ARDKernel(ls, 1.2), z), z, x, 1e-6, verbose=False, eigh_device=eigh_device, group=group)
+    cost = GaussianCost(0.3, y, IdentityLinkFunction())
+    return pkg, basis, cost, xs, j
+
+
+def _steps(basis, cost, u, first, count, seed=4242):
+    from projected_langevin_sampling_amd.basis import NoiseSpec
+
+    eta = 0.5 * float(basis.eigenvalues.min())  # eta / lambda_min < 2: a stable chain, rounding stays rounding
+    cur, nxt = u.clone(), torch.empty_like(u)
+    for t in range(first, first + count):
+        basis.fused_step(cost, cur, eta, out=nxt, new_state=True, noise=NoiseSpec(seed=seed, step=t, j_offset=basis.j_offset))
+        cur, nxt = nxt, cur
+    return cur
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_default_dtype(torch.float64)
+    torch.cuda.set_device(0)  # both ranks share the one card of this box
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from projected_langevin_sampling_amd import checkpoint, samplers
+    from projected_langevin_sampling_amd import distributed as D
+
+    samplers.DEFAULT_NORMAL_STREAM = "device"
+    pkg, basis, cost, xs, j = _build("cuda")  # collective: rank 0 factorises, everybody receives the same bits
+    mk = basis.approximation_dimension
+    j0, j1 = D.attach_shard(basis, j, rank, world)
+    u0 = torch.randn(mk, j, generator=torch.Generator().manual_seed(5), dtype=torch.float64)
+    mine = _steps(basis, cost, u0[:, j0:j1].contiguous().cuda(), 0, 6)
+    pls = pkg.PLS(basis, cost)
+    # C1: the mean energy over ALL particles
+    energy = D.mean_over_particles(pls.particle_energy_potential(mine), j)
+    # C2: predictive moments over ALL particles, noise keyed by the global column
+    torch.manual_seed(9)
+    samples = pls.predict_samples(mine, xs)
+    mean, var = D.predictive_moments(samples, j)
+    # checkpoint: save mid-run, rebuild the basis (the same collective), resume
+    path = os.path.join(out_dir, f"rank{rank}.pth")
+    mid = _steps(basis, cost, u0[:, j0:j1].contiguous().cuda(), 0, 3)
+    checkpoint.save_pls(pls, mid, path, noise_step=3, number_of_particles=j)
+    pkg2, basis2, cost2, _, _ = _build("cuda")
+    D.attach_shard(basis2, j, rank, world)
+    _, restored, _, _ = checkpoint.load_pls(pkg2.PLS(basis2, cost2), path)
+    resumed = _steps(basis2, cost2, restored, 3, 3)
+    assert torch.equal(resumed, mine), "resume under the shared device gauge != uninterrupted shard"
+    torch.save({"particles": mine.cpu(), "energy": energy, "mean": mean.cpu(), "var": var.cpu(), "samples": samples.cpu(),
+                "lam": basis.eigenvalues.cpu(), "vec": basis.eigenvectors.cpu(), "j0": j0, "j1": j1},
+               os.path.join(out_dir, f"out{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_equal_the_unsharded_run(tmp_path):
+    assert torch.cuda.is_available(), "this test needs the MI355X"
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+        outs = [torch.load(tmp_path / f"out{r}.pt", weights_only=False) for r in range(2)]
+        assert torch.equal(outs[0]["lam"], outs[1]["lam"]) and torch.equal(outs[0]["vec"], outs[1]["vec"])  # ONE spectrum
+        # the unsharded run in this process, with the spectrum the job agreed on
+        from projected_langevin_sampling_amd import distributed as D
+        from projected_langevin_sampling_amd import samplers
+
+        pkg, basis, cost, xs, j = _build("cuda")
+        assert torch.equal(basis.eigenvalues.cpu(), outs[0]["lam"]) and torch.equal(basis.eigenvectors.cpu(), outs[0]["vec"])
+        mk = basis.approximation_dimension
+        u0 = torch.randn(mk, j, generator=torch.Generator().manual_seed(5), dtype=torch.float64)
+        whole = _steps(basis, cost, u0.cuda(), 0, 6)
+        got = torch.cat([o["particles"] for o in outs], dim=1)
+        assert [(o["j0"], o["j1"]) for o in outs] == [D.shard_bounds(j, r, 2) for r in range(2)]
+        # (a shard of 165 columns and the full 330 may take different tile configurations: equal to rounding, not bit for bit)
+        assert _relerr(got, whole.cpu()) < 1e-12, "sharded particles != unsharded run"
+        pls = pkg.PLS(basis, cost)
+        e_whole = pls.particle_energy_potential(whole).mean().item()
+        assert all(abs(o["energy"] - e_whole) <= 1e-12 * abs(e_whole) for o in outs)
+        prev_stream = samplers.DEFAULT_NORMAL_STREAM
+        samplers.DEFAULT_NORMAL_STREAM = "device"
+        try:
+            torch.manual_seed(9)
+            s_whole = pls.predict_samples(whole, xs).cpu()
+        finally:
+            samplers.DEFAULT_NORMAL_STREAM = prev_stream
+        assert _relerr(torch.cat([o["samples"] for o in outs], dim=1), s_whole) < 1e-11, "predictive samples depend on the rank count"
+        for o in outs:
+            assert torch.allclose(o["mean"], s_whole.mean(dim=1), rtol=1e-12, atol=1e-14)
+            assert torch.allclose(o["var"], s_whole.var(dim=1), rtol=1e-10)
+    finally:
+        torch.set_default_dtype(prev)
