@@ -231,6 +231,24 @@ typedef struct {
    * energy_sums (the values the finishing launch computes, bit for bit) -- so a training iteration is ONE launch.  Calls
    * that may run concurrently need different counters.  NULL (or any other route): a finishing launch follows. */
   uint32_t *energy_sync;
+  /* Optional (ABI 4), LAGGED energies for training loops on the Gaussian/identity fast paths (pls_onb_step_blocks,
+   * pls_ipb_whitened_step_blocks).  The reduction of a step's energy by-product over the tile rows is a global dependency
+   * behind its last MFMA: finished inside the launch it adds 4.4-5 us of serial tail, as a launch of its own 6-9 us.  Instead:
+   *   energy_partials       (out) this launch leaves ONLY its partial rows here (pls_energy_partials_bytes(rows, j) bytes;
+   *                         energy_in / energy_sums / energy_sync are then not used);
+   *   energy_partials_prev  (in)  the partial rows the PREVIOUS launch of the loop left (another buffer: alternate two); this
+   *                         launch finishes them at its START, under the landing of its first operand rows, into
+   *   energy_prev           (out) the J energies of the previous launch's input particles, and
+   *   energy_sums_prev      (out, optional) their 256-column chunk sums (may be pinned host memory);
+   *   energy_flush          1: no step at all -- the last launch's partial rows are finished by a small launch of their own
+   *                         (pass the particle matrix and step arguments of the step calls; out may be NULL).
+   * The values are the ones the other forms compute, bit for bit; they arrive one launch later. */
+  double *energy_partials;
+  const double *energy_partials_prev;
+  double *energy_prev;
+  double *energy_sums_prev;
+  int32_t energy_flush;
+  int32_t reserved;
 } pls_block_desc;
 
 const char *pls_last_error(void);
@@ -455,6 +473,10 @@ size_t pls_onb_step_workspace_bytes(const pls_onb_desc *basis, int64_t j, int64_
 int pls_onb_step(const pls_onb_desc *basis, const pls_cost_desc *cost, const double *y, double *U, int64_t ldu,
                  int64_t j, double eta, const pls_noise_desc *noise, double *out, int64_t ldo, int32_t out_mode,
                  int32_t force_generic, double *energy_in, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Bytes of pls_block_desc.energy_partials for a basis with `rows` functions (Mk, or M of the inducing-point basis) and j
+ * particle columns. */
+size_t pls_energy_partials_bytes(int64_t rows, int64_t j);
 
 /* pls_onb_step with one step size PER COLUMN BLOCK (pls_block_desc): the batched step-size search. */
 int pls_onb_step_blocks(const pls_onb_desc *basis, const pls_cost_desc *cost, const double *y, double *U, int64_t ldu,

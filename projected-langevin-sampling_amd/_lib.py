@@ -118,7 +118,9 @@ class CholDesc(C.Structure):
 
 
 class BlockDesc(C.Structure):
-    _fields_ = [("block_cols", C.c_int64), ("eta", C.c_void_p), ("energy_sums", C.c_void_p), ("energy_sync", C.c_void_p)]
+    _fields_ = [("block_cols", C.c_int64), ("eta", C.c_void_p), ("energy_sums", C.c_void_p), ("energy_sync", C.c_void_p),
+                ("energy_partials", C.c_void_p), ("energy_partials_prev", C.c_void_p), ("energy_prev", C.c_void_p),
+                ("energy_sums_prev", C.c_void_p), ("energy_flush", C.c_int32), ("reserved", C.c_int32)]
 
 
 _P, _I64, _I32, _U64, _D, _SZ = C.c_void_p, C.c_int64, C.c_int32, C.c_uint64, C.c_double, C.c_size_t
@@ -173,6 +175,7 @@ SIGNATURES = {
     "pls_chol_forward_solve": (C.c_int, [_CHD, _P, _I64, _I64, _P, _I64, _P]),
     "pls_chol_solve_workspace_bytes": (_SZ, [_I64, _I64]),
     "pls_tri_scratch_bytes": (_SZ, [_I64, _I64]),
+    "pls_energy_partials_bytes": (_SZ, [_I64, _I64]),
     "pls_chol_solve_ws": (C.c_int, [_CHD, _P, _I64, _I64, _P, _I64, _P, _SZ, _P]),
     "pls_ipb_build_whitened_workspace_bytes": (_SZ, [_I64]),
     "pls_ipb_build_whitened": (C.c_int, [_ID, _D, _P, _I64, _P, _P, _SZ, _P]),

@@ -51,7 +51,9 @@ class BlockSpec:
     freezes a block."""
 
     def __init__(self, block_cols: int, eta: torch.Tensor, energy_sums: int | None = None,
-                 energy_sync: torch.Tensor | None = None):
+                 energy_sync: torch.Tensor | None = None, energy_partials: torch.Tensor | None = None,
+                 energy_partials_prev: torch.Tensor | None = None, energy_prev: torch.Tensor | None = None,
+                 energy_sums_prev: int | None = None, energy_flush: bool = False):
         """``energy_sums`` (optional): raw address (device, or pinned host memory) of cdiv(J, 256) doubles that receive the
         256-column chunk sums of the per-particle energies from the launch that finishes the step's energy by-product
         (Gaussian/identity fast paths; see pls_block_desc)."""
@@ -64,12 +66,27 @@ class BlockSpec:
         if energy_sync is not None:
             assert energy_sync.device.type == "cuda" and energy_sync.dtype == torch.int32 and energy_sync.is_contiguous()
         self.energy_sync = energy_sync
+        #: LAGGED energies (pls_block_desc.energy_partials ...): this launch leaves its partial rows in ``energy_partials``
+        #: and finishes the previous launch's (``energy_partials_prev``) into ``energy_prev`` (J device doubles) and, optionally,
+        #: ``energy_sums_prev`` (raw address of cdiv(J, 256) doubles, device or pinned host memory); ``energy_flush``: no
+        #: step, only that finish (BasisWithFlush.flush_energies)
+        for t in (energy_partials, energy_partials_prev, energy_prev):
+            if t is not None:
+                L.require_gpu_tensor(t, "energy buffer")
+                assert t.is_contiguous()
+        self.energy_partials, self.energy_partials_prev, self.energy_prev = energy_partials, energy_partials_prev, energy_prev
+        self.energy_sums_prev, self.energy_flush = energy_sums_prev, bool(energy_flush)
 
     def desc(self) -> L.BlockDesc:
         d = L.BlockDesc()
         d.block_cols, d.eta = self.block_cols, self.eta.data_ptr()
         d.energy_sums = self.energy_sums
         d.energy_sync = None if self.energy_sync is None else self.energy_sync.data_ptr()
+        d.energy_partials = None if self.energy_partials is None else self.energy_partials.data_ptr()
+        d.energy_partials_prev = None if self.energy_partials_prev is None else self.energy_partials_prev.data_ptr()
+        d.energy_prev = None if self.energy_prev is None else self.energy_prev.data_ptr()
+        d.energy_sums_prev = self.energy_sums_prev
+        d.energy_flush = 1 if self.energy_flush else 0
         return d
 
 

@@ -202,6 +202,24 @@ class InducingPointBasis(PLSBasis):
                                                      L.stream_ptr()), "pls_ipb_whitened_step_blocks")
         return out
 
+    def supports_lagged_energies(self, cost) -> bool:
+        """(see OrthonormalBasis.supports_lagged_energies) -- for loops that stay in whitened coordinates"""
+        return self.supports_energy_sums(cost)
+
+    def energy_partial_rows_bytes(self, j: int) -> int:
+        return int(L.load().pls_energy_partials_bytes(self.approximation_dimension, j))
+
+    def flush_energies(self, cost, state: torch.Tensor, blocks: BlockSpec) -> None:
+        """(see OrthonormalBasis.flush_energies); ``state`` = the WHITENED particle matrix of the whitened_step calls"""
+        s = _rows_contiguous(L.require_gpu_tensor(state, "whitened particles"))
+        self._prepare_for(cost)
+        nd = NoiseSpec(none=True).desc()
+        L.check(
+            L.load().pls_ipb_whitened_step_blocks(self._desc(with_gaussian=True), cost.desc(), s.data_ptr(), L.ld(s), s.shape[1],
+                                                  blocks.desc(), nd, None, 0, L.OUT_DELTA, None, None, 0, L.stream_ptr()),
+            "pls_ipb_whitened_step_blocks",
+        )
+
     def whitened_particle_energy(self, cost, whitened: torch.Tensor) -> torch.Tensor:
         """e_j of whitened particles: S^T Q S / 2 - c~^T S + y^T y / (2 sigma2) (pls_ipb_whitened_energy)."""
         s = _rows_contiguous(L.require_gpu_tensor(whitened, "whitened particles"))

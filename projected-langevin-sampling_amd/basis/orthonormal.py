@@ -318,6 +318,29 @@ class OrthonormalBasis(PLSBasis):
             )
         return out
 
+    #: fused_step itself takes BlockSpec.energy_partials (the inducing-point basis only in whitened_step)
+    fused_step_takes_lagged_energies = True
+
+    def supports_lagged_energies(self, cost) -> bool:
+        """True if a training loop may let launch k + 1 finish the energies of launch k (BlockSpec.energy_partials ...): the
+        Gaussian/identity fast path."""
+        return self.supports_energy_sums(cost)
+
+    def energy_partial_rows_bytes(self, j: int) -> int:
+        return int(L.load().pls_energy_partials_bytes(self.approximation_dimension, j))
+
+    def flush_energies(self, cost, state: torch.Tensor, blocks: BlockSpec) -> None:
+        """Finish the partial rows the LAST step launch of a loop left (``blocks``: energy_flush=True, energy_partials_prev,
+        energy_prev[, energy_sums_prev]); ``state``: the particle matrix the step calls were given (same shape / strides)."""
+        u = _rows_contiguous(L.require_gpu_tensor(state, "particles"))
+        self.prepare_gaussian(cost.y_device())
+        nd = NoiseSpec(none=True).desc()
+        L.check(
+            L.load().pls_onb_step_blocks(self._desc(with_gaussian=True), cost.desc(), cost.y_device().data_ptr(), u.data_ptr(), L.ld(u),
+                                         u.shape[1], blocks.desc(), nd, None, 0, L.OUT_DELTA, 0, None, None, 0, L.stream_ptr()),
+            "pls_onb_step_blocks",
+        )
+
     def fused_particle_energy(self, cost, particles: torch.Tensor, force_generic: bool = False) -> torch.Tensor:
         """Per-particle energy (pls_onb_energy): the cost is reduced inside a GEMM epilogue -- the N x Mk x J forward
         GEMM in general, the Mk x Mk x J quadratic form for Gaussian/identity."""

@@ -391,6 +391,14 @@ __device__ __forceinline__ void gemm_tn_mainloop(const GemmShape &g, int64_t i0,
   }
 }
 
+// An epilogue may carry a PROLOGUE: work some workgroups do at the START of the launch for the launch before it (the Langevin
+// epilogue finishes the previous step's energies there, under the landing of the first operand rows: prev_owner / prev_reduce /
+// prev_store).  Detected by the member's presence.
+template <class E, class = void>
+struct epi_has_prev : std::false_type {};
+template <class E>
+struct epi_has_prev<E, std::void_t<decltype(&E::prev_owner)>> : std::true_type {};
+
 // largest leading dimension (doubles) the direct epilogue addresses with 32-bit byte offsets (67 rows * ld * 8 < 2^31)
 constexpr int64_t kDirectMaxLd = (int64_t)1 << 21;
 
@@ -479,6 +487,13 @@ __global__ __launch_bounds__((BI / WI) * (BJ / WJ) * 64, MINW) void gemm_tn_f64_
    }
   }
   gemm_tile_coords(blockIdx.x, g.nti, g.ntj, tile_i, tile_j);
+  if constexpr (epi_has_prev<Epilogue>::value) {
+    if (epi.prev_owner(tile_i, tile_j)) {  // (workgroup-uniform; two workgroups share a CU here: the other one covers this)
+      double v, tot;
+      epi.prev_reduce(tile_j, v, tot);
+      epi.prev_store(tile_j, v, tot);
+    }
+  }
   gemm_tile<BI, BJ, WI, WJ, BK>(g, epi, tile_i, tile_j, lds);
 }
 

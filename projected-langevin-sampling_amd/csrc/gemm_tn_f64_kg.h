@@ -48,9 +48,11 @@ struct KgNoHook {
 // wave has drained its vector-memory operations (s_waitcnt vmcnt(0): the first operand rows have landed -- and whatever the
 // wave stored before the call has been performed).  The balanced triangular kernel signals a published partial sum from
 // there, so that the store drain rides on the wait the first k-step needs anyway.
-template <int KG, class Hook = KgNoHook>
+// pre(): called once by every thread right after the first operand rows have been REQUESTED (or at once if the k range holds
+// no full super-step): work placed there -- it may hold workgroup barriers -- runs while those rows travel.
+template <int KG, class Hook = KgNoHook, class Pre = KgNoHook>
 __device__ __forceinline__ void kg_contract(const GemmShape &g, int64_t i0, int64_t j0, int64_t kbeg, int64_t kend, double *lds,
-                                            AccFrag<2, 2> &acc, Hook hook = Hook{}) {
+                                            AccFrag<2, 2> &acc, Hook hook = Hook{}, Pre pre = Pre{}) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using G = KgGeom<KG>;
   constexpr int NW = G::NW, NT = G::NT, SROWS = G::SROWS, TILE = G::TILE, BUF = G::BUF;
@@ -137,9 +139,11 @@ __device__ __forceinline__ void kg_contract(const GemmShape &g, int64_t i0, int6
   // straight-line code, the odd step still inside the pipeline (its rows are requested and its first fragments fetched by
   // the last pair).
   bool hooked = false;
+  if (nS == 0) pre();
   if (nS > 0) {
     double fa[2], fb[2], ga[2], gb[2];
     dma_load(0);
+    pre();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (what the barrier needs anyway: the rows have landed)
     __syncthreads();
     hook();
@@ -297,7 +301,19 @@ __global__ __launch_bounds__(256 * KG, 4) void gemm_tn_f64_kg_kernel(GemmShape g
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc.v[a][b] = double4_t{0.0, 0.0, 0.0, 0.0};
-  kg_contract<KG>(g, i0, j0, kbeg, kend, lds, acc);
+  if constexpr (epi_has_prev<Epilogue>::value) {
+    // this workgroup may finish a chunk of the PREVIOUS launch's energies: loads and sums under the landing of its first
+    // operand rows, the results kept in two registers and stored behind the k-loop (a store in front of it would be waited
+    // for at the first barrier -- the chunk sum may travel to pinned host memory)
+    const bool owner = epi.prev_owner(tile_i, tile_j);  // (workgroup-uniform)
+    double pv = 0.0, ptot = 0.0;
+    kg_contract<KG>(g, i0, j0, kbeg, kend, lds, acc, KgNoHook{}, [&]() {
+      if (owner) epi.prev_reduce(tile_j, pv, ptot);
+    });
+    if (owner) epi.prev_store(tile_j, pv, ptot);
+  } else {
+    kg_contract<KG>(g, i0, j0, kbeg, kend, lds, acc);
+  }
 
   // ---- hand-over between the k-groups, then the epilogue on the sum ----
   if constexpr (KG == 1) {

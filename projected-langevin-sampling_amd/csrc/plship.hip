@@ -278,6 +278,58 @@ struct EpiLangevinGaussian {
     int nparts, nti;    // partial rows in epart; tile rows of the launch (arrivals per column tile)
   } fin;
 
+  // Optional (pls_block_desc.energy_partials_prev): this launch FINISHES the energies of the launch before it -- whose partial
+  // rows a kernel boundary has made visible -- at its start: the workgroup of tile row 0 whose tile begins a 256-column chunk
+  // adds the chunk's partial rows in ascending order, + the constant, and the chunk's sum in the library's fixed order: the
+  // finishing kernel's values, bit for bit, with no tail behind any launch (the energies arrive one launch later).
+  struct Prev {
+    const double *part;  // previous launch's partial rows (nparts x J, leading dimension J); NULL: nothing to finish
+    double *e;           // (J) their energies
+    double *sums;        // cdiv(J, 256) chunk sums, may be NULL / pinned host memory
+    double yscale;
+    const double *yty;
+    int nparts;
+  } prev;
+
+  __device__ __forceinline__ bool prev_owner(int tile_i, int tile_j) const {
+    return prev.part != nullptr && tile_i == 0 && (((int64_t)tile_j * bj) & 255) == 0;
+  }
+  __device__ __forceinline__ void prev_reduce(int tile_j, double &v, double &tot) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ double pws[4];
+    const int tid = threadIdx.x;
+    const int64_t J = ldp, c0 = (int64_t)tile_j * bj, col = c0 + tid;
+    v = 0.0;
+    if (tid < 256 && col < J) {
+      double s = 0.0;
+      for (int p0 = 0; p0 < prev.nparts; p0 += 8) {  // eight loads in flight, added in ascending row order
+        double t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = (p0 + k < prev.nparts) ? prev.part[(int64_t)(p0 + k) * J + col] : 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (p0 + k < prev.nparts) s += t[k];
+      }
+      v = s + prev.yscale * (*prev.yty);
+    }
+    double r = v;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) r += __shfl_xor(r, o);
+    __syncthreads();  // (pws may still be read by an earlier use)
+    if (tid < 256 && (tid & 63) == 0) pws[tid >> 6] = r;
+    __syncthreads();
+    tot = (pws[0] + pws[1]) + (pws[2] + pws[3]);
+#else
+    (void)tile_j, (void)v, (void)tot;
+#endif
+  }
+  __device__ __forceinline__ void prev_store(int tile_j, double v, double tot) const {
+    const int tid = threadIdx.x;
+    const int64_t J = ldp, c0 = (int64_t)tile_j * bj, col = c0 + tid;
+    if (tid < 256 && col < J) prev.e[col] = v;
+    if (tid == 0 && prev.sums) prev.sums[c0 >> 8] = tot;
+  }
+
   __device__ __forceinline__ void store_partial(double *p, double v) const {
 #if defined(__HIP_DEVICE_COMPILE__)
     if (fin.sync)
@@ -1546,25 +1598,64 @@ struct FastOp {
   const double *yty;
 };
 
+// LAGGED energies of a training loop (pls_block_desc.energy_partials ...): launch k leaves only the partial rows of its energy
+// by-product; launch k + 1 finishes them at its START (EpiLangevinGaussian::Prev), under the landing of its first operand
+// rows, so no launch carries the reduction's serial tail (4.4-5 us at the end of every step launch otherwise).
+struct EnergyLag {
+  double *partials_out = nullptr;
+  const double *partials_prev = nullptr;
+  double *e_prev = nullptr;
+  double *sums_prev = nullptr;
+  int flush = 0;
+};
+
+static EnergyLag make_lag(const pls_block_desc *b) {
+  EnergyLag l;
+  if (b) {
+    l.partials_out = b->energy_partials;
+    l.partials_prev = b->energy_partials_prev;
+    l.e_prev = b->energy_prev;
+    l.sums_prev = b->energy_sums_prev;
+    l.flush = b->energy_flush;
+  }
+  return l;
+}
+
+static int validate_lag(const pls_block_desc *b) {
+  if (!b) return PLS_OK;
+  PLS_REQUIRE(!b->energy_partials_prev || b->energy_prev, "step_blocks: energy_partials_prev needs energy_prev");
+  PLS_REQUIRE(!b->energy_flush || b->energy_partials_prev, "step_blocks: energy_flush needs energy_partials_prev");
+  PLS_REQUIRE(!b->energy_partials || b->energy_partials != b->energy_partials_prev,
+              "step_blocks: energy_partials and energy_partials_prev must be different buffers");
+  return PLS_OK;
+}
+
 static int fast_step_launch(const FastOp &op, const double *U, int64_t ldu, int64_t j, const EtaP &etap, const NoiseP &nz,
                             double *out, int64_t ldo, int out_mode, double *energy_in, void *workspace,
                             size_t workspace_bytes, hipStream_t st, const char *who, double *esums = nullptr,
-                            uint32_t *esync = nullptr) {
+                            uint32_t *esync = nullptr, const EnergyLag &lag = EnergyLag{}) {
   const bool big = pick_gemm_cfg(op.B, op.ldb, U, ldu, op.mk, j, op.mk) == CFG_BIG;
   const int64_t parts = big ? 2 * cdiv(op.mk, 128) : cdiv(op.mk, 64);
-  double *epart = nullptr;
-  if (energy_in) {
+  if (lag.flush) {  // no step: the partial rows of the LAST launch of a loop are finished by the finishing kernel
+    hipLaunchKernelGGL(gaussian_energy_finish_kernel, dim3((unsigned)cdiv(j, 256)), dim3(256), 0, st, lag.partials_prev, j, parts, j,
+                       lag.e_prev, op.yscale, op.yty, lag.sums_prev);
+    return check_launch("gaussian_energy_finish");
+  }
+  double *epart = lag.partials_out;
+  if (energy_in && !epart) {
     if (!workspace || workspace_bytes < (size_t)parts * j * sizeof(double))
       return fail(PLS_ERR_WORKSPACE_TOO_SMALL, "%s: energy by-product needs %zu workspace bytes", who,
                   (size_t)parts * j * sizeof(double));
     epart = static_cast<double *>(workspace);
   }
-  EpiLangevinGaussian e{out, ldo, U, ldu, op.c, op.lam, etap, op.inv_noise, out_mode, nz, epart, j, 2, big ? 128 : 64, {}};
-  const bool fused_finish = energy_in && esync && g_energy_fused_finish.load() != 0;
+  EpiLangevinGaussian e{out, ldo, U, ldu, op.c, op.lam, etap, op.inv_noise, out_mode, nz, epart, j, 2, big ? 128 : 64, {}, {}};
+  if (lag.partials_prev) e.prev = EpiLangevinGaussian::Prev{lag.partials_prev, lag.e_prev, lag.sums_prev, op.yscale, op.yty, (int)parts};
+  const bool lagged = lag.partials_out != nullptr;  // (the NEXT launch, or a flush, finishes this launch's energies)
+  const bool fused_finish = !lagged && energy_in && esync && g_energy_fused_finish.load() != 0;
   if (fused_finish)  // the step launch finishes the energies itself (pls_block_desc.energy_sync)
     e.fin = EpiLangevinGaussian::Finish{esync, energy_in, esums, op.yscale, op.yty, (int)parts, (int)cdiv(op.mk, big ? 128 : 64)};
   int rc = launch_gemm_any(op.B, op.ldb, U, ldu, op.mk, j, op.mk, e, st);
-  if (rc || !energy_in || fused_finish) return rc;
+  if (rc || lagged || !energy_in || fused_finish) return rc;
   hipLaunchKernelGGL(gaussian_energy_finish_kernel, dim3((unsigned)cdiv(j, 256)), dim3(256), 0, st, epart, j, parts, j,
                      energy_in, op.yscale, op.yty, esums);
   return check_launch("gaussian_energy_finish");
@@ -1611,6 +1702,10 @@ const char *pls_last_error(void) { return g_last_error.c_str(); }
 int pls_abi_version(void) { return PLSHIP_ABI_VERSION; }
 
 size_t pls_tri_scratch_bytes(int64_t m, int64_t j) { return (m > 0 && j > 0) ? kg_tri_scratch_bytes(m, j) : 0; }
+
+size_t pls_energy_partials_bytes(int64_t rows, int64_t j) {
+  return (rows > 0 && j > 0) ? (size_t)(2 * cdiv(rows, 128)) * j * sizeof(double) : 0;
+}
 
 int pls_set_option(int32_t option, int64_t value) {
   switch (option) {
@@ -2003,6 +2098,15 @@ static int onb_step_impl(const pls_onb_desc *basis, const pls_cost_desc *cost, c
   if (rc) return rc;
   rc = validate_blocks(blocks, j);
   if (rc) return rc;
+  rc = validate_lag(blocks);
+  if (rc) return rc;
+  if (blocks && blocks->energy_flush) {  // finish the last launch's partial rows; no step (U / ldu as in the step calls)
+    PLS_REQUIRE(onb_fast_path(basis, cost, force_generic), "onb_step: energy_flush is for the Gaussian/identity fast path");
+    PLS_REQUIRE(U && j > 0 && ldu >= j, "onb_step: energy_flush needs the particle matrix of the step calls");
+    const FastOp op{basis->B, basis->ldb, basis->c, basis->lam, basis->mk, 1.0 / cost->p[0], 0.5 / cost->p[0], basis->c + basis->mk};
+    return fast_step_launch(op, U, ldu, j, make_etap(eta, blocks), make_noisep(noise, blocks), nullptr, 0, 0, nullptr, nullptr, 0,
+                            S(stream), "onb_step", nullptr, nullptr, make_lag(blocks));
+  }
   PLS_REQUIRE(U && out && y, "onb_step: NULL pointer");
   PLS_REQUIRE(out != U, "onb_step: out must not alias U (ping-pong the particle buffers)");
   PLS_REQUIRE(j >= 0 && ldu >= j && ldo >= j, "onb_step: bad sizes");
@@ -2016,8 +2120,10 @@ static int onb_step_impl(const pls_onb_desc *basis, const pls_cost_desc *cost, c
   if (onb_fast_path(basis, cost, force_generic)) {
     const FastOp op{basis->B, basis->ldb, basis->c, basis->lam, basis->mk, 1.0 / cost->p[0], 0.5 / cost->p[0], basis->c + basis->mk};
     return fast_step_launch(op, U, ldu, j, etap, nz, out, ldo, out_mode, energy_in, workspace, workspace_bytes, st, "onb_step",
-                            blocks ? blocks->energy_sums : nullptr, blocks ? blocks->energy_sync : nullptr);
+                            blocks ? blocks->energy_sums : nullptr, blocks ? blocks->energy_sync : nullptr, make_lag(blocks));
   }
+  PLS_REQUIRE(!blocks || (!blocks->energy_partials && !blocks->energy_partials_prev),
+              "onb_step: lagged energies (energy_partials) exist on the Gaussian/identity fast path only");
   // workspace: [D slabs][cost partial rows (energy by-product)][G chunk]; the chunk length follows from what is left
   const size_t d_bytes = align_up((size_t)basis->mk * j * sizeof(double), 256);
   const int64_t max_slabs = onb_max_slabs(basis->mk, j, basis->n);
@@ -2277,6 +2383,8 @@ static int ipb_step_impl(const pls_ipb_desc *basis, const pls_cost_desc *cost, c
   if (rc) return rc;
   rc = validate_blocks(blocks, j);
   if (rc) return rc;
+  PLS_REQUIRE(!blocks || (!blocks->energy_partials && !blocks->energy_partials_prev && !blocks->energy_flush),
+              "ipb_step: lagged energies (energy_partials) exist on pls_onb_step_blocks and pls_ipb_whitened_step_blocks only");
   PLS_REQUIRE(U && out && y, "ipb_step: NULL pointer");
   PLS_REQUIRE(out != U, "ipb_step: out must not alias U");
   PLS_REQUIRE(j >= 0 && ldu >= j && ldo >= j && eta >= 0.0, "ipb_step: bad sizes");
@@ -2537,12 +2645,19 @@ static int ipb_whitened_step_impl(const pls_ipb_desc *basis, const pls_cost_desc
   PLS_REQUIRE(cost->cost == PLS_COST_GAUSSIAN && cost->link == PLS_LINK_IDENTITY, "ipb_whitened_step: Gaussian cost with the identity link only");
   PLS_REQUIRE(basis->Q && basis->ct && basis->q_inv_noise == 1.0 / cost->p[0],
               "ipb_whitened_step: the descriptor's Q / ct were not built for this observation noise (pls_ipb_build_whitened)");
+  rc = validate_lag(blocks);
+  if (rc) return rc;
+  if (blocks && blocks->energy_flush) {
+    PLS_REQUIRE(Sw && j > 0 && lds >= j, "ipb_whitened_step: energy_flush needs the particle matrix of the step calls");
+    return fast_step_launch(ipb_whitened_op(basis), Sw, lds, j, make_etap(eta, blocks), make_noisep(noise, blocks), nullptr, 0, 0,
+                            nullptr, nullptr, 0, S(stream), "ipb_whitened_step", nullptr, nullptr, make_lag(blocks));
+  }
   PLS_REQUIRE(Sw && out && out != Sw && j >= 0 && lds >= j && ldo >= j && eta >= 0.0, "ipb_whitened_step: bad arguments");
   PLS_REQUIRE(out_mode == 0 || out_mode == 1, "ipb_whitened_step: out_mode must be 0 or 1");
   if (j == 0) return PLS_OK;
   return fast_step_launch(ipb_whitened_op(basis), Sw, lds, j, make_etap(eta, blocks), make_noisep(noise, blocks), out, ldo,
                           out_mode, energy_in, workspace, workspace_bytes, S(stream), "ipb_whitened_step",
-                          blocks ? blocks->energy_sums : nullptr, blocks ? blocks->energy_sync : nullptr);
+                          blocks ? blocks->energy_sums : nullptr, blocks ? blocks->energy_sync : nullptr, make_lag(blocks));
 }
 
 int pls_ipb_whitened_step(const pls_ipb_desc *basis, const pls_cost_desc *cost, const double *Sw, int64_t lds, int64_t j,

@@ -115,6 +115,14 @@ class CapturedTraining:
         self._nchunk = (j + 255) // 256
         self._sums = torch.zeros(steps_per_replay, self._nchunk, dtype=torch.float64, device=particles.device)
         self._sync = torch.zeros(self._nchunk, dtype=torch.int32, device=particles.device)  # (pls_block_desc.energy_sync)
+        # lagged energies (trainers.LAGGED_ENERGIES): launch s + 1 of the replay finishes the energies of launch s at its start,
+        # one small finishing launch closes the replay
+        from . import trainers as _tr
+
+        self._lagged = bool(self._fused_sums and _tr.LAGGED_ENERGIES and getattr(pls.basis, "fused_step_takes_lagged_energies", False))
+        if self._lagged:
+            pbytes = pls.basis.energy_partial_rows_bytes(j)
+            self._parts = [torch.empty((pbytes + 7) // 8, dtype=torch.float64, device=particles.device) for _ in range(2)]
         self._eta = torch.full((1,), float(step_size), dtype=torch.float64, device=particles.device)
         self.counter = torch.zeros(1, dtype=torch.int64, device=particles.device)
         basis, cost = pls.basis, pls.cost
@@ -130,7 +138,15 @@ class CapturedTraining:
             cur, nxt = self.particles, self._pong
             for s in range(self.k):
                 spec = NoiseSpec(seed=self.seed, step=s, j_offset=basis.j_offset, step_base=self.counter)
-                if self._fused_sums:
+                if self._lagged:
+                    from .basis.base import BlockSpec
+
+                    blocks = BlockSpec(cur.shape[1], self._eta, energy_partials=self._parts[s % 2],
+                                       energy_partials_prev=self._parts[(s - 1) % 2] if s > 0 else None,
+                                       energy_prev=self._e if s > 0 else None,
+                                       energy_sums_prev=self._sums[s - 1].data_ptr() if s > 0 else None)
+                    basis.fused_step(cost, cur, self.step_size, out=nxt, new_state=True, noise=spec, blocks=blocks)
+                elif self._fused_sums:
                     from .basis.base import BlockSpec
 
                     blocks = BlockSpec(cur.shape[1], self._eta, energy_sums=self._sums[s].data_ptr(), energy_sync=self._sync)
@@ -141,6 +157,12 @@ class CapturedTraining:
                                      workspace=self._ws)
                     _ops.block_means(self._e, out=self.means[s: s + 1])  # E(U_{k0 + s}), the INPUT of launch k0 + s
                 cur, nxt = nxt, cur
+            if self._lagged:  # the last step's partial rows: a finishing launch of their own
+                from .basis.base import BlockSpec
+
+                basis.flush_energies(cost, cur, BlockSpec(cur.shape[1], self._eta, energy_partials_prev=self._parts[(self.k - 1) % 2],
+                                                          energy_prev=self._e, energy_sums_prev=self._sums[self.k - 1].data_ptr(),
+                                                          energy_flush=True))
             if cur is not self.particles:
                 self.particles.copy_(cur)
             L.check(L.load().pls_counter_add(self.counter.data_ptr(), self.k, L.stream_ptr()), "pls_counter_add")

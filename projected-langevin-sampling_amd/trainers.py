@@ -68,6 +68,10 @@ class _LoopSpace:
         fn = basis.whitened_step if self.whitened else basis.fused_step
         return fn(cost, state, float(step_size), out=out, new_state=True, noise=noise, input_energy=input_energy, blocks=blocks)
 
+    def flush(self, state, blocks) -> None:
+        """finish the partial rows of the last step launch (lagged energies: BlockSpec.energy_flush)"""
+        self.pls.basis.flush_energies(self.pls.cost, state, blocks)
+
     def energy(self, state) -> torch.Tensor:
         if self.whitened:
             return self.pls.basis.whitened_particle_energy(self.pls.cost, state)
@@ -157,6 +161,9 @@ def train_pls(
 #: share of an iteration 29 or 63 us, tools/train_loop_probe.py), and a queue of eight 0.27 ms launches rides that out.
 #: Costs depth + 1 particle buffers and up to `depth` speculative launches past the stop (discarded).
 IN_FLIGHT_DEPTH = 8
+#: Gaussian fast paths: launch k + 1 finishes the energies of launch k at its start (pls_block_desc.energy_partials ...), so
+#: that no launch carries the reduction's serial tail; False: every launch finishes its own (energy_sync)
+LAGGED_ENERGIES = True
 #: ... as long as the rotating particle buffers stay below this many bytes (depth is reduced, never below 2)
 IN_FLIGHT_BUFFER_BYTES = 4 << 30
 
@@ -203,6 +210,16 @@ def _train_pls_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs: in
     # ... and, with one zeroed counter per chunk (pls_block_desc.energy_sync), the step launch finishes the energies itself:
     # an iteration is ONE launch (the finishing launch was 5-6 us of a 47 us iteration on the shard of an 8-GPU run)
     sync = torch.zeros(nchunk, dtype=torch.int32, device=particles.device) if fused_sums else None
+    # ... or, better, launch k + 1 finishes the energies of launch k at its START, under the landing of its first operand rows
+    # (pls_block_desc.energy_partials / _prev): the reduction over the tile rows -- 4.4-5 us of serial tail behind the last MFMA
+    # when a launch finishes its own -- leaves the critical path altogether; E(U_k) then arrives with launch k + 1, and the
+    # last launch's partial rows are finished by a small launch of their own (flush)
+    lagged = bool(fused_sums and LAGGED_ENERGIES and getattr(pls.basis, "supports_lagged_energies", lambda c: False)(pls.cost)
+                  and (space.whitened or getattr(pls.basis, "fused_step_takes_lagged_energies", False)))
+    if lagged:
+        pbytes = pls.basis.energy_partial_rows_bytes(j)
+        parts = [torch.empty((pbytes + 7) // 8, dtype=torch.float64, device=particles.device) for _ in range(2)]
+    flushed = [False]
     events = [torch.cuda.Event() for _ in range(NB)]
     rng_states = {}
     launched = 0
@@ -212,7 +229,15 @@ def _train_pls_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs: in
         k = launched
         rng_states[k] = torch.get_rng_state()  # (a speculative launch may have to be un-drawn)
         spec = NoiseSpec(injected=noises[k]) if noises is not None else None
-        if fused_sums:  # one column block = all particles, its step size from a device word, chunk sums to the host slot
+        if lagged:  # launch k leaves the partial rows of E(U_k) and finishes those of E(U_{k-1}) into slot k - 1
+            prev = (k - 1) % NB
+            if k > 0:
+                host_bits[prev * nchunk:(prev + 1) * nchunk] = UNWRITTEN
+            blocks = BlockSpec(j, eta_dev, energy_partials=parts[k % 2], energy_partials_prev=parts[(k - 1) % 2] if k > 0 else None,
+                               energy_prev=e_dev[prev] if k > 0 else None,
+                               energy_sums_prev=host_ptr + 8 * nchunk * prev if k > 0 else None)
+            space.step(bufs[k % NB], step_size, bufs[(k + 1) % NB], spec, None, blocks=blocks)
+        elif fused_sums:  # one column block = all particles, its step size from a device word, chunk sums to the host slot
             host_bits[(k % NB) * nchunk:(k % NB + 1) * nchunk] = UNWRITTEN
             blocks = BlockSpec(j, eta_dev, energy_sums=host_ptr + 8 * nchunk * (k % NB), energy_sync=sync)
             space.step(bufs[k % NB], step_size, bufs[(k + 1) % NB], spec, e_dev[k % NB], blocks=blocks)
@@ -252,6 +277,13 @@ def _train_pls_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs: in
             # the stop below may return slot (t+1) % NB: k + 1 - (t + 1) <= depth < NB, so that slot is never overwritten
             while launched < T and launched <= t + depth:
                 launch()
+            if lagged and launched == T and not flushed[0]:
+                # every step is queued: E(U_{T-1}) has no following launch to ride on -- a small finishing launch of its own
+                k = T - 1
+                host_bits[(k % NB) * nchunk:(k % NB + 1) * nchunk] = UNWRITTEN
+                space.flush(bufs[k % NB], BlockSpec(j, eta_dev, energy_partials_prev=parts[k % 2], energy_prev=e_dev[k % NB],
+                                                    energy_sums_prev=host_ptr + 8 * nchunk * (k % NB), energy_flush=True))
+                flushed[0] = True
             if t + 1 < T:
                 wait_for((t + 1) % NB)
                 energy_potential = read_energy((t + 1) % NB)

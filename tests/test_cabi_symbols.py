@@ -77,7 +77,7 @@ def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(L.OnbDesc) == 10 * 8
     assert ctypes.sizeof(L.IpbDesc) == 29 * 8  # (ABI 4: + tri_scratch, tri_scratch_bytes, Pt, ldpt)
     assert ctypes.sizeof(L.CholDesc) == 15 * 8
-    assert ctypes.sizeof(L.BlockDesc) == 4 * 8
+    assert ctypes.sizeof(L.BlockDesc) == 9 * 8
     assert L.CostDesc.p.offset == 16 and L.CostDesc.jitter.offset == 48
 
 

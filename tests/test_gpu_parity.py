@@ -845,6 +845,59 @@ def test_fused_energy_finish_equals_the_finishing_launch(P, mk, j):
     assert torch.equal(out2, out1) and torch.equal(e2, e1) and torch.equal(s2, s1)
 
 
+@pytest.mark.parametrize("basis_kind,mk,j", [("onb", 96, 300), ("onb", 256, 1024), ("onb", 1024, 2048), ("ipb", 200, 520)])
+def test_lagged_energies_equal_the_finishing_forms(P, basis_kind, mk, j):
+    """trainers.LAGGED_ENERGIES (pls_block_desc.energy_partials ...): launch k + 1 finishes the energies of launch k at its
+    start, a small launch finishes the last one's.  Against the loop whose launches finish their own energies: the same
+    particles, the same energies BIT FOR BIT, the same stop index and torch generator state -- eager and captured loops, runs
+    that stop early, runs of one, two and three epochs, a loop that stays in whitened coordinates (inducing-point basis)."""
+    from projected_langevin_sampling_amd import trainers
+
+    pr = make_problem(1500, mk if basis_kind == "ipb" else max(mk, 16), j, 3, seed=40 + mk)
+    if basis_kind == "onb":
+        g = pr["gen"]
+        a = cu(torch.randn(mk, 1500, generator=g) / math.sqrt(1500))
+        lam = cu(torch.rand(mk, generator=g) + 0.5)
+        basis = P.basis.OrthonormalBasis.from_projection(a, lam)
+        u0 = cu(torch.randn(mk, j, generator=g))
+        eta = 0.05
+    else:
+        pr["ls"] = pr["ls"] * 0.5
+        gk = P.pkg.ARDKernel(pr["ls"], 1.3)
+        basis = P.basis.InducingPointBasis(P.pkg.PLSKernel(gk, pr["z"]), pr["z"], pr["y"][:mk], pr["x"])
+        u0 = cu(pr["u"])
+        eta = 1e-7
+    gc = P.costs.GaussianCost(0.3, pr["y"], P.links.IdentityLinkFunction())
+    pls = P.pkg.PLS(basis, gc)
+
+    def run(lagged, epochs, patience, captured=False):
+        prev = trainers.LAGGED_ENERGIES
+        trainers.LAGGED_ENERGIES = lagged
+        try:
+            torch.manual_seed(3)
+            if captured:
+                u, e = P.pkg.train_pls_captured(pls, u0.clone(), epochs, eta, patience, steps_per_replay=5, seed=77)
+            else:
+                u, e = P.pkg.train_pls(pls, u0.clone(), epochs, eta, patience)
+            return u, e, torch.get_rng_state()
+        finally:
+            trainers.LAGGED_ENERGIES = prev
+
+    probe_u, probe_e, _ = run(False, 30, 1e9)
+    # a patience that stops the run somewhere in the middle: the energies of a noisy chain stop improving now and then
+    gaps = [i for i in range(1, len(probe_e)) if probe_e[i] >= min(probe_e[:i])]
+    cases = [(30, 1e9), (1, 1e9), (2, 1e9), (3, 1e9)] + ([(30, eta * 1.5)] if gaps else [])
+    for epochs, patience in cases:
+        a_u, a_e, a_rng = run(False, epochs, patience)
+        b_u, b_e, b_rng = run(True, epochs, patience)
+        assert len(a_e) == len(b_e) and a_e == b_e, (epochs, patience)
+        assert torch.equal(a_u, b_u) and torch.equal(a_rng, b_rng), (epochs, patience)
+    if basis_kind == "onb":
+        a_u, a_e, _ = run(False, 23, 1e9, captured=True)
+        b_u, b_e, _ = run(True, 23, 1e9, captured=True)
+        assert a_e == b_e and torch.equal(a_u, b_u)
+
+
 @pytest.mark.parametrize("mk", [129, 144, 150, 165, 192, 200, 224, 241, 257, 300])
 def test_ranks_just_above_a_tile_multiple(P, mk):
     """Ranks a little above a multiple of 128 take the back-projection in row blocks (csrc/gemm_tn_f64_rows.h: 129 rows
