@@ -1,5 +1,6 @@
 """What the energy by-product costs inside the fused Gaussian step (M_k = 1024): the step alone, with the by-product and a
-finishing launch (PLS_OPT_ENERGY_FUSED_FINISH 0), with the by-product finished by the step launch itself (energy_sync), as
+finishing launch (PLS_OPT_ENERGY_FUSED_FINISH 0), with the by-product finished by the step launch itself (energy_sync), with
+the partial rows finished by the NEXT launch at its start (energy_partials: lagged energies), as
 hipGraph replays of 20 steps (no host in the loop), for the shard of an 8- / 4-GPU run and the full particle matrix."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -54,6 +55,16 @@ for j in [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["10
                                       blocks=BlockSpec(j, eta, energy_sums=sums.data_ptr()))
     fused = lambda: basis.fused_step(cost, u, 1e-7, out=out, new_state=True, noise=ns, input_energy=e, workspace=ws,
                                      blocks=BlockSpec(j, eta, energy_sums=sums.data_ptr(), energy_sync=sync))
-    t0, t1, t2 = graph_time(plain), graph_time(with_e), graph_time(fused)
+    parts = [torch.empty(basis.energy_partial_rows_bytes(j) // 8, device="cuda") for _ in (0, 1)]
+    turn = [0]
+
+    def lagged():
+        k = turn[0]
+        turn[0] = k ^ 1
+        basis.fused_step(cost, u, 1e-7, out=out, new_state=True, noise=ns, workspace=ws,
+                         blocks=BlockSpec(j, eta, energy_partials=parts[k], energy_partials_prev=parts[k ^ 1], energy_prev=e,
+                                          energy_sums_prev=sums.data_ptr()))
+
+    t0, t1, t2, t3 = graph_time(plain), graph_time(with_e), graph_time(fused), graph_time(lagged)
     print(f"M_k={mk} J={j:5d}: step {t0:7.2f} us | + energy, finishing launch {t1:7.2f} us (+{t1 - t0:.2f}) | + energy, finished by the step "
-          f"launch {t2:7.2f} us (+{t2 - t0:.2f})", flush=True)
+          f"launch {t2:7.2f} us (+{t2 - t0:.2f}) | + energy, finished by the NEXT launch {t3:7.2f} us (+{t3 - t0:.2f})", flush=True)
