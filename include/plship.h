@@ -287,7 +287,10 @@ typedef enum pls_option {
   PLS_OPT_IPB_STEP_OPERATOR = 10,
   /* 1 (default): pls_block_desc.energy_sync is honoured (the step launch finishes the energies); 0: always a finishing
    * launch (A/B runs, tests). */
-  PLS_OPT_ENERGY_FUSED_FINISH = 11
+  PLS_OPT_ENERGY_FUSED_FINISH = 11,
+  /* 1 (default): the k-split kernel of narrow particle shards draws the Philox noise of its output block in front of its
+   * k-loop, while the first operand rows travel; 0: in the epilogue, like the other tilings.  Same bits either way. */
+  PLS_OPT_KG_NOISE_PREGEN = 12
 } pls_option;
 /* Diagnostic: out[i] = op(x[i]) with the device exp (op 0) / log (op 1) the per-element kernels use (csrc/fmath.h), or
  * out[i] = x[i] / x[n + i] with their division (op 2: fast_div, IEEE special cases restored; op 3: fast_div_normal), so

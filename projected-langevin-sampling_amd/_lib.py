@@ -225,6 +225,7 @@ OPT_ROW_BLOCKS = 8
 OPT_TRI_BALANCE = 9
 OPT_IPB_STEP_OPERATOR = 10
 OPT_ENERGY_FUSED_FINISH = 11
+OPT_KG_NOISE_PREGEN = 12
 TAG_NAMES = {1: "gemm_store", 2: "gemm_cost_deriv", 3: "gemm_cost_value", 4: "gemm_langevin_gaussian",
              5: "langevin_update", 6: "kernel_gram", 7: "other", 8: "small_rank_drift", 9: "small_rank_value",
              10: "tri_solve"}

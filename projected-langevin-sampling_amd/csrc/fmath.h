@@ -34,6 +34,7 @@ __device__ __forceinline__ double fma_k(double a, double b, double k) {
 // exp(x): n = rint(x log2 e), r = x - n ln 2 (two-piece ln 2), degree-13 Taylor polynomial in Horner form
 // (|r| <= 0.347: truncation 4e-18 relative), scaled by 2^n with v_ldexp (gradual underflow as libm).
 __device__ __forceinline__ double fast_exp(double x) {
+#pragma clang fp contract(off)
   const double n = rint(x * 1.4426950408889634074);
   double r = fma(n, -6.93147180369123816490e-01, x);
   r = fma(n, -1.90821492927058770002e-10, r);
@@ -69,6 +70,7 @@ __device__ __forceinline__ double fast_exp(double x) {
 // a / b for b well inside the normal range (no scaling steps): reciprocal seed + Newton + one residual correction of the
 // quotient; <= 1 ulp
 __device__ __forceinline__ double fast_div_normal(double a, double b) {
+#pragma clang fp contract(off)
   double r = __builtin_amdgcn_rcp(b);
   r = fma(fma(-b, r, 1.0), r, r);
 #if PLS_DIV_NEWTON_STEPS >= 2
@@ -83,6 +85,7 @@ __device__ __forceinline__ double fast_div_normal(double a, double b) {
 // back (b = 0, infinities, NaN).  7 vector instructions against the ~15 of the compiler's scaled division sequence;
 // what is given up is correct rounding and the rescaling of operands within a factor 2^-1022 .. 2^1022 of the limits.
 __device__ __forceinline__ double fast_div(double a, double b) {
+#pragma clang fp contract(off)
 #if defined(__HIP_DEVICE_COMPILE__)
   double r = __builtin_amdgcn_rcp(b);
   r = fma(fma(-b, r, 1.0), r, r);
@@ -102,6 +105,10 @@ __device__ __forceinline__ double fast_div(double a, double b) {
 // generator, (n + 1/2) 2^-53 with 0 <= n < 2^53, strictly inside (0, 1).  fast_log adds the three special cases (zero,
 // infinity, negative: a compare and two 32-bit selects each, 9 vector instructions such an argument can never take).
 __device__ __forceinline__ double fast_log_unit(double x) {
+  // (contraction written out: the noise generator is inlined into several kernels, and left to the compiler `t2 + t1` or
+  // `dk * ln2 - ...` became an fma in one and a multiply-add pair in another -- 1 ulp apart in one normal deviate per ~6000,
+  // so a particle's noise depended on the tiling its shard happened to take)
+#pragma clang fp contract(off)
   double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1) (subnormals included)
   int k = __builtin_amdgcn_frexp_exp(x);
   const bool low = m < 0.70710678118654752440;
@@ -112,12 +119,12 @@ __device__ __forceinline__ double fast_log_unit(double x) {
   const double s = fast_div_normal(f, 2.0 + f);
   const double z = s * s, w = z * z;
   const double t1 = w * fma_k(w, fma_k(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
-  const double t2 =
-      z * fma_k(w, fma_k(w, fma_k(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01),
-                6.666666666666735130e-01);
-  const double R = t2 + t1;
+  const double p2 =
+      fma_k(w, fma_k(w, fma_k(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01),
+            6.666666666666735130e-01);
+  const double R = fma(z, p2, t1);
   const double hfsq = 0.5 * f * f;
-  return dk * 6.93147180369123816490e-01 - ((hfsq - fma(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f);
+  return fma(dk, 6.93147180369123816490e-01, -((hfsq - fma(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f));
 }
 
 __device__ __forceinline__ double fast_log(double x) {

@@ -399,6 +399,13 @@ struct epi_has_prev : std::false_type {};
 template <class E>
 struct epi_has_prev<E, std::void_t<decltype(&E::prev_owner)>> : std::true_type {};
 
+// Epilogues whose per-element noise does not depend on the contraction can draw it BEFORE the k-loop (the k-split kernel of
+// gemm_tn_f64_kg.h does, under the landing of its first operand rows: pregen_on / pregen_pairs / apply_pregen).
+template <class E, class = void>
+struct epi_has_pregen : std::false_type {};
+template <class E>
+struct epi_has_pregen<E, std::void_t<decltype(&E::pregen_on)>> : std::true_type {};
+
 // largest leading dimension (doubles) the direct epilogue addresses with 32-bit byte offsets (67 rows * ld * 8 < 2^31)
 constexpr int64_t kDirectMaxLd = (int64_t)1 << 21;
 
@@ -488,11 +495,10 @@ __global__ __launch_bounds__((BI / WI) * (BJ / WJ) * 64, MINW) void gemm_tn_f64_
   }
   gemm_tile_coords(blockIdx.x, g.nti, g.ntj, tile_i, tile_j);
   if constexpr (epi_has_prev<Epilogue>::value) {
-    if (epi.prev_owner(tile_i, tile_j)) {  // (workgroup-uniform; two workgroups share a CU here: the other one covers this)
-      double v, tot;
-      epi.prev_reduce(tile_j, v, tot);
-      epi.prev_store(tile_j, v, tot);
-    }
+    // (workgroup-uniform.  Two workgroups share a CU here and the other one covers this prologue; workgroups of their own behind
+    // the tiles -- what the k-split kernel does -- find no room beside 512 resident tiles and run as a tail: +2.5 us at
+    // J = 8192 against +1.8 us this way)
+    if (epi.prev_owner(tile_i, tile_j)) epi.prev_chunk(epi.prev_chunk_of(tile_j));
   }
   gemm_tile<BI, BJ, WI, WJ, BK>(g, epi, tile_i, tile_j, lds);
 }
@@ -517,6 +523,7 @@ constexpr int epi_lds_doubles_per_wave() { return 2 * 16 * (WJ + EPI_PAD); }  //
 struct RowConsts {
   double k0_lo, k0_hi, k1_lo, k1_hi;
   double x_lo, x_hi;  // companion matrix X at (i_lo, j) and (i_lo + 4, j) (0 when X is not staged)
+  int it;             // iteration of the slab's row loop (a compile-time constant in the functor once the loop is unrolled)
 };
 
 // X / ldx (optional): a companion matrix addressed like the output (the particles U of the Langevin and energy
@@ -528,7 +535,8 @@ struct RowConsts {
 template <int TI, int TJ, int NCONST = 2, int UNROLL = 1, class Fn>
 __device__ __forceinline__ void epilogue_row_pairs(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int wave,
                                                    int64_t I, int64_t J, double *lds, double k0, double k1, Fn &&fn,
-                                                   const double *X = nullptr, int64_t ldx = 0) {
+                                                   const double *X = nullptr, int64_t ldx = 0, const double *xpre = nullptr) {
+  // xpre (optional, TI == 1): the lane's 16 / RPI companion values of slab 0, loaded by the caller earlier (in load_x's order)
   // NCONST: how many of the per-row constant registers (k0, k1) the functor uses (their cross-lane reads are skipped otherwise)
   constexpr int WJ = TJ * 16;
   constexpr int STRIDE = WJ + EPI_PAD;
@@ -548,7 +556,14 @@ __device__ __forceinline__ void epilogue_row_pairs(const AccFrag<TI, TJ> &acc, i
       xr[k] = (i < I && j < J) ? X[i * ldx + j] : 0.0;
     }
   };
-  if (X) load_x(0);
+  if (X) {
+    if (xpre) {
+#pragma unroll
+      for (int k = 0; k < NXL; ++k) xr[k] = xpre[k];
+    } else {
+      load_x(0);
+    }
+  }
   // One copy of the per-element code: the slab loop and the row loop are run-time loops (`unroll 1`); only the
   // register -> LDS write needs compile-time accumulator indices, so it sits in a wave-uniform switch.  (Fully unrolled,
   // the cost/Box-Muller code was inlined 64 times -- ~0.5 MB of instructions per kernel, every epilogue an I-cache miss
@@ -591,7 +606,7 @@ __device__ __forceinline__ void epilogue_row_pairs(const AccFrag<TI, TJ> &acc, i
       const int64_t i_lo = iw + ta * 16 + rr;
       const double v_lo = w[rr * STRIDE + col], v_hi = w[(rr + 4) * STRIDE + col];
       const int lr = ta * 16 + rr;
-      RowConsts rc{0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      RowConsts rc{0.0, 0.0, 0.0, 0.0, 0.0, 0.0, it};
       if (X) {
         rc.x_lo = wx[rr * STRIDE + col];
         rc.x_hi = wx[(rr + 4) * STRIDE + col];

@@ -258,15 +258,25 @@ __device__ __forceinline__ void kg_handover(const AccFrag<2, 2> &acc, double *ld
 }
 
 // The epilogue of a two-group tile on the waves' 16 x 32 blocks of the sum.
+// pre-drawn (optional): the noise pairs, the companion values and the two per-row constants of the wave's block, drawn /
+// requested before the k-loop (Epilogue::pregen; 8 elements per lane).  Plain arrays and scalars, not a struct: passed
+// around as one object they stayed in scratch memory.
 template <class Epilogue>
 __device__ __forceinline__ void kg_finish2(const GemmShape &g, const Epilogue &epi, const AccFrag<1, 2> &fin, int64_t i0,
-                                           int64_t j0, int tile_i, int split, double *lds) {
+                                           int64_t j0, int tile_i, int split, double *lds, const double (*pz)[8] = nullptr,
+                                           const double (*px)[8] = nullptr, double pcl = 0.0, double pil = 0.0) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int grp = wave >> 2, w = wave & 3, wr = w >> 1, wc = w & 1;
   const bool edge = (i0 + 64 > g.I) || (j0 + 64 > g.J);
   const int v = (2 * wr + grp) * 2 + wc;  // wave index in the 4 x 2 arrangement of 16 x 32 blocks
   const int64_t iw = i0 + (2 * wr + grp) * 16, jw = j0 + wc * 32;
+  if constexpr (epi_has_pregen<Epilogue>::value) {
+    if (pz) {
+      epi.template apply_pregen<1, 2>(fin, iw, jw, lane, v, g.I, g.J, tile_i, split, lds, *pz, *px, pcl, pil);
+      return;
+    }
+  }
   if constexpr (Epilogue::kDirect) {
     if constexpr (Epilogue::template direct_tile<1, 2>()) {
       if (!edge && epi.direct_ld() < kDirectMaxLd) {
@@ -284,6 +294,16 @@ __global__ __launch_bounds__(256 * KG, 4) void gemm_tn_f64_kg_kernel(GemmShape g
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) double lds[];
 
+  if constexpr (epi_has_prev<Epilogue>::value) {
+    // workgroups BEHIND the tiles (launch_gemm_kg appends Epilogue::prev_chunks() of them): each finishes one 256-column chunk
+    // of the PREVIOUS launch's energies -- sixteen loads per thread, two barriers, two stores -- on whatever CU has room,
+    // beside the tiles' k-loops.  (As a prologue of the tiles of row 0 the same work made those four workgroups, and with
+    // them the launch, 2.5 us late: a launch lasts as long as its slowest workgroup.)
+    if ((int)blockIdx.x >= g.nti * g.ntj) {
+      epi.prev_chunk((int)blockIdx.x - g.nti * g.ntj);
+      return;
+    }
+  }
   int tile_i, tile_j;
   gemm_tile_coords(blockIdx.x, g.nti, g.ntj, tile_i, tile_j);
   const int64_t i0 = (int64_t)tile_i * 64, j0 = (int64_t)tile_j * 64;
@@ -301,16 +321,23 @@ __global__ __launch_bounds__(256 * KG, 4) void gemm_tn_f64_kg_kernel(GemmShape g
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc.v[a][b] = double4_t{0.0, 0.0, 0.0, 0.0};
-  if constexpr (epi_has_prev<Epilogue>::value) {
-    // this workgroup may finish a chunk of the PREVIOUS launch's energies: loads and sums under the landing of its first
-    // operand rows, the results kept in two registers and stored behind the k-loop (a store in front of it would be waited
-    // for at the first barrier -- the chunk sum may travel to pinned host memory)
-    const bool owner = epi.prev_owner(tile_i, tile_j);  // (workgroup-uniform)
-    double pv = 0.0, ptot = 0.0;
+  // noise drawn in front of the k-loop (two k-groups; launch-uniform switch)
+  constexpr bool kPregen = KG == 2 && epi_has_pregen<Epilogue>::value;
+  [[maybe_unused]] double pz[8], px[8], pcl = 0.0, pil = 0.0;
+  [[maybe_unused]] bool pregen = false;
+  if constexpr (kPregen) pregen = epi.pregen_on();
+  if constexpr (kPregen) {
+    // the epilogue's own operands (particles, per-row constants) are REQUESTED here and land during the k-loop, and the
+    // Philox / Box-Muller code of the wave's 16 x 32 block of the output (8 elements per lane) runs while the first operand
+    // rows travel: the vector ALU has nothing else to do there, and behind the k-loop a memory round trip and ~560
+    // instructions per wave are serial time of a launch that lasts 40 us
     kg_contract<KG>(g, i0, j0, kbeg, kend, lds, acc, KgNoHook{}, [&]() {
-      if (owner) epi.prev_reduce(tile_j, pv, ptot);
+      if (pregen) {
+        const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        const int grp = wave >> 2, w = wave & 3, wr = w >> 1, wc = w & 1;
+        epi.pregen(i0 + (2 * wr + grp) * 16, j0 + wc * 32, (int)(threadIdx.x & 63), g.I, g.J, pz, px, pcl, pil);
+      }
     });
-    if (owner) epi.prev_store(tile_j, pv, ptot);
   } else {
     kg_contract<KG>(g, i0, j0, kbeg, kend, lds, acc);
   }
@@ -334,6 +361,12 @@ __global__ __launch_bounds__(256 * KG, 4) void gemm_tn_f64_kg_kernel(GemmShape g
   } else {
     AccFrag<1, 2> fin;
     kg_handover(acc, lds, fin);
+    if constexpr (kPregen) {
+      if (pregen) {
+        kg_finish2(g, epi, fin, i0, j0, tile_i, split, lds, &pz, &px, pcl, pil);
+        return;
+      }
+    }
     kg_finish2(g, epi, fin, i0, j0, tile_i, split, lds);
   }
 #else

@@ -87,6 +87,7 @@ __device__ __forceinline__ void philox4x32_10_device(uint32_t c0, uint32_t c1, u
 // sqrt(x) for x well inside the normal range: v_rsq_f64 seed, one coupled Newton step for (sqrt, 1 / (2 sqrt)), one residual
 // correction; <= 1 ulp
 __device__ __forceinline__ double sqrt_normal(double x) {
+#pragma clang fp contract(off)
 #if defined(__HIP_DEVICE_COMPILE__)
   const double r = __builtin_amdgcn_rsq(x);
 #else
@@ -102,6 +103,7 @@ __device__ __forceinline__ double sqrt_normal(double x) {
 // Both Box-Muller outputs of the pair that contains row `ibase` (bit 2 of ibase must be clear).
 __device__ __forceinline__ void normal_pair(uint64_t seed, uint64_t step, int64_t ibase, int64_t jg, double &z_lo,
                                             double &z_hi) {
+#pragma clang fp contract(off)
   uint32_t x[4];
   philox4x32_10_device((uint32_t)ibase, (uint32_t)jg, (uint32_t)step, (uint32_t)(step >> 32), (uint32_t)seed,
                        (uint32_t)(seed >> 32), x);

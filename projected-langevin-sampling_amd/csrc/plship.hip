@@ -290,24 +290,29 @@ struct EpiLangevinGaussian {
     const double *yty;
     int nparts;
   } prev;
+  int pregen_flag;  // 1: the k-split kernel draws the noise in front of its k-loop (PLS_OPT_KG_NOISE_PREGEN; launch-uniform)
 
   __device__ __forceinline__ bool prev_owner(int tile_i, int tile_j) const {
     return prev.part != nullptr && tile_i == 0 && (((int64_t)tile_j * bj) & 255) == 0;
   }
-  __device__ __forceinline__ void prev_reduce(int tile_j, double &v, double &tot) const {
+  __device__ __forceinline__ int prev_chunk_of(int tile_j) const { return (int)(((int64_t)tile_j * bj) >> 8); }
+  // chunks of 256 columns the previous launch's energies fall into (0: nothing to finish): the k-split kernel appends that
+  // many workgroups BEHIND its tiles, each finishing one chunk (prev_chunk) while the tiles contract
+  __host__ __device__ int prev_chunks() const { return prev.part ? (int)((ldp + 255) >> 8) : 0; }
+  __device__ __forceinline__ void prev_reduce(int chunk, double &v, double &tot) const {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ double pws[4];
     const int tid = threadIdx.x;
-    const int64_t J = ldp, c0 = (int64_t)tile_j * bj, col = c0 + tid;
+    const int64_t J = ldp, c0 = (int64_t)chunk << 8, col = c0 + tid;
     v = 0.0;
     if (tid < 256 && col < J) {
       double s = 0.0;
-      for (int p0 = 0; p0 < prev.nparts; p0 += 8) {  // eight loads in flight, added in ascending row order
-        double t[8];
+      for (int p0 = 0; p0 < prev.nparts; p0 += 16) {  // sixteen loads in flight, added in ascending row order
+        double t[16];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t[k] = (p0 + k < prev.nparts) ? prev.part[(int64_t)(p0 + k) * J + col] : 0.0;
+        for (int k = 0; k < 16; ++k) t[k] = (p0 + k < prev.nparts) ? prev.part[(int64_t)(p0 + k) * J + col] : 0.0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
+        for (int k = 0; k < 16; ++k)
           if (p0 + k < prev.nparts) s += t[k];
       }
       v = s + prev.yscale * (*prev.yty);
@@ -320,14 +325,19 @@ struct EpiLangevinGaussian {
     __syncthreads();
     tot = (pws[0] + pws[1]) + (pws[2] + pws[3]);
 #else
-    (void)tile_j, (void)v, (void)tot;
+    (void)chunk, (void)v, (void)tot;
 #endif
   }
-  __device__ __forceinline__ void prev_store(int tile_j, double v, double tot) const {
+  __device__ __forceinline__ void prev_store(int chunk, double v, double tot) const {
     const int tid = threadIdx.x;
-    const int64_t J = ldp, c0 = (int64_t)tile_j * bj, col = c0 + tid;
+    const int64_t J = ldp, c0 = (int64_t)chunk << 8, col = c0 + tid;
     if (tid < 256 && col < J) prev.e[col] = v;
-    if (tid == 0 && prev.sums) prev.sums[c0 >> 8] = tot;
+    if (tid == 0 && prev.sums) prev.sums[chunk] = tot;
+  }
+  __device__ __forceinline__ void prev_chunk(int chunk) const {
+    double v, tot;
+    prev_reduce(chunk, v, tot);
+    prev_store(chunk, v, tot);
   }
 
   __device__ __forceinline__ void store_partial(double *p, double v) const {
@@ -387,43 +397,100 @@ struct EpiLangevinGaussian {
     (void)j_tile;
 #endif
   }
+  // In front of the k-loop (gemm_tn_f64_kg.h, two k-groups): what the epilogue of a lane's 16 x 32 block needs and the
+  // contraction does not produce.  The noise of its four row pairs, in the order the row loop of apply<1, 2> takes them
+  // (iteration `it` handles pair p = 2 it + lane / 32: rows rr and rr + 4 of the block with rr = 8 (p >> 2) + (p & 3)) -- the
+  // same normal_pair calls as in the epilogue, the same bits --, the particles of its eight elements in load_x's order, the
+  // per-row constants of row iw + lane.
+  __device__ __forceinline__ bool pregen_on() const { return pregen_flag != 0; }
+  __device__ __forceinline__ void pregen(int64_t iw, int64_t jw, int lane, int64_t I, int64_t J, double (&pz)[8], double (&px)[8],
+                                         double &pcl, double &pil) const {
+    const int col = lane & 31, sub = lane >> 5;
+    const int64_t jl = jw + col;
+    pcl = load_row_constants(c, iw, lane, I);
+    const double lm = (lam && iw + lane < I) ? lam[iw + lane] : 1.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int64_t i = iw + k * 2 + sub;
+      px[k] = (i < I && jl < J) ? U[i * ldu + jl] : 0.0;
+    }
+    const int64_t jc = jl < J ? jl : J - 1;
+    if (nz.kind == PLS_NOISE_PHILOX) {
+      const int64_t jg = nz.global_column(jc);
+      const uint64_t nstep = nz.live_step();
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int p = it * 2 + sub, rr = (p >> 2) * 8 + (p & 3);
+        normal_pair(nz.seed, nstep, iw + rr, jg, pz[2 * it], pz[2 * it + 1]);
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int p = it * 2 + sub, rr = (p >> 2) * 8 + (p & 3);
+        const int64_t i = iw + rr;
+        const bool inj = nz.kind == PLS_NOISE_INJECTED && jl < J;
+        pz[2 * it] = (inj && i < I) ? nz.xi[i * nz.ldxi + jl] : 0.0;
+        pz[2 * it + 1] = (inj && i + 4 < I) ? nz.xi[(i + 4) * nz.ldxi + jl] : 0.0;
+      }
+    }
+    pil = (lam && iw + lane < I) ? 1.0 / lm : 0.0;
+  }
+  template <int TI, int TJ>
+  __device__ __forceinline__ void apply_pregen(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int wave, int64_t I,
+                                               int64_t J, int tile_i, int split, double *lds, const double (&pz)[8],
+                                               const double (&px)[8], double pcl, double pil) const {
+    static_assert(TI == 1 && TJ == 2, "the pre-drawn pairs follow the row loop of a 16 x 32 block");
+    apply_impl<TI, TJ, true>(acc, iw, jw, lane, wave, I, J, tile_i, split, lds, pz, px, pcl, pil);
+  }
   template <int TI, int TJ>
   __device__ void apply(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int wave, int64_t I, int64_t J,
-                        int tile_i, int, double *lds) const {
+                        int tile_i, int split, double *lds) const {
+    const double none[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    apply_impl<TI, TJ, false>(acc, iw, jw, lane, wave, I, J, tile_i, split, lds, none, none, 0.0, 0.0);
+  }
+  template <int TI, int TJ, bool PRE>
+  __device__ __forceinline__ void apply_impl(const AccFrag<TI, TJ> &acc, int64_t iw, int64_t jw, int lane, int wave, int64_t I,
+                                             int64_t J, int tile_i, int, double *lds, const double (&pz)[8],
+                                             const double (&px)[8], double pcl, double pil) const {
     double es = 0.0;
     const double pscale = 0.5 * inv_noise;
-    const double cl = load_row_constants(c, iw, lane, I);
-    const double ilaml = (lam && iw + lane < I) ? 1.0 / lam[iw + lane] : 0.0;
+    const double cl = PRE ? pcl : load_row_constants(c, iw, lane, I);
+    const double ilaml = PRE ? pil : ((lam && iw + lane < I) ? 1.0 / lam[iw + lane] : 0.0);
     const uint64_t nstep = nz.live_step();
     // a lane owns ONE column for the whole epilogue: its step size and Philox column are loop invariants
     const int64_t jl = jw + lane % (TJ * 16);
     const int64_t jc = jl < J ? jl : J - 1;
-    const double eta = etap.at(jc), sq2eta = sqrt(2.0 * eta);
+    const double eta = etap.at(jc), sq2eta = sqrt(2.0 * eta), neta = -eta;
     const int64_t jg = nz.global_column(jc);
-    epilogue_row_pairs<TI, TJ>(
+    epilogue_row_pairs<TI, TJ, 2, PRE ? 4 : 1>(  // (PRE: the row loop unrolled, so that rc.it is a constant)
         acc, iw, jw, lane, wave, I, J, lds, cl, ilaml,
         [&](int64_t i, int64_t j, double v0, bool hi, double v1, const RowConsts &rc) {
           double z0 = 0.0, z1 = 0.0;
-          if (nz.kind == PLS_NOISE_PHILOX) {
+          if constexpr (PRE) {
+            z0 = pz[2 * rc.it];
+            z1 = pz[2 * rc.it + 1];
+          } else if (nz.kind == PLS_NOISE_PHILOX) {
             normal_pair(nz.seed, nstep, i, jg, z0, z1);  // rows i and i + 4 share one Philox call
           } else if (nz.kind == PLS_NOISE_INJECTED) {
             z0 = nz.xi[i * nz.ldxi + j];
             if (hi) z1 = nz.xi[(i + 4) * nz.ldxi + j];
           }
+          // (explicit fma's: both instantiations -- noise drawn here or in front of the k-loop -- must round alike, and left
+          // to itself the compiler contracts a sum of products one way or another depending on the code around it)
           {
             const double u = rc.x_lo, ci = rc.k0_lo, il = rc.k1_lo;
-            const double d = -eta * inv_noise * (v0 - ci) - eta * u * il + sq2eta * z0;
+            const double d = fma(neta, fma(inv_noise, v0 - ci, u * il), sq2eta * z0);
             out[i * ldo + j] = add_u ? u + d : d;
-            es += pscale * u * (v0 - 2.0 * ci) + 0.5 * u * u * il;
+            es += fma(pscale * u, fma(-2.0, ci, v0), (0.5 * u) * u * il);
           }
           if (hi) {
             const double u = rc.x_hi, ci = rc.k0_hi, il = rc.k1_hi;
-            const double d = -eta * inv_noise * (v1 - ci) - eta * u * il + sq2eta * z1;
+            const double d = fma(neta, fma(inv_noise, v1 - ci, u * il), sq2eta * z1);
             out[(i + 4) * ldo + j] = add_u ? u + d : d;
-            es += pscale * u * (v1 - 2.0 * ci) + 0.5 * u * u * il;
+            es += fma(pscale * u, fma(-2.0, ci, v1), (0.5 * u) * u * il);
           }
         },
-        U, ldu);
+        U, ldu, PRE ? px : nullptr);
     if (epart) {  // wave-uniform; fixed-order cross-wave sum like EpiCostValue
       constexpr int WJ = TJ * 16;
       if (WJ == 32) es += __shfl_xor(es, 32);
@@ -558,9 +625,11 @@ static int launch_gemm_kg(GemmShape g, const Epi &epi, hipStream_t st) {
   const int64_t nwg = (int64_t)g.nti * g.ntj;
   if (nwg <= 0) return PLS_OK;
   if (nwg > 0x7fffffff) return fail(PLS_ERR_INVALID_ARGUMENT, "gemm: too many tiles");
+  int64_t extra = 0;  // workgroups behind the tiles that finish the previous launch's energies (gemm_tn_f64_kg_kernel)
+  if constexpr (epi_has_prev<Epi>::value) extra = epi.prev_chunks();
   {
     LaunchScope scope(Epi::kTag, st);
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg, 1), dim3(G::NT), lds_bytes, st, g, epi);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nwg + extra), 1), dim3(G::NT), lds_bytes, st, g, epi);
   }
   return check_launch("gemm_tn_f64_kg");
 }
@@ -1390,6 +1459,7 @@ static int validate_noise(const pls_noise_desc *n, int64_t rows) {
 // ---- small projection ranks: fused kernels (small_rank.h) -------------------------------------------------------
 static std::atomic<int64_t> g_small_rank_max{128};  // pls_set_option(PLS_OPT_SMALL_RANK_MAX)
 static std::atomic<int64_t> g_ipb_explicit_inverse{0};  // pls_set_option(PLS_OPT_IPB_EXPLICIT_INVERSE)
+static std::atomic<int64_t> g_kg_noise_pregen{1};      // pls_set_option(PLS_OPT_KG_NOISE_PREGEN): Philox noise in front of the k-split kernel's k-loop
 static std::atomic<int64_t> g_energy_fused_finish{1};   // pls_set_option(PLS_OPT_ENERGY_FUSED_FINISH): honour pls_block_desc.energy_sync
 static std::atomic<int64_t> g_ipb_step_operator{1};     // pls_set_option(PLS_OPT_IPB_STEP_OPERATOR): 1 = Pt route when the descriptor has it
 static std::atomic<int64_t> g_solve_mode{1};  // pls_set_option(PLS_OPT_SOLVE_MODE): 0 block substitution, 1 inverse-factor products where available
@@ -1649,6 +1719,7 @@ static int fast_step_launch(const FastOp &op, const double *U, int64_t ldu, int6
     epart = static_cast<double *>(workspace);
   }
   EpiLangevinGaussian e{out, ldo, U, ldu, op.c, op.lam, etap, op.inv_noise, out_mode, nz, epart, j, 2, big ? 128 : 64, {}, {}};
+  e.pregen_flag = g_kg_noise_pregen.load() != 0;
   if (lag.partials_prev) e.prev = EpiLangevinGaussian::Prev{lag.partials_prev, lag.e_prev, lag.sums_prev, op.yscale, op.yty, (int)parts};
   const bool lagged = lag.partials_out != nullptr;  // (the NEXT launch, or a flush, finishes this launch's energies)
   const bool fused_finish = !lagged && energy_in && esync && g_energy_fused_finish.load() != 0;
@@ -1745,6 +1816,10 @@ int pls_set_option(int32_t option, int64_t value) {
       PLS_REQUIRE(value == 0 || value == 1, "set_option: fused energy finish must be 0 or 1");
       g_energy_fused_finish.store(value);
       return PLS_OK;
+    case PLS_OPT_KG_NOISE_PREGEN:
+      PLS_REQUIRE(value == 0 || value == 1, "set_option: noise pre-generation must be 0 or 1");
+      g_kg_noise_pregen.store(value);
+      return PLS_OK;
     default: return fail(PLS_ERR_INVALID_ARGUMENT, "set_option: unknown option %d", (int)option);
   }
 }
@@ -1768,6 +1843,7 @@ int64_t pls_get_option(int32_t option) {
     case PLS_OPT_TRI_BALANCE: return g_tri_balance.load();
     case PLS_OPT_IPB_STEP_OPERATOR: return g_ipb_step_operator.load();
     case PLS_OPT_ENERGY_FUSED_FINISH: return g_energy_fused_finish.load();
+    case PLS_OPT_KG_NOISE_PREGEN: return g_kg_noise_pregen.load();
     default: return -1;
   }
 }

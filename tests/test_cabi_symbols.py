@@ -62,6 +62,8 @@ def test_options_validate_without_touching_the_gpu():
     assert lib.pls_get_option(L.OPT_TRI_BALANCE) == 1 and lib.pls_set_option(L.OPT_TRI_BALANCE, 2) != 0
     assert lib.pls_set_option(L.OPT_TRI_BALANCE, 0) == 0 and lib.pls_set_option(L.OPT_TRI_BALANCE, 1) == 0
     assert lib.pls_get_option(L.OPT_ENERGY_FUSED_FINISH) == 1 and lib.pls_set_option(L.OPT_ENERGY_FUSED_FINISH, 2) != 0
+    assert lib.pls_get_option(L.OPT_KG_NOISE_PREGEN) == 1 and lib.pls_set_option(L.OPT_KG_NOISE_PREGEN, 2) != 0
+    assert lib.pls_set_option(L.OPT_KG_NOISE_PREGEN, 0) == 0 and lib.pls_set_option(L.OPT_KG_NOISE_PREGEN, 1) == 0
     assert lib.pls_get_option(L.OPT_IPB_STEP_OPERATOR) == 1 and lib.pls_set_option(L.OPT_IPB_STEP_OPERATOR, 3) != 0
     assert lib.pls_set_option(L.OPT_IPB_STEP_OPERATOR, 0) == 0 and lib.pls_set_option(L.OPT_IPB_STEP_OPERATOR, 1) == 0
     assert lib.pls_tri_scratch_bytes(1024, 1024) == 16384 + 8 * 16 * 2 * 4096 * 8 and lib.pls_tri_scratch_bytes(0, 5) == 0

@@ -183,3 +183,60 @@ def test_ksplit_kernel_on_the_full_width_launch(P):
     with ksplit(P, 1, max_tiles=1 << 30):
         new = basis.fused_step(cost, u, 1e-3, noise=P.basis.NoiseSpec(seed=9, step=1))
     assert relerr(new, old) < 1e-13
+
+
+def test_noise_drawn_in_front_of_the_k_loop_is_the_same_noise(P):
+    """PLS_OPT_KG_NOISE_PREGEN: the k-split kernel draws the Philox pairs of its output block while its first operand rows
+    travel.  Bit for bit the step of the in-epilogue generator: tiles on and off the 64 grid, a k range below one super-step,
+    shard offsets, per-block step sizes with a Philox column restart, the energy by-product, in-place and delta forms."""
+    from projected_langevin_sampling_amd import _lib as L
+    from projected_langevin_sampling_amd.basis.base import BlockSpec
+
+    lib = L.load()
+    g = torch.Generator().manual_seed(31 + FUZZ_SEED)
+    for (mk, j, n) in ((64, 64, 300), (24, 48, 200), (100, 130, 400), (200, 333, 500), (257, 65, 600), (1024, 1024, 1500)):
+        a = cu(torch.randn(mk, n, generator=g) / mk ** 0.5)
+        lam = cu(torch.rand(mk, generator=g) + 0.5)
+        basis = P.basis.OrthonormalBasis.from_projection(a, lam)
+        cost = P.costs.GaussianCost(0.5, torch.randn(n, generator=g), P.links.IdentityLinkFunction())
+        u = cu(torch.randn(mk, j, generator=g))
+        bc = max(1, j // 3)
+        eta = cu(torch.tensor([1e-3, 0.0, 2e-3, 5e-4][: (j + bc - 1) // bc]))
+
+        def run(pregen):
+            L.check(lib.pls_set_option(L.OPT_KG_NOISE_PREGEN, pregen))
+            try:
+                with ksplit(P, 2):
+                    ns = P.basis.NoiseSpec(seed=77, step=5, j_offset=4096)
+                    e = torch.empty(j, device="cuda")
+                    d = basis.fused_step(cost, u, 1e-3, noise=ns, input_energy=e)
+                    new = basis.fused_step(cost, u, 1e-3, noise=ns, new_state=True)
+                    blk = basis.fused_step(cost, u, 0.0, noise=P.basis.NoiseSpec(seed=78, step=1), new_state=True,
+                                           blocks=BlockSpec(bc, eta))
+                return d, new, blk, e
+            finally:
+                L.check(lib.pls_set_option(L.OPT_KG_NOISE_PREGEN, 1))
+
+        on, off = run(1), run(0)
+        for x, y in zip(on, off):
+            assert torch.equal(x, y), (mk, j)
+        assert (on[0] - (on[1] - u)).abs().max().item() < 1e-12
+
+
+def test_the_noise_of_a_particle_does_not_depend_on_the_tiling(P):
+    """The Philox / Box-Muller code is inlined into every tiling's epilogue (128 x 128 direct, 64 x 64 through LDS, k-split with
+    the noise drawn in front of the k-loop); its floating-point contractions are written out (csrc/fmath.h, philox.h), so a
+    particle's noise is the same BITS whichever kernel its shard takes.  With U = 0 the contraction contributes exact zeros
+    and the step is -eta (0 - c) / sigma^2 + sqrt(2 eta) xi: full-width launch against the shards of an 8-GPU run."""
+    basis, cost, g = _big_gaussian_basis(P, seed=3)
+    j = 8192
+    u = torch.zeros(1024, j, device="cuda")
+    full = basis.fused_step(cost, u, 1e-3, noise=P.basis.NoiseSpec(seed=11, step=4))
+    assert full.abs().max().item() > 0.05  # (noise of standard deviation sqrt(2e-3) is in there)
+    for rank in (0, 5, 7):
+        j0 = rank * 1024
+        sh = u[:, j0:j0 + 1024].contiguous()
+        for mode in (1, 0):  # k-split kernel; the 64 x 64 tiles of round 2
+            with ksplit(P, mode):
+                got = basis.fused_step(cost, sh, 1e-3, noise=P.basis.NoiseSpec(seed=11, step=4, j_offset=j0))
+            assert torch.equal(got, full[:, j0:j0 + 1024]), (rank, mode)

@@ -42,7 +42,10 @@ def graph_time(fn, steps=20, reps=30):
     return best
 
 
-for j in [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["1024", "2048", "8192"])]:
+for pregen, j in [(p, int(v)) for p in (1, 0) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["1024", "2048", "8192"])]:
+    if pregen == 0 and j >= 4096:
+        continue  # (the 128 x 128 tiles of the full-width launch draw their noise in the epilogue either way)
+    L.check(lib.pls_set_option(L.OPT_KG_NOISE_PREGEN, pregen))
     u, out = torch.randn(mk, j, device="cuda"), torch.empty(mk, j, device="cuda")
     e = torch.empty(j, device="cuda")
     nchunk = (j + 255) // 256
@@ -66,5 +69,5 @@ for j in [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["10
                                           energy_sums_prev=sums.data_ptr()))
 
     t0, t1, t2, t3 = graph_time(plain), graph_time(with_e), graph_time(fused), graph_time(lagged)
-    print(f"M_k={mk} J={j:5d}: step {t0:7.2f} us | + energy, finishing launch {t1:7.2f} us (+{t1 - t0:.2f}) | + energy, finished by the step "
+    print(f"M_k={mk} J={j:5d} noise {'in front of the k-loop' if pregen and j < 4096 else 'in the epilogue        '}: step {t0:7.2f} us | + energy, finishing launch {t1:7.2f} us (+{t1 - t0:.2f}) | + energy, finished by the step "
           f"launch {t2:7.2f} us (+{t2 - t0:.2f}) | + energy, finished by the NEXT launch {t3:7.2f} us (+{t3 - t0:.2f})", flush=True)
