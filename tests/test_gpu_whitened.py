@@ -17,6 +17,8 @@ from oracle import pls_oracle as O
 from test_gpu_ksplit import P, _f64_default, ksplit  # noqa: F401
 from test_gpu_parity import FUZZ_SEED, TOL, build_ipb, cu, make_problem, relerr
 
+TOL0 = TOL
+
 
 class solve_mode:
     def __init__(self, P, mode):
@@ -81,7 +83,9 @@ def test_whitened_route_of_the_inducing_point_step_against_the_oracle(P, n, m, j
     # TOL with no conditioning allowance holds up to cond(k(Z,Z)) ~ 1e8, as for the block substitution (two valid
     # Cholesky factors of one matrix already move the update by cond * 1e-17: the oracle's LAPACK factor is one of them)
     cond = torch.linalg.cond(ob.base_gram_induce).item()
-    assert cond <= 1e8, f"test construction: cond(k(Z,Z)) = {cond:.1e}"
+    assert cond <= 1e10, f"test construction: cond(k(Z,Z)) = {cond:.1e}"
+    # (the committed draws stay below 1e8; soak runs with PLS_FUZZ_SEED may not: two valid factors differ by ~2 cond 1e-17)
+    TOL = TOL0 if cond <= 1e8 else TOL0 * 2.0 * cond / 1e8
     oc, gc = _gauss_pair(P, pr)
     u = pr["u"]
     e_noise = torch.randn(m, j, generator=pr["gen"])

@@ -12,6 +12,9 @@ from projected_langevin_sampling_amd.costs import GaussianCost
 from projected_langevin_sampling_amd.link_functions import IdentityLinkFunction
 
 lib = L.load()
+if os.environ.get("PLS_KSPLIT_MAX_TILES"):  # e.g. 512: J = 4096 (256 tiles of 128 x 128) through the k-split kernel as well
+    L.check(lib.pls_set_option(L.OPT_KSPLIT_MAX_TILES, int(os.environ["PLS_KSPLIT_MAX_TILES"])))
+    print("PLS_OPT_KSPLIT_MAX_TILES =", os.environ["PLS_KSPLIT_MAX_TILES"], flush=True)
 torch.set_default_dtype(torch.float64)
 mk, n = 1024, 20000
 g = torch.Generator().manual_seed(0)
@@ -43,7 +46,7 @@ def graph_time(fn, steps=20, reps=30):
 
 
 for pregen, j in [(p, int(v)) for p in (1, 0) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["1024", "2048", "8192"])]:
-    if pregen == 0 and j >= 4096:
+    if pregen == 0 and j >= 4096 and not os.environ.get("PLS_KSPLIT_MAX_TILES"):
         continue  # (the 128 x 128 tiles of the full-width launch draw their noise in the epilogue either way)
     L.check(lib.pls_set_option(L.OPT_KG_NOISE_PREGEN, pregen))
     u, out = torch.randn(mk, j, device="cuda"), torch.empty(mk, j, device="cuda")
