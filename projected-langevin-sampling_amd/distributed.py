@@ -43,6 +43,108 @@ def mean_over_particles(local_values: torch.Tensor, number_of_particles: int, gr
     return (s / number_of_particles).item()
 
 
+class EnergyMean:
+    """``train_pls(..., energy_reduce=EnergyMean(J))`` for a J-sharded run: the mean energy over ALL particles, which the stop
+    rule of the reference's loop looks at after every step (experiments/trainers.py:158-161) -- the one exchange between the
+    ranks that a training iteration needs (collective C1 of SURVEY.md 2.2).
+
+    Called with a tensor it is ``mean_over_particles`` (an all-reduce the caller waits for).  The pipelined loop of
+    trainers.py instead hands over the rank's LOCAL energy sum as a host float -- it arrives in pinned host memory from the
+    step launch itself, while further steps are already queued -- and ``reduce_local_sum`` exchanges those floats between the
+    HOST processes without touching the GPU queues:
+
+      * ranks of one node (what bench.py --gpus N and a torchrun --nnodes=1 job are): a board in POSIX shared memory,
+        /dev/shm/pls_energy_<id> -- ring of 16 iterations x world (sequence number, value).  A rank stores its value, then
+        the iteration's sequence number (x86-64: stores become visible in program order; aligned 8-byte stores are single
+        copies), polls until every rank's number has arrived, and adds the values in RANK order: every rank gets the same
+        bits, so every rank takes the same stop decision.  About a microsecond per iteration, no system call, no kernel;
+      * otherwise (several hosts, or board=False): a blocking all-reduce of one double per iteration on the group.
+
+    Slot t % 16 is reused at iteration t + 16, which a rank only reaches after every rank has published -- hence finished
+    reading -- iteration t + 15 > t.  ``timeout_s`` bounds the wait for a rank that died."""
+
+    RING = 16
+
+    def __init__(self, number_of_particles: int, group=None, board: bool | None = None, timeout_s: float = 600.0):
+        self.number_of_particles = int(number_of_particles)
+        self.group = group
+        self.timeout_s = float(timeout_s)
+        on = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if on else 1
+        self.rank = dist.get_rank(group) if on else 0
+        self._t = 0
+        self._seq = self._val = self._map = None
+        if self.world > 1 and board is not False:
+            self._open_board(required=board is True)
+
+    def _open_board(self, required: bool) -> None:
+        import os
+        import socket
+        import uuid
+
+        import numpy as np
+
+        hosts = [None] * self.world
+        dist.all_gather_object(hosts, (socket.gethostname(), os.path.isdir("/dev/shm")), group=self.group)
+        same = all(h == hosts[0] for h in hosts) and hosts[0][1]
+        if not same:
+            if required:
+                raise RuntimeError("EnergyMean(board=True): the ranks of the group do not share one host with /dev/shm")
+            return
+        name = [f"/dev/shm/pls_energy_{os.getpid()}_{uuid.uuid4().hex[:12]}" if self.rank == 0 else None]
+        nbytes = 2 * self.RING * self.world * 8
+        if self.rank == 0:
+            with open(name[0], "wb") as f:
+                f.write(b"\0" * nbytes)
+        dist.broadcast_object_list(name, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        self._map = np.memmap(name[0], dtype=np.int64, mode="r+", shape=(2, self.RING, self.world))
+        self._seq = self._map[0]
+        self._val = self._map[1].view(np.float64)
+        dist.barrier(group=self.group)  # everybody has the file mapped: its name can go (the mapping keeps the pages)
+        if self.rank == 0:
+            os.unlink(name[0])
+
+    @property
+    def uses_board(self) -> bool:
+        return self._seq is not None
+
+    def __call__(self, local_values: torch.Tensor) -> float:
+        return mean_over_particles(local_values, self.number_of_particles, self.group)
+
+    def reduce_local_sum(self, local_sum: float) -> float:
+        """The global MEAN from this rank's local SUM of per-particle values; every rank of the group must call it once per
+        iteration, in the same order."""
+        if self.world == 1:
+            return float(local_sum) / self.number_of_particles
+        if self._seq is None:
+            s = torch.tensor([float(local_sum)], dtype=torch.float64)
+            if dist.get_backend(self.group) == "nccl":
+                s = s.cuda()
+            dist.all_reduce(s, op=dist.ReduceOp.SUM, group=self.group)
+            return s.item() / self.number_of_particles
+        import time
+
+        t = self._t
+        slot, tag = t % self.RING, t + 1
+        self._val[slot, self.rank] = float(local_sum)
+        self._seq[slot, self.rank] = tag  # (after the value)
+        row = self._seq[slot]
+        spins, t0 = 0, None
+        while not bool((row == tag).all()):
+            spins += 1
+            if spins % 4096 == 0:
+                t0 = t0 or time.monotonic()
+                if time.monotonic() - t0 > self.timeout_s:
+                    raise RuntimeError(f"EnergyMean: rank(s) {[r for r in range(self.world) if row[r] != tag]} did not publish "
+                                       f"iteration {t} within {self.timeout_s:.0f} s")
+                time.sleep(0)
+        total = 0.0
+        for r in range(self.world):  # rank order: the same bits on every rank
+            total += float(self._val[slot, r])
+        self._t = t + 1
+        return total / self.number_of_particles
+
+
 def predictive_moments(local_samples: torch.Tensor, number_of_particles: int, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Mean and unbiased variance over all J particles of (N*, J_local) samples, two passes (sum, then squared deviations
     about the global mean), each followed by one all-reduce of N* doubles (collective C2; replaces

@@ -127,8 +127,9 @@ def train_pls(
 
     from .basis.base import NoiseSpec
 
-    if energy_reduce is None and particles.is_cuda:
-        return _train_pls_in_flight(pls, particles, number_of_epochs, step_size, early_stopper, noises)
+    if particles.is_cuda and (energy_reduce is None or hasattr(energy_reduce, "reduce_local_sum")):
+        # (a J-sharded run hands in distributed.EnergyMean: the ranks' local sums meet on the host, the GPU queues stay full)
+        return _train_pls_in_flight(pls, particles, number_of_epochs, step_size, early_stopper, noises, mean=energy_reduce)
 
     space = _LoopSpace(pls, noises)
     cur = space.enter(particles)
@@ -169,7 +170,7 @@ IN_FLIGHT_BUFFER_BYTES = 4 << 30
 
 
 def _train_pls_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs: int, step_size: float,
-                         early_stopper: EarlyStopper, noises, depth: int | None = None) -> Tuple[torch.Tensor, List[float]]:
+                         early_stopper: EarlyStopper, noises, depth: int | None = None, mean=None) -> Tuple[torch.Tensor, List[float]]:
     """The pipelined loop with `depth` step launches queued: launch k computes U_{k+1} from U_k and, as a by-product, the
     energy of U_k.  The mean energy travels to pinned host memory by the launch that finishes the by-product (the host
     polls that slot; costs without fused chunk sums: a mean launch followed by an event), and launches k+1 .. k+depth-1
@@ -251,6 +252,9 @@ def _train_pls_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs: in
         launched += 1
 
     def read_energy(slot: int) -> float:
+        if mean is not None:  # J-sharded run (distributed.EnergyMean): the local SUM goes to the ranks' host-side exchange
+            local = mean_from_chunk_sums(host[slot * nchunk:(slot + 1) * nchunk].tolist(), 1) if fused_sums else host[slot].item() * j
+            return mean.reduce_local_sum(local)
         if fused_sums:
             return mean_from_chunk_sums(host[slot * nchunk:(slot + 1) * nchunk].tolist(), j)
         return host[slot].item()
@@ -288,7 +292,8 @@ def _train_pls_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs: in
                 wait_for((t + 1) % NB)
                 energy_potential = read_energy((t + 1) % NB)
             else:  # the energy after the last update has no following launch to ride on
-                energy_potential = _mean_energy(space.energy(bufs[T % NB]))
+                last = space.energy(bufs[T % NB])
+                energy_potential = _mean_energy(last) if mean is None else mean.reduce_local_sum(last.sum().item())
             if early_stopper.should_stop(loss=energy_potential, step_size=step_size):
                 if launched > t + 1:
                     torch.set_rng_state(rng_states[t + 1])

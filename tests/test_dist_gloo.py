@@ -162,3 +162,52 @@ def test_reductions_inside_a_sub_group(tmp_path):
     port = _free_port()
     mp.spawn(_subgroup_worker, args=(4, port, str(tmp_path)), nprocs=4, join=True)
     assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(4))
+
+
+def _energy_board_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import time
+
+    from projected_langevin_sampling_amd import distributed as D
+
+    j = 1000
+    board = D.EnergyMean(j, board=True)
+    plain = D.EnergyMean(j, board=False)
+    assert board.uses_board and not plain.uses_board
+    rng = np.random.default_rng(7)  # the same stream on every rank: column r is rank r's local sum
+    vals = rng.standard_normal((400, world)) * 10.0 ** rng.integers(-3, 6, size=(400, 1))
+    got = []
+    for t in range(400):  # 25 times round the ring of 16, the ranks drifting apart and catching up
+        if (t + rank) % 37 == 0:
+            time.sleep(0.002)
+        got.append(board.reduce_local_sum(vals[t, rank]))
+    want = []
+    for t in range(400):
+        tot = 0.0
+        for r in range(world):
+            tot += float(vals[t, r])
+        want.append(tot / j)
+    assert got == want, "rank-order sum, bit for bit"
+    for t in (0, 1, 2):  # the all-reduce fallback agrees to rounding
+        assert np.isclose(plain.reduce_local_sum(vals[t, rank]), want[t], rtol=1e-13, atol=1e-300)
+    # called with a tensor it is the blocking collective
+    e_local = torch.full((10,), float(rank + 1), dtype=torch.float64)
+    assert np.isclose(board(e_local), 10.0 * sum(range(1, world + 1)) / j)
+    mine = torch.tensor(got, dtype=torch.float64)
+    everyone = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(everyone, mine)
+    assert all(torch.equal(everyone[0], e) for e in everyone), "every rank holds the same bits (the same stop decisions)"
+    dist.barrier()
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("pls_energy_")], "the board's file name is gone (rank 0 unlinks it)"
+    dist.destroy_process_group()
+    open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+
+
+def test_energy_mean_over_a_shared_memory_board(tmp_path):
+    """distributed.EnergyMean: the per-iteration exchange of the ranks' local energy sums through /dev/shm (ranks of one
+    node), against the sum in rank order and the all-reduce fallback; 3 ranks, 400 iterations, deliberately skewed ranks."""
+    port = _free_port()
+    mp.spawn(_energy_board_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(3))

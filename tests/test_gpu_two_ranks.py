@@ -94,8 +94,32 @@ def _worker(rank, world, port, out_dir):
     _, restored, _, _ = checkpoint.load_pls(pkg2.PLS(basis2, cost2), path)
     resumed = _steps(basis2, cost2, restored, 3, 3)
     assert torch.equal(resumed, mine), "resume under the shared device gauge != uninterrupted shard"
+    # the training loop of the sharded run: the stop rule looks at the mean energy over ALL particles after every step.
+    # Pipelined loop + the ranks' host-side exchange (distributed.EnergyMean: shared-memory board) against the plain loop with
+    # a blocking all-reduce per iteration: the same particles bit for bit, the same energies to rounding, the same stop
+    from projected_langevin_sampling_amd.trainers import train_pls
+
+    eta = 0.5 * float(basis.eigenvalues.min())
+    # (particles drawn from the prior, u_m ~ N(0, lambda_m): the chain starts near equilibrium, so the mean energy
+    # fluctuates from the first steps on and a short patience stops the run somewhere in the middle)
+    ueq = u0 * basis.eigenvalues.cpu().sqrt()[:, None]
+    shard0 = ueq[:, j0:j1].contiguous().cuda()
+    em = D.EnergyMean(j)
+    assert em.uses_board
+    runs = {}
+    # (the runs that must stop: a step size beyond the stability bound of the stiffest mode, eta / lambda_min = 2.5 > 2 -- its
+    # energy grows by 2.25 per step and turns the mean energy round within a few steps; patience = three such steps)
+    blocking = lambda e: D.mean_over_particles(e, j)
+    for name, red, step, patience in (("board", em, eta, 1e9), ("blocking", blocking, eta, 1e9),
+                                      ("board_stop", em, 5.0 * eta, 12.5 * eta), ("blocking_stop", blocking, 5.0 * eta, 12.5 * eta)):
+        torch.manual_seed(21)
+        runs[name] = train_pls(pls, shard0.clone(), 40, step, patience, energy_reduce=red)
+    for a, b in (("board", "blocking"), ("board_stop", "blocking_stop")):
+        assert torch.equal(runs[a][0], runs[b][0]), (a, b)
+        assert len(runs[a][1]) == len(runs[b][1]) and max(abs(x - y) / abs(y) for x, y in zip(runs[a][1], runs[b][1])) < 1e-12
+    train = {k: (v[0].cpu(), v[1]) for k, v in runs.items() if k.startswith("board")}
     torch.save({"particles": mine.cpu(), "energy": energy, "mean": mean.cpu(), "var": var.cpu(), "samples": samples.cpu(),
-                "lam": basis.eigenvalues.cpu(), "vec": basis.eigenvectors.cpu(), "j0": j0, "j1": j1},
+                "lam": basis.eigenvalues.cpu(), "vec": basis.eigenvectors.cpu(), "j0": j0, "j1": j1, "train": train},
                os.path.join(out_dir, f"out{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -125,6 +149,18 @@ def test_two_ranks_on_one_gpu_equal_the_unsharded_run(tmp_path):
         pls = pkg.PLS(basis, cost)
         e_whole = pls.particle_energy_potential(whole).mean().item()
         assert all(abs(o["energy"] - e_whole) <= 1e-12 * abs(e_whole) for o in outs)
+        # the sharded training loop against the unsharded one: same energies (both ranks hold the SAME floats), same stop
+        from projected_langevin_sampling_amd.trainers import train_pls
+
+        eta = 0.5 * float(basis.eigenvalues.min())
+        for name, step, patience in (("board", eta, 1e9), ("board_stop", 5.0 * eta, 12.5 * eta)):
+            torch.manual_seed(21)
+            u_w, e_w = train_pls(pls, (u0 * basis.eigenvalues.cpu().sqrt()[:, None]).cuda(), 40, step, patience)
+            assert outs[0]["train"][name][1] == outs[1]["train"][name][1], "the ranks disagree about the energies they stopped on"
+            e_s = outs[0]["train"][name][1]
+            assert len(e_s) == len(e_w) and max(abs(x - y) / abs(y) for x, y in zip(e_s, e_w)) < 1e-10, name
+            assert _relerr(torch.cat([o["train"][name][0] for o in outs], dim=1), u_w.cpu()) < 1e-10, name
+        assert len(outs[0]["train"]["board_stop"][1]) < 40, "test construction: the patience never stopped the run"
         prev_stream = samplers.DEFAULT_NORMAL_STREAM
         samplers.DEFAULT_NORMAL_STREAM = "device"
         try:
