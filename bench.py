@@ -721,7 +721,8 @@ def main():
             pls = pkg.PLS(basis, cost)
             if mode == "plain":
                 basis.supports_input_energy = lambda c: False
-            reduce_fn = (lambda e: D.mean_over_particles(e, j_total)) if world > 1 else None
+            # (sharded runs: the pipelined loop with the ranks' host-side exchange, the plain one with a blocking all-reduce)
+            reduce_fn = None if world == 1 else (D.EnergyMean(j_total) if mode == "pipelined" else (lambda e: D.mean_over_particles(e, j_total)))
             try:
                 train_pls(pls, particles.clone(), 2, eta, 1e30, energy_reduce=reduce_fn)  # warm-up
                 barrier()

@@ -118,6 +118,19 @@ def _worker(rank, world, port, out_dir):
         assert torch.equal(runs[a][0], runs[b][0]), (a, b)
         assert len(runs[a][1]) == len(runs[b][1]) and max(abs(x - y) / abs(y) for x, y in zip(runs[a][1], runs[b][1])) < 1e-12
     train = {k: (v[0].cpu(), v[1]) for k, v in runs.items() if k.startswith("board")}
+    # a cost without the Gaussian chunk sums (the mean travels through pls_block_means and an event): same exchange
+    from projected_langevin_sampling_amd.costs import PoissonCost
+    from projected_langevin_sampling_amd.link_functions import SquareLinkFunction
+
+    counts = torch.poisson(torch.full_like(cost.y_train, 3.0), generator=torch.Generator().manual_seed(8))
+    ppls = pkg.PLS(basis, PoissonCost(counts, SquareLinkFunction()))
+    pstart = (1.0 + 0.1 * u0[:, j0:j1]).contiguous().cuda()
+    torch.manual_seed(22)
+    pa = train_pls(ppls, pstart.clone(), 12, 0.2 * eta, 1e9, energy_reduce=em)
+    torch.manual_seed(22)
+    pb = train_pls(ppls, pstart.clone(), 12, 0.2 * eta, 1e9, energy_reduce=blocking)
+    assert torch.equal(pa[0], pb[0]) and len(pa[1]) == len(pb[1]) == 12
+    assert max(abs(x - y) / abs(y) for x, y in zip(pa[1], pb[1])) < 1e-12
     torch.save({"particles": mine.cpu(), "energy": energy, "mean": mean.cpu(), "var": var.cpu(), "samples": samples.cpu(),
                 "lam": basis.eigenvalues.cpu(), "vec": basis.eigenvectors.cpu(), "j0": j0, "j1": j1, "train": train},
                os.path.join(out_dir, f"out{rank}.pt"))
