@@ -78,31 +78,58 @@ class EnergyMean:
             self._open_board(required=board is True)
 
     def _open_board(self, required: bool) -> None:
+        """Collective over the group.  Every step that can fail locally (creating, mapping the file) is followed by an
+        agreement between the ranks, so that either all of them use the board or none does -- never a mixture that would wait
+        for each other in different places."""
         import os
         import socket
         import uuid
 
         import numpy as np
 
+        def all_agree(ok: bool) -> bool:
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+            if dist.get_backend(self.group) == "nccl":
+                flag = flag.cuda()
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            return bool(flag.item())
+
         hosts = [None] * self.world
         dist.all_gather_object(hosts, (socket.gethostname(), os.path.isdir("/dev/shm")), group=self.group)
-        same = all(h == hosts[0] for h in hosts) and hosts[0][1]
-        if not same:
+        if not (all(h == hosts[0] for h in hosts) and hosts[0][1]):
             if required:
                 raise RuntimeError("EnergyMean(board=True): the ranks of the group do not share one host with /dev/shm")
             return
-        name = [f"/dev/shm/pls_energy_{os.getpid()}_{uuid.uuid4().hex[:12]}" if self.rank == 0 else None]
+        name = [None]
         nbytes = 2 * self.RING * self.world * 8
         if self.rank == 0:
-            with open(name[0], "wb") as f:
-                f.write(b"\0" * nbytes)
+            try:
+                path = f"/dev/shm/pls_energy_{os.getpid()}_{uuid.uuid4().hex[:12]}"
+                with open(path, "wb") as f:
+                    f.write(b"\0" * nbytes)
+                name[0] = path
+            except OSError:
+                name[0] = None
         dist.broadcast_object_list(name, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
-        self._map = np.memmap(name[0], dtype=np.int64, mode="r+", shape=(2, self.RING, self.world))
-        self._seq = self._map[0]
-        self._val = self._map[1].view(np.float64)
-        dist.barrier(group=self.group)  # everybody has the file mapped: its name can go (the mapping keeps the pages)
-        if self.rank == 0:
-            os.unlink(name[0])
+        mapped = None
+        if name[0] is not None:
+            try:
+                mapped = np.memmap(name[0], dtype=np.int64, mode="r+", shape=(2, self.RING, self.world))
+            except (OSError, ValueError):
+                mapped = None
+        ok = all_agree(mapped is not None)  # (also the point after which the file's name can go: everybody has mapped it, or given up)
+        if self.rank == 0 and name[0] is not None:
+            try:
+                os.unlink(name[0])
+            except OSError:
+                pass
+        if not ok:
+            if required:
+                raise RuntimeError("EnergyMean(board=True): the board could not be created or mapped on every rank")
+            return
+        self._map = mapped
+        self._seq = mapped[0]
+        self._val = mapped[1].view(np.float64)
 
     @property
     def uses_board(self) -> bool:
