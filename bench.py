@@ -500,7 +500,12 @@ def main():
 
         here = kernel_source_hash()
         traffic_src = "no PMC summary under profiles/ was collected from the current kernel sources"
+        # (rNN_pmc_summary.json only: that name is the configs[1] workload on one GPU; other configs and shard runs carry a tag)
+        import re
+
         for prof in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), reverse=True):
+            if not re.fullmatch(r"r\d+_pmc_summary\.json", os.path.basename(prof)):
+                continue
             pm = json.load(open(prof))
             if pm.get("_kernel_source_hash") != here:
                 continue
