@@ -209,6 +209,30 @@ class InducingPointBasis(PLSBasis):
     def energy_partial_rows_bytes(self, j: int) -> int:
         return int(L.load().pls_energy_partials_bytes(self.approximation_dimension, j))
 
+    def lagged_step_launcher(self, cost, state: torch.Tensor, eta: torch.Tensor):
+        """(see OrthonormalBasis.lagged_step_launcher) -- the whitened step, pls_ipb_whitened_step_blocks, pre-bound"""
+        s = _rows_contiguous(L.require_gpu_tensor(state, "whitened particles"))
+        assert self.whitened and self._is_gaussian(cost, False)
+        self._prepare_for(cost)
+        fn = L.load().pls_ipb_whitened_step_blocks
+        desc, cd = self._desc(with_gaussian=True), cost.desc()
+        blocks, nd = L.BlockDesc(), L.NoiseDesc()
+        j = s.shape[1]
+        blocks.block_cols, blocks.eta = j, L.require_gpu_tensor(eta, "eta").data_ptr()
+        nd.kind, nd.step, nd.j_offset = L.NOISE_PHILOX, 0, int(self.j_offset)
+        stream, mode = L.stream_ptr(), L.OUT_NEW_STATE
+
+        def launch(s_ptr, lds, out_ptr, ldo, seed, partials_out, partials_prev, energy_prev, sums_prev):
+            nd.seed = seed
+            blocks.energy_partials, blocks.energy_partials_prev = partials_out, partials_prev
+            blocks.energy_prev, blocks.energy_sums_prev = energy_prev, sums_prev
+            rc = fn(desc, cd, s_ptr, lds, j, blocks, nd, out_ptr, ldo, mode, None, None, 0, stream)
+            if rc:
+                L.check(rc, "pls_ipb_whitened_step_blocks")
+
+        launch.keep_alive = (desc, cd, eta, self)
+        return launch
+
     def flush_energies(self, cost, state: torch.Tensor, blocks: BlockSpec) -> None:
         """(see OrthonormalBasis.flush_energies); ``state`` = the WHITENED particle matrix of the whitened_step calls"""
         s = _rows_contiguous(L.require_gpu_tensor(state, "whitened particles"))

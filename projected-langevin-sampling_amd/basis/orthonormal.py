@@ -329,6 +329,35 @@ class OrthonormalBasis(PLSBasis):
     def energy_partial_rows_bytes(self, j: int) -> int:
         return int(L.load().pls_energy_partials_bytes(self.approximation_dimension, j))
 
+    def lagged_step_launcher(self, cost, state: torch.Tensor, eta: torch.Tensor):
+        """The lagged Gaussian step of a training loop (pls_onb_step_blocks with energy_partials ...) as a PRE-BOUND call:
+        the descriptors, the step-size word, the Philox column offset and the stream are fixed for the whole loop, so they are
+        built once; the returned function takes what changes from launch to launch as raw addresses.  (Building the same call
+        through fused_step costs ~10 us of Python per iteration -- half of an iteration at the reference's own problem sizes.)
+        launch(u_ptr, ldu, out_ptr, ldo, seed, partials_out, partials_prev, energy_prev, sums_prev); ``state``: any of the
+        loop's particle buffers (shape only)."""
+        u = _rows_contiguous(L.require_gpu_tensor(state, "particles"))
+        y = cost.y_device()
+        self.prepare_gaussian(y)
+        fn = L.load().pls_onb_step_blocks
+        desc, cd = self._desc(with_gaussian=True), cost.desc()
+        blocks, nd = L.BlockDesc(), L.NoiseDesc()
+        j = u.shape[1]
+        blocks.block_cols, blocks.eta = j, L.require_gpu_tensor(eta, "eta").data_ptr()
+        nd.kind, nd.step, nd.j_offset = L.NOISE_PHILOX, 0, int(self.j_offset)
+        y_ptr, stream, mode = y.data_ptr(), L.stream_ptr(), L.OUT_NEW_STATE
+
+        def launch(u_ptr, ldu, out_ptr, ldo, seed, partials_out, partials_prev, energy_prev, sums_prev):
+            nd.seed = seed
+            blocks.energy_partials, blocks.energy_partials_prev = partials_out, partials_prev
+            blocks.energy_prev, blocks.energy_sums_prev = energy_prev, sums_prev
+            rc = fn(desc, cd, y_ptr, u_ptr, ldu, j, blocks, nd, out_ptr, ldo, mode, 0, None, None, 0, stream)
+            if rc:
+                L.check(rc, "pls_onb_step_blocks")
+
+        launch.keep_alive = (desc, cd, y, eta, self)
+        return launch
+
     def flush_energies(self, cost, state: torch.Tensor, blocks: BlockSpec) -> None:
         """Finish the partial rows the LAST step launch of a loop left (``blocks``: energy_flush=True, energy_partials_prev,
         energy_prev[, energy_sums_prev]); ``state``: the particle matrix the step calls were given (same shape / strides)."""

@@ -7,6 +7,7 @@ from typing import List, Tuple
 import numpy as np
 import torch
 
+from . import _lib as L
 from . import _ops
 from .projected_langevin_sampling import PLS
 
@@ -67,6 +68,11 @@ class _LoopSpace:
         basis, cost = self.pls.basis, self.pls.cost
         fn = basis.whitened_step if self.whitened else basis.fused_step
         return fn(cost, state, float(step_size), out=out, new_state=True, noise=noise, input_energy=input_energy, blocks=blocks)
+
+    def lagged_launcher(self, state, eta_dev):
+        """the lagged Gaussian step as a pre-bound call (basis.lagged_step_launcher), or None"""
+        make = getattr(self.pls.basis, "lagged_step_launcher", None)
+        return None if make is None else make(self.pls.cost, state, eta_dev)
 
     def flush(self, state, blocks) -> None:
         """finish the partial rows of the last step launch (lagged energies: BlockSpec.energy_flush)"""
@@ -217,9 +223,24 @@ def _train_pls_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs: in
     # last launch's partial rows are finished by a small launch of their own (flush)
     lagged = bool(fused_sums and LAGGED_ENERGIES and getattr(pls.basis, "supports_lagged_energies", lambda c: False)(pls.cost)
                   and (space.whitened or getattr(pls.basis, "fused_step_takes_lagged_energies", False)))
+    fast = None
     if lagged:
         pbytes = pls.basis.energy_partial_rows_bytes(j)
         parts = [torch.empty((pbytes + 7) // 8, dtype=torch.float64, device=particles.device) for _ in range(2)]
+        if noises is None and all(b.dim() == 2 and b.stride(1) == 1 for b in bufs):
+            # The host's share of an iteration is what bounds the loop at the reference's own problem sizes (a 10 us kernel
+            # against 20 us of Python): the step call is bound once (descriptors, stream), the buffers' addresses are looked up
+            # once, the pinned slots are polled through numpy views, and the per-step keys are drawn from torch's global
+            # generator in batches -- the same stream of draws as one per step, and the generator is left exactly where the
+            # plain loop leaves it (below)
+            fast = space.lagged_launcher(bufs[0], eta_dev)
+    if fast is not None:
+        buf_ptr, buf_ld = [b.data_ptr() for b in bufs], [L.ld(b) for b in bufs]
+        e_ptr, part_ptr = [e.data_ptr() for e in e_dev], [p_.data_ptr() for p_ in parts]
+        keys: List[int] = []
+        rng_start = torch.get_rng_state()
+    host_np = host.numpy()  # (shares the pinned pages)
+    host_np_bits = host_np.view(np.int64)
     flushed = [False]
     events = [torch.cuda.Event() for _ in range(NB)]
     rng_states = {}
@@ -228,6 +249,18 @@ def _train_pls_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs: in
     def launch():
         nonlocal launched
         k = launched
+        if fast is not None:  # launch k leaves the partial rows of E(U_k) and finishes those of E(U_{k-1}) into slot k - 1
+            if k >= len(keys):
+                keys.extend(torch.randint(0, 2**62, (256,), dtype=torch.int64).tolist())
+            a, b, prev = k % NB, (k + 1) % NB, (k - 1) % NB
+            if k > 0:
+                host_np_bits[prev * nchunk:(prev + 1) * nchunk] = UNWRITTEN
+                fast(buf_ptr[a], buf_ld[a], buf_ptr[b], buf_ld[b], keys[k], part_ptr[k % 2], part_ptr[(k - 1) % 2], e_ptr[prev],
+                     host_ptr + 8 * nchunk * prev)
+            else:
+                fast(buf_ptr[a], buf_ld[a], buf_ptr[b], buf_ld[b], keys[k], part_ptr[0], None, None, None)
+            launched += 1
+            return
         rng_states[k] = torch.get_rng_state()  # (a speculative launch may have to be un-drawn)
         spec = NoiseSpec(injected=noises[k]) if noises is not None else None
         if lagged:  # launch k leaves the partial rows of E(U_k) and finishes those of E(U_{k-1}) into slot k - 1
@@ -253,17 +286,17 @@ def _train_pls_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs: in
 
     def read_energy(slot: int) -> float:
         if mean is not None:  # J-sharded run (distributed.EnergyMean): the local SUM goes to the ranks' host-side exchange
-            local = mean_from_chunk_sums(host[slot * nchunk:(slot + 1) * nchunk].tolist(), 1) if fused_sums else host[slot].item() * j
+            local = mean_from_chunk_sums(host_np[slot * nchunk:(slot + 1) * nchunk].tolist(), 1) if fused_sums else float(host_np[slot]) * j
             return mean.reduce_local_sum(local)
         if fused_sums:
-            return mean_from_chunk_sums(host[slot * nchunk:(slot + 1) * nchunk].tolist(), j)
-        return host[slot].item()
+            return mean_from_chunk_sums(host_np[slot * nchunk:(slot + 1) * nchunk].tolist(), j)
+        return float(host_np[slot])
 
     def wait_for(slot: int) -> None:
         if not fused_sums:
             events[slot].synchronize()
             return
-        bits = host_bits[slot * nchunk:(slot + 1) * nchunk]
+        bits = host_np_bits[slot * nchunk:(slot + 1) * nchunk]
         spins = 0
         while bool((bits == UNWRITTEN).any()):
             spins += 1
@@ -275,6 +308,7 @@ def _train_pls_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs: in
 
     energy_potentials: List[float] = []
     final = None
+    keys_used = T  # (the plain loop draws one key per step it executes: T, or t + 1 when iteration t stops it)
     try:
         for t in range(T):  # iteration t of the plain loop: update t done (U_{t+1}), its energy E(U_{t+1}) wanted
             # launch t+1 carries E(U_{t+1}); t+2 .. t+depth keep the queue non-empty.  Launch k writes slot (k+1) % NB and
@@ -295,7 +329,9 @@ def _train_pls_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs: in
                 last = space.energy(bufs[T % NB])
                 energy_potential = _mean_energy(last) if mean is None else mean.reduce_local_sum(last.sum().item())
             if early_stopper.should_stop(loss=energy_potential, step_size=step_size):
-                if launched > t + 1:
+                if fast is not None:
+                    keys_used = t + 1
+                elif launched > t + 1:
                     torch.set_rng_state(rng_states[t + 1])
                 final = bufs[(t + 1) % NB]
                 break
@@ -304,6 +340,10 @@ def _train_pls_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs: in
         # up to `depth` launches are still queued: they write the pinned slots and the rotating buffers, which must not go
         # back to torch's allocators (on ANY exit: a raising early stopper, a failed launch) before they have drained
         torch.cuda.current_stream().synchronize()
+    if fast is not None:  # leave torch's generator where one draw per executed step leaves it (batched draws == single draws)
+        torch.set_rng_state(rng_start)
+        if keys_used > 0:
+            torch.randint(0, 2**62, (keys_used,), dtype=torch.int64)
     if final is None:
         final = bufs[T % NB]
     space.leave(final, particles)
