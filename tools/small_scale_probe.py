@@ -4,8 +4,8 @@ import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import projected_langevin_sampling_amd as P
 from projected_langevin_sampling_amd.basis import OrthonormalBasis
-from projected_langevin_sampling_amd.costs import GaussianCost
-from projected_langevin_sampling_amd.link_functions import IdentityLinkFunction
+from projected_langevin_sampling_amd.costs import BernoulliCost, GaussianCost
+from projected_langevin_sampling_amd.link_functions import IdentityLinkFunction, SigmoidLinkFunction
 from projected_langevin_sampling_amd.trainers import train_pls, train_pls_captured
 
 torch.set_default_dtype(torch.float64)
@@ -29,3 +29,12 @@ for (n, m, j, d) in ((100, 10, 64, 1), (4096, 128, 512, 4)):
         _, e = train_pls_captured(pls, u.clone(), 5000, eta, 1e9, steps_per_replay=k, seed=1)
         torch.cuda.synchronize(); w = time.perf_counter() - t0
         print(f"N={n} M={m} J={j}: train_pls_captured({k}) {w / len(e) * 1e6:6.2f} us per iteration incl. capture", flush=True)
+    # a cost without the Gaussian algebra: the loop launches the fused small-rank / two-GEMM step and a mean kernel per iteration
+    yb = (y > 0).double()
+    bpls = P.PLS(basis, BernoulliCost(yb, SigmoidLinkFunction()))
+    train_pls(bpls, u.clone(), 50, eta, 1e9)
+    for rep in range(2):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        _, e = train_pls(bpls, u.clone(), 3000, eta, 1e9)
+        torch.cuda.synchronize(); w = time.perf_counter() - t0
+        print(f"N={n} M={m} J={j}: Bernoulli/sigmoid train_pls {w / len(e) * 1e6:6.2f} us per iteration", flush=True)
