@@ -358,6 +358,42 @@ class OrthonormalBasis(PLSBasis):
         launch.keep_alive = (desc, cd, y, eta, self)
         return launch
 
+    def step_launcher(self, cost, state: torch.Tensor, step_size: float):
+        """pls_onb_step with the energy by-product, followed by the mean of the energies into a caller's slot (pls_block_means),
+        as a PRE-BOUND call for a training loop -- any cost (see lagged_step_launcher for why).  The loop owns the workspace
+        this binds.  launch(u_ptr, ldu, out_ptr, ldo, seed, energy_ptr, mean_ptr)"""
+        u = _rows_contiguous(L.require_gpu_tensor(state, "particles"))
+        j = u.shape[1]
+        y, cd = cost.y_device(), cost.desc()
+        gaussian = cd.cost == L.COST_GAUSSIAN and cd.link == L.LINK_IDENTITY
+        if gaussian:
+            self.prepare_gaussian(y)
+        lib = L.load()
+        desc = self._desc(with_gaussian=gaussian)
+        if gaussian:
+            ws_bytes = 2 * ((self.approximation_dimension + 127) // 128) * j * 8
+        else:
+            need_min = lib.pls_onb_step_workspace_bytes(desc, j, 128)
+            need_full = lib.pls_onb_step_workspace_bytes(desc, j, self._n)
+            ws_bytes = max(need_min, min(need_full, self.workspace_bytes))
+        ws = torch.empty((ws_bytes + 7) // 8, dtype=torch.float64, device=u.device)
+        nd = L.NoiseDesc()
+        nd.kind, nd.step, nd.j_offset = L.NOISE_PHILOX, 0, int(self.j_offset)
+        step, means = lib.pls_onb_step, lib.pls_block_means
+        y_ptr, ws_ptr, stream, mode, eta = y.data_ptr(), ws.data_ptr(), L.stream_ptr(), L.OUT_NEW_STATE, float(step_size)
+
+        def launch(u_ptr, ldu, out_ptr, ldo, seed, energy_ptr, mean_ptr):
+            nd.seed = seed
+            rc = step(desc, cd, y_ptr, u_ptr, ldu, j, eta, nd, out_ptr, ldo, mode, 0, energy_ptr, ws_ptr, ws_bytes, stream)
+            if rc:
+                L.check(rc, "pls_onb_step")
+            rc = means(energy_ptr, j, j, mean_ptr, stream)
+            if rc:
+                L.check(rc, "pls_block_means")
+
+        launch.keep_alive = (desc, cd, y, ws, self)
+        return launch
+
     def flush_energies(self, cost, state: torch.Tensor, blocks: BlockSpec) -> None:
         """Finish the partial rows the LAST step launch of a loop left (``blocks``: energy_flush=True, energy_partials_prev,
         energy_prev[, energy_sums_prev]); ``state``: the particle matrix the step calls were given (same shape / strides)."""

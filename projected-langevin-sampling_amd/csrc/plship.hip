@@ -888,21 +888,43 @@ __global__ __launch_bounds__(256) void column_reduce_kernel(const double *__rest
                                                              double pscale, const double *__restrict__ padd) {
   const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (col >= j) return;
+  // (Loads in batches of eight, sums in the order they always had: with a few hundred particles this kernel is two workgroups
+  // whose threads walk nparts + m rows one dependent load at a time -- 40 us for 32 + 128 rows, the longest launch of a
+  // training iteration at the reference's own problem sizes -- while the bits of the energies must not move.)
   double s = 0.0;
-  for (int64_t p = 0; p < nparts; ++p) s += partial[p * ldp + col];
+  for (int64_t p0 = 0; p0 < nparts; p0 += 8) {
+    double t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = (p0 + k < nparts) ? partial[(p0 + k) * ldp + col] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (p0 + k < nparts) s += t[k];
+  }
   s = pscale * (s + (padd ? *padd : 0.0)) + (accumulate ? out[col] : 0.0);
   if (prior_kind == 1) {
     double e = 0.0;
-    for (int64_t r = 0; r < m; ++r) {
-      const double u = P[r * ldpp + col];
-      e += u * u / lam[r];
+    for (int64_t r0 = 0; r0 < m; r0 += 8) {
+      double u[8], l[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const bool in = r0 + k < m;
+        u[k] = in ? P[(r0 + k) * ldpp + col] : 0.0;
+        l[k] = in ? lam[r0 + k] : 1.0;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (r0 + k < m) e += u[k] * u[k] / l[k];
     }
     s += 0.5 * e;
   } else if (prior_kind == 2) {
     double e = 0.0;
-    for (int64_t r = 0; r < m; ++r) {
-      const double u = P[r * ldpp + col];
-      e += u * u;
+    for (int64_t r0 = 0; r0 < m; r0 += 8) {
+      double u[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) u[k] = (r0 + k < m) ? P[(r0 + k) * ldpp + col] : 0.0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (r0 + k < m) e += u[k] * u[k];
     }
     s += scale * e;
   }
@@ -945,7 +967,14 @@ __global__ __launch_bounds__(256) void langevin_update_kernel(double *out, int64
       if (i < rows) {
         const double ps = lam ? 1.0 / lam[i] : pconst;
         double drift = D[i * ldd + col];
-        for (int sl = 1; sl < nslab; ++sl) drift += D[sl * slab_stride + i * ldd + col];  // split-K slabs, fixed order
+        for (int s0 = 1; s0 < nslab; s0 += 8) {  // split-K slabs, fixed order; eight loads in flight
+          double t[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) t[k] = (s0 + k < nslab) ? D[(int64_t)(s0 + k) * slab_stride + i * ldd + col] : 0.0;
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            if (s0 + k < nslab) drift += t[k];
+        }
         if (dsub) drift -= dsub_scale * dsub[i];  // (IPB Gaussian fast path: drift = (B V - c) / sigma2)
         const double d = -eta * drift - eta * ps * P[i * ldp + col] + sq2eta * (h ? z1 : z0);
         out[i * ldo + col] = add_u ? U[i * ldu + col] + d : d;

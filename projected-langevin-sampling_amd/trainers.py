@@ -69,6 +69,11 @@ class _LoopSpace:
         fn = basis.whitened_step if self.whitened else basis.fused_step
         return fn(cost, state, float(step_size), out=out, new_state=True, noise=noise, input_energy=input_energy, blocks=blocks)
 
+    def general_launcher(self, state, step_size):
+        """step + energy by-product + mean as a pre-bound call (basis.step_launcher), or None"""
+        make = None if self.whitened else getattr(self.pls.basis, "step_launcher", None)
+        return None if make is None else make(self.pls.cost, state, step_size)
+
     def lagged_launcher(self, state, eta_dev):
         """the lagged Gaussian step as a pre-bound call (basis.lagged_step_launcher), or None"""
         make = getattr(self.pls.basis, "lagged_step_launcher", None)
@@ -234,9 +239,15 @@ def _train_pls_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs: in
             # generator in batches -- the same stream of draws as one per step, and the generator is left exactly where the
             # plain loop leaves it (below)
             fast = space.lagged_launcher(bufs[0], eta_dev)
-    if fast is not None:
+    general = None
+    if not fused_sums and noises is None and pls.cost.is_native() and all(b.dim() == 2 and b.stride(1) == 1 for b in bufs):
+        # (other costs: the same host-side trim around pls_onb_step + pls_block_means; the mean's pinned slot is polled like
+        # the chunk sums instead of waited for through an event)
+        general = space.general_launcher(bufs[0], step_size)
+    if fast is not None or general is not None:
         buf_ptr, buf_ld = [b.data_ptr() for b in bufs], [L.ld(b) for b in bufs]
-        e_ptr, part_ptr = [e.data_ptr() for e in e_dev], [p_.data_ptr() for p_ in parts]
+        e_ptr = [e.data_ptr() for e in e_dev]
+        part_ptr = [p_.data_ptr() for p_ in parts] if fast is not None else None
         keys: List[int] = []
         rng_start = torch.get_rng_state()
     host_np = host.numpy()  # (shares the pinned pages)
@@ -259,6 +270,14 @@ def _train_pls_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs: in
                      host_ptr + 8 * nchunk * prev)
             else:
                 fast(buf_ptr[a], buf_ld[a], buf_ptr[b], buf_ld[b], keys[k], part_ptr[0], None, None, None)
+            launched += 1
+            return
+        if general is not None:  # launch k: U_{k+1} from U_k, E(U_k) as a by-product, its mean into slot k
+            if k >= len(keys):
+                keys.extend(torch.randint(0, 2**62, (256,), dtype=torch.int64).tolist())
+            a, b = k % NB, (k + 1) % NB
+            host_np_bits[a] = UNWRITTEN
+            general(buf_ptr[a], buf_ld[a], buf_ptr[b], buf_ld[b], keys[k], e_ptr[a], host_ptr + 8 * a)
             launched += 1
             return
         rng_states[k] = torch.get_rng_state()  # (a speculative launch may have to be un-drawn)
@@ -293,7 +312,7 @@ def _train_pls_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs: in
         return float(host_np[slot])
 
     def wait_for(slot: int) -> None:
-        if not fused_sums:
+        if not fused_sums and general is None:
             events[slot].synchronize()
             return
         bits = host_np_bits[slot * nchunk:(slot + 1) * nchunk]
@@ -329,7 +348,7 @@ def _train_pls_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs: in
                 last = space.energy(bufs[T % NB])
                 energy_potential = _mean_energy(last) if mean is None else mean.reduce_local_sum(last.sum().item())
             if early_stopper.should_stop(loss=energy_potential, step_size=step_size):
-                if fast is not None:
+                if fast is not None or general is not None:
                     keys_used = t + 1
                 elif launched > t + 1:
                     torch.set_rng_state(rng_states[t + 1])
@@ -340,7 +359,7 @@ def _train_pls_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs: in
         # up to `depth` launches are still queued: they write the pinned slots and the rotating buffers, which must not go
         # back to torch's allocators (on ANY exit: a raising early stopper, a failed launch) before they have drained
         torch.cuda.current_stream().synchronize()
-    if fast is not None:  # leave torch's generator where one draw per executed step leaves it (batched draws == single draws)
+    if fast is not None or general is not None:  # leave torch's generator where one draw per executed step leaves it
         torch.set_rng_state(rng_start)
         if keys_used > 0:
             torch.randint(0, 2**62, (keys_used,), dtype=torch.int64)
