@@ -362,6 +362,35 @@ class InducingPointBasis(PLSBasis):
             )
         return out
 
+    def step_launcher(self, cost, state: torch.Tensor, step_size: float):
+        """(see OrthonormalBasis.step_launcher) -- pls_ipb_step with the energy by-product + pls_block_means, pre-bound for a
+        training loop that stays in the original coordinates (any cost but the Gaussian fast path's whitened loop)"""
+        u = _rows_contiguous(L.require_gpu_tensor(state, "particles"))
+        j = u.shape[1]
+        lib = L.load()
+        gaussian = self._is_gaussian(cost, False)
+        if gaussian:
+            self._prepare_for(cost)
+        desc, cd, y = self._desc(with_gaussian=gaussian), cost.desc(), cost.y_device()
+        ws_bytes = max(lib.pls_ipb_step_workspace_bytes(desc, j, 128), min(lib.pls_ipb_step_workspace_bytes(desc, j, self._n), self.workspace_bytes))
+        ws = torch.empty((ws_bytes + 7) // 8, dtype=torch.float64, device=u.device)
+        nd = L.NoiseDesc()
+        nd.kind, nd.step, nd.j_offset = L.NOISE_PHILOX, 0, int(self.j_offset)
+        step, means = lib.pls_ipb_step, lib.pls_block_means
+        y_ptr, ws_ptr, stream, mode, eta = y.data_ptr(), ws.data_ptr(), L.stream_ptr(), L.OUT_NEW_STATE, float(step_size)
+
+        def launch(u_ptr, ldu, out_ptr, ldo, seed, energy_ptr, mean_ptr):
+            nd.seed = seed
+            rc = step(desc, cd, y_ptr, u_ptr, ldu, j, eta, nd, out_ptr, ldo, mode, 0, energy_ptr, ws_ptr, ws_bytes, stream)
+            if rc:
+                L.check(rc, "pls_ipb_step")
+            rc = means(energy_ptr, j, j, mean_ptr, stream)
+            if rc:
+                L.check(rc, "pls_block_means")
+
+        launch.keep_alive = (desc, cd, y, ws, self)
+        return launch
+
     def step_workspace_bytes(self, cost, j: int, with_energy: bool, force_generic: bool = False) -> int:
         """Bytes fused_step asks of its workspace for ``j`` columns (graph captures allocate their own buffer)."""
         lib = L.load()

@@ -714,6 +714,37 @@ def test_train_pls_is_pipelined_for_every_native_cost(P, rank_path):
     assert np.allclose(runs["pipelined"][1], want, rtol=1e-8)
 
 
+@pytest.mark.parametrize("basis_kind", ["onb", "ipb"])
+def test_pre_bound_step_calls_change_nothing(P, basis_kind):
+    """The pipelined loop binds its step call once (basis.step_launcher: descriptors, workspace, stream), draws the per-step
+    keys from torch's generator in batches and polls the mean's pinned slot instead of an event.  Against the same loop
+    building every call through fused_step: the same particles, energies, stop index and generator state, bit for bit --
+    library noise (Philox), a cost without the Gaussian algebra, both bases, with and without an early stop."""
+    pr = make_problem(700, 24, 80, 2, seed=11 + FUZZ_SEED)
+    if basis_kind == "onb":
+        _, gb = build_onb(P, pr)
+    else:
+        _, gb = build_ipb(P, pr)
+    mk = gb.approximation_dimension
+    _, _, gc = make_costs(P, pr["y"], pr["fstar"], pr["gen"])[2]  # bernoulli/sigmoid
+    pls = P.pkg.PLS(gb, gc)
+    u0 = cu(pr["u"][:mk].contiguous())
+    for patience in (1e9, 5e-6):
+        runs = []
+        for bound in (True, False):
+            if not bound:
+                gb.step_launcher = None  # (an instance attribute shadows the method: the loop falls back to fused_step)
+            try:
+                torch.manual_seed(44)
+                u, e = P.pkg.train_pls(pls, u0.clone(), 25, 2e-6, patience)
+                runs.append((u, e, torch.get_rng_state()))
+            finally:
+                if not bound:
+                    del gb.step_launcher
+        assert runs[0][1] == runs[1][1] and len(runs[0][1]) >= 1
+        assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][2], runs[1][2])
+
+
 @pytest.mark.parametrize("cost_idx,epochs,k,patience", [(0, 37, 8, 1e9), (0, 40, 16, 3e-3), (0, 40, 5, 3e-3), (0, 40, 1, 3e-3),
                                                         (2, 21, 8, 1e9), (2, 30, 4, 1e9), (0, 5, 16, 1e9)])
 def test_captured_training_matches_the_eager_loop(P, cost_idx, epochs, k, patience):
