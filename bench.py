@@ -354,7 +354,7 @@ def main():
     t_setup = time.perf_counter()
     kernel = pkg.PLSKernel(pkg.ARDKernel(ls, 1.0), z)
     basis = OrthonormalBasis(kernel, z, x, eigenvalue_threshold=cfg.get("threshold", 0.0), verbose=False, keep_gram=False,
-                             eigh_device=args.eigh_device, setup_times=setup)
+                             eigh_device=args.eigh_device, setup_times=setup, group=True if world > 1 else None)
     basis.workspace_bytes = int(args.workspace_gb * (1 << 30))
     setup["eigh_device"] = args.eigh_device  # (cuda: the first call of the process also loads the solver library, ~0.2 s)
     mk = basis.approximation_dimension
@@ -863,7 +863,7 @@ def main():
             t0 = time.perf_counter()
             k2 = pkg.PLSKernel(pkg.ARDKernel(ls, 1.0), z)
             b2 = OrthonormalBasis(k2, z, x, eigenvalue_threshold=cfg.get("threshold", 0.0), verbose=False, keep_gram=False,
-                                  eigh_device=eigh_device)
+                                  eigh_device=eigh_device, group=True if world > 1 else None)
             b2.workspace_bytes = basis.workspace_bytes
             if cfg["cost"] == "poisson":
                 c2 = PoissonCost(y, SquareLinkFunction())

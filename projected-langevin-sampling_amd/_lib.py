@@ -271,7 +271,16 @@ def check(rc: int, what: str = "") -> None:
         raise PlsHipError(f"{what or 'libplship'} failed (status {rc}): {msg}")
 
 
-def require_gpu_tensor(t: torch.Tensor, name: str) -> torch.Tensor:
+#: floating dtypes a caller may hand in where the library only READS (particles, cost derivatives, injected noise ...): the
+#: reference's bases compute in whatever dtype the caller uses (basis/base.py:52-63, :99-102 of the reference; its tests run
+#: in float32); libplship computes in float64, so such inputs are promoted on entry -- like x / z / y in kernel._dev -- and
+#: results are float64
+PROMOTED_DTYPES = (torch.float32, torch.float16, torch.bfloat16)
+
+
+def require_gpu_tensor(t: torch.Tensor, name: str, promote: bool = False) -> torch.Tensor:
+    """``t`` as a float64 device tensor.  ``promote``: a float32 / float16 / bfloat16 device tensor the library only reads
+    comes back as a float64 COPY; buffers the library writes (out=, loop state, workspaces) must be float64 already."""
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name} must be a torch.Tensor")
     if t.device.type != "cuda":
@@ -280,7 +289,10 @@ def require_gpu_tensor(t: torch.Tensor, name: str) -> torch.Tensor:
             "(no CPU fallback); move it with .cuda()"
         )
     if t.dtype != torch.float64:
-        raise PlsHipError(f"{name} must be float64 on the device, got {t.dtype}")
+        if promote and t.dtype in PROMOTED_DTYPES:
+            return t.detach().to(torch.float64)
+        raise TypeError(f"{name} must be float64 on the device, got {t.dtype}: convert it with {name}.double() "
+                        "(libplship computes in float64; read-only inputs in float32 are promoted automatically)")
     return t
 
 

@@ -34,7 +34,7 @@ class NoiseSpec:
         if self.none:
             d.kind = L.NOISE_NONE
         elif self.injected is not None:
-            xi = L.require_gpu_tensor(self.injected, "noise")
+            xi = L.require_gpu_tensor(self.injected, "noise", promote=True)
             assert xi.stride(-1) == 1
             d.kind, d.xi, d.ldxi = L.NOISE_INJECTED, xi.data_ptr(), L.ld(xi)
         else:

@@ -152,7 +152,7 @@ class InducingPointBasis(PLSBasis):
     # ---- whitened coordinates S = Lc^-1 U (Gaussian cost, identity link) ------------------------------------------------
     def whiten(self, particles: torch.Tensor) -> torch.Tensor:
         """S = Lc^-1 U (pls_ipb_whiten)."""
-        u = _rows_contiguous(L.require_gpu_tensor(particles, "particles"))
+        u = _rows_contiguous(L.require_gpu_tensor(particles, "particles", promote=True))
         s = torch.empty_like(u, memory_format=torch.contiguous_format)
         if u.shape[1]:
             L.check(L.load().pls_ipb_whiten(self._desc(), u.data_ptr(), L.ld(u), u.shape[1], s.data_ptr(), L.ld(s), L.stream_ptr()),
@@ -162,7 +162,8 @@ class InducingPointBasis(PLSBasis):
     def unwhiten(self, whitened: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
         """U = Lc S (pls_ipb_unwhiten)."""
         s = _rows_contiguous(L.require_gpu_tensor(whitened, "whitened particles"))
-        u = torch.empty_like(s, memory_format=torch.contiguous_format) if out is None else out
+        u = torch.empty_like(s, memory_format=torch.contiguous_format) if out is None else L.require_gpu_tensor(out, "out")
+        assert u.shape == s.shape, f"out has shape {tuple(u.shape)}, the whitened particles {tuple(s.shape)}"
         if s.shape[1]:
             L.check(L.load().pls_ipb_unwhiten(self._desc(), s.data_ptr(), L.ld(s), s.shape[1], u.data_ptr(), L.ld(u), L.stream_ptr()),
                     "pls_ipb_unwhiten")
@@ -179,6 +180,9 @@ class InducingPointBasis(PLSBasis):
         j = s.shape[1]
         if out is None:
             out = torch.empty_like(s, memory_format=torch.contiguous_format)
+        else:  # (written as float64 through a raw pointer: a buffer of another dtype or shape must never get this far)
+            L.require_gpu_tensor(out, "out")
+            assert out.shape == s.shape, f"out has shape {tuple(out.shape)}, the particles {tuple(s.shape)}"
         if j == 0:
             return out
         assert out.data_ptr() != s.data_ptr(), "whitened_step: out must not alias its input"
@@ -270,7 +274,7 @@ class InducingPointBasis(PLSBasis):
 
     def calculate_untransformed_train_prediction_samples(self, particles: torch.Tensor) -> torch.Tensor:
         """F = k(X,Z) k(Z,Z)^-1 U  (:81-93)."""
-        u = _rows_contiguous(L.require_gpu_tensor(particles, "particles"))
+        u = _rows_contiguous(L.require_gpu_tensor(particles, "particles", promote=True))
         j = u.shape[1]
         m = self.approximation_dimension
         f = torch.empty((self._n, j), dtype=torch.float64, device=u.device)
@@ -284,9 +288,9 @@ class InducingPointBasis(PLSBasis):
 
     def particle_energy_potential(self, particles: torch.Tensor, cost: torch.Tensor | None) -> torch.Tensor:
         """e_j = cost_j + M/2 ||k(Z,Z)^-1 U_j||^2  (:95-114)."""
-        u = _rows_contiguous(L.require_gpu_tensor(particles, "particles"))
+        u = _rows_contiguous(L.require_gpu_tensor(particles, "particles", promote=True))
         j = u.shape[1]
-        c = None if cost is None else L.require_gpu_tensor(cost, "cost").contiguous()
+        c = None if cost is None else L.require_gpu_tensor(cost, "cost", promote=True).contiguous()
         e = torch.empty(j, dtype=torch.float64, device=u.device)
         ws = self._workspace(self.approximation_dimension * j * 8, u.device)
         L.check(
@@ -302,8 +306,8 @@ class InducingPointBasis(PLSBasis):
     def _calculate_particle_update(self, particles: torch.Tensor, cost_derivative: torch.Tensor, step_size: float,
                                    noise: torch.Tensor | None = None) -> torch.Tensor:
         """dU = -eta k(Z,X) G - eta M k(Z,Z)^-1 U + sqrt(2 eta) e  (:117-150); ``noise`` is e itself."""
-        u = _rows_contiguous(L.require_gpu_tensor(particles, "particles"))
-        g = _rows_contiguous(L.require_gpu_tensor(cost_derivative, "cost_derivative"))
+        u = _rows_contiguous(L.require_gpu_tensor(particles, "particles", promote=True))
+        g = _rows_contiguous(L.require_gpu_tensor(cost_derivative, "cost_derivative", promote=True))
         j = u.shape[1]
         assert g.shape == (self._n, j), f"cost_derivative has shape {tuple(g.shape)}, expected ({self._n}, {j})"
         du = torch.empty_like(u, memory_format=torch.contiguous_format)
@@ -328,10 +332,13 @@ class InducingPointBasis(PLSBasis):
         """One whole Langevin step (pls_ipb_step).  ``input_energy`` (J,) receives the per-particle energy of
         ``particles`` as a by-product (cost of the same F + (M/2)||K^-1 U||^2).  ``blocks``: one step size per column
         block (pls_ipb_step_blocks; ``step_size`` is then ignored).  ``workspace``: a caller-owned buffer (graph captures)."""
-        u = _rows_contiguous(L.require_gpu_tensor(particles, "particles"))
+        u = _rows_contiguous(L.require_gpu_tensor(particles, "particles", promote=True))
         j = u.shape[1]
         if out is None:
             out = torch.empty_like(u, memory_format=torch.contiguous_format)
+        else:  # (written as float64 through a raw pointer: a buffer of another dtype or shape must never get this far)
+            L.require_gpu_tensor(out, "out")
+            assert out.shape == u.shape, f"out has shape {tuple(out.shape)}, the particles {tuple(u.shape)}"
         if j == 0:
             return out
         assert out.data_ptr() != u.data_ptr(), "fused_step: out must not alias particles"
@@ -407,7 +414,7 @@ class InducingPointBasis(PLSBasis):
         return bool(cost.is_native()) and self.whitened and self._is_gaussian(cost, False)
 
     def fused_particle_energy(self, cost, particles: torch.Tensor, force_generic: bool = False) -> torch.Tensor:
-        u = _rows_contiguous(L.require_gpu_tensor(particles, "particles"))
+        u = _rows_contiguous(L.require_gpu_tensor(particles, "particles", promote=True))
         j = u.shape[1]
         lib = L.load()
         gaussian = self._is_gaussian(cost, force_generic)
@@ -449,12 +456,12 @@ class InducingPointBasis(PLSBasis):
     def predict_untransformed_samples(self, particles: torch.Tensor, x: torch.Tensor,
                                       noise: torch.Tensor | None = None) -> torch.Tensor:
         """G(x) + r(x,Z) r(Z,Z)^-1 (U - G(Z))  (:204-240); r(Z,Z) is factorised on the device once per call."""
-        u = _rows_contiguous(L.require_gpu_tensor(particles, "particles"))
+        u = _rows_contiguous(L.require_gpu_tensor(particles, "particles", promote=True))
         gram_induce_x = self.kernel.forward(x1=self.x_induce, x2=x, additional_approximation_samples=x)  # r(Z,x) (M,N*)
         gram_induce = self.kernel.forward(x1=self.x_induce, x2=self.x_induce, additional_approximation_samples=x)
         if noise is None:
             noise = self.sample_predictive_noise(particles=particles, x=x)
-        noise = L.require_gpu_tensor(noise, "noise")
+        noise = L.require_gpu_tensor(noise, "noise", promote=True)
         m = self.approximation_dimension
         # r(Z,Z)^-1 r(Z,x): gpytorch.solve(lhs=r(x,Z), input=r(Z,Z), rhs=...) at :235-239 -- a psd-safe Cholesky of r(Z,Z)
         # (its condition number is the SQUARE of k(Z,Z)'s: the jitter schedule matters here) and two triangular solves

@@ -61,8 +61,10 @@ class OrthonormalBasis(PLSBasis):
             # is the reference's CPU path (host LAPACK: 0.9 s at M = 1024, 21 s at 4096 on a GPU box's host share; the
             # whole setup otherwise takes 0.1 s); on the GPU the same factorisation takes 0.03 / 0.15 s -- another,
             # equally valid, eigenvector gauge (signs made canonical, basis/spectrum.py), and eigenvalues that differ in
-            # the last bits.  ONE process decides: under torch.distributed rank 0 of ``group`` factorises and broadcasts
-            # (lambda, V), so every rank of a J-sharded run keeps the same count and the same gauge, bit for bit.
+            # the last bits.  A J-sharded run passes ``group`` (True = the default process group, or a ProcessGroup): ONE
+            # process decides -- rank 0 of the group factorises and broadcasts (lambda, V) after the group has checked
+            # that all ranks hold the same k(Z,Z)/M -- so every rank keeps the same count and the same gauge, bit for
+            # bit.  ``group=None`` (default) enters no collective: the reference's local eigh (basis/spectrum.py).
             from ..samplers import resolve_eigh_device
             from .spectrum import shared_spectrum
 
@@ -198,7 +200,7 @@ class OrthonormalBasis(PLSBasis):
 
     def calculate_untransformed_train_prediction_samples(self, particles: torch.Tensor) -> torch.Tensor:
         """F = k(X,Z) V~ U = A^T U  (N, J)  (:98-108)."""
-        u = _rows_contiguous(L.require_gpu_tensor(particles, "particles"))
+        u = _rows_contiguous(L.require_gpu_tensor(particles, "particles", promote=True))
         j = u.shape[1]
         f = torch.empty((self._n, j), dtype=torch.float64, device=u.device)
         L.check(
@@ -209,9 +211,9 @@ class OrthonormalBasis(PLSBasis):
 
     def particle_energy_potential(self, particles: torch.Tensor, cost: torch.Tensor | None) -> torch.Tensor:
         """Per-particle energy e_j = cost_j + 1/2 sum_m U_mj^2 / lambda_m  (J,)  (:120-125)."""
-        u = _rows_contiguous(L.require_gpu_tensor(particles, "particles"))
+        u = _rows_contiguous(L.require_gpu_tensor(particles, "particles", promote=True))
         j = u.shape[1]
-        c = None if cost is None else L.require_gpu_tensor(cost, "cost").contiguous()
+        c = None if cost is None else L.require_gpu_tensor(cost, "cost", promote=True).contiguous()
         e = torch.empty(j, dtype=torch.float64, device=u.device)
         L.check(
             L.load().pls_onb_prior_energy(self._desc(), u.data_ptr(), L.ld(u), j, L.ptr(c), e.data_ptr(), L.stream_ptr()),
@@ -225,8 +227,8 @@ class OrthonormalBasis(PLSBasis):
     def _calculate_particle_update(self, particles: torch.Tensor, cost_derivative: torch.Tensor, step_size: float,
                                    noise: torch.Tensor | None = None) -> torch.Tensor:
         """dU = -eta V~^T k(Z,X) G - eta Lambda^-1 U + sqrt(2 eta) xi  (:128-159)."""
-        u = _rows_contiguous(L.require_gpu_tensor(particles, "particles"))
-        g = _rows_contiguous(L.require_gpu_tensor(cost_derivative, "cost_derivative"))
+        u = _rows_contiguous(L.require_gpu_tensor(particles, "particles", promote=True))
+        g = _rows_contiguous(L.require_gpu_tensor(cost_derivative, "cost_derivative", promote=True))
         j = u.shape[1]
         assert g.shape == (self._n, j), f"cost_derivative has shape {tuple(g.shape)}, expected ({self._n}, {j})"
         du = torch.empty_like(u, memory_format=torch.contiguous_format)
@@ -273,10 +275,13 @@ class OrthonormalBasis(PLSBasis):
         ``input_energy`` (J,) receives the per-particle energy of ``particles`` as a by-product.  ``blocks``: one step size
         per column block (pls_onb_step_blocks; ``step_size`` is then ignored).  ``workspace``: a caller-owned buffer --
         a captured hipGraph freezes its address, so captures never use the basis' own growable scratch."""
-        u = _rows_contiguous(L.require_gpu_tensor(particles, "particles"))
+        u = _rows_contiguous(L.require_gpu_tensor(particles, "particles", promote=True))
         j = u.shape[1]
         if out is None:
             out = torch.empty_like(u, memory_format=torch.contiguous_format)
+        else:  # (written as float64 through a raw pointer: a buffer of another dtype or shape must never get this far)
+            L.require_gpu_tensor(out, "out")
+            assert out.shape == u.shape, f"out has shape {tuple(out.shape)}, the particles {tuple(u.shape)}"
         if j == 0:
             return out
         assert out.data_ptr() != u.data_ptr(), "fused_step: out must not alias particles"
@@ -409,7 +414,7 @@ class OrthonormalBasis(PLSBasis):
     def fused_particle_energy(self, cost, particles: torch.Tensor, force_generic: bool = False) -> torch.Tensor:
         """Per-particle energy (pls_onb_energy): the cost is reduced inside a GEMM epilogue -- the N x Mk x J forward
         GEMM in general, the Mk x Mk x J quadratic form for Gaussian/identity."""
-        u = _rows_contiguous(L.require_gpu_tensor(particles, "particles"))
+        u = _rows_contiguous(L.require_gpu_tensor(particles, "particles", promote=True))
         j = u.shape[1]
         lib = L.load()
         cd = cost.desc()
@@ -430,7 +435,8 @@ class OrthonormalBasis(PLSBasis):
     # ---- prediction (one-time, not on the step path) -----------------------------------------------
     def sample_predictive_noise(self, particles: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
         """(M_k + N*, J) joint Gaussian noise G([Z, x]) (:161-214).  Gram blocks and the products are libplship kernels, the
-        normals come from the device generator keyed by the global particle column (samplers.DEFAULT_NORMAL_STREAM), and
+        normals come from samplers.DEFAULT_NORMAL_STREAM (the reference's host stream; for a J-sharded run the device generator
+        keyed by the global particle column), and
         the (M_k + N*) eigh of the sampler (samplers.py:27) is remembered per test-point tensor: tempering and conformal
         calibration predict at the same points again and again (temper/base.py:30-59, conformalise/base.py:58-114)."""
         lt = self._predictive_factor(x)
@@ -456,11 +462,11 @@ class OrthonormalBasis(PLSBasis):
     def predict_untransformed_samples(self, particles: torch.Tensor, x: torch.Tensor,
                                       noise: torch.Tensor | None = None) -> torch.Tensor:
         """G(x) + k(x,Z) V~ (U - G(Z))  (:216-244), as  G(x) + P U - P G(Z)  with P^T = V~^T k(Z,x) built once."""
-        u = _rows_contiguous(L.require_gpu_tensor(particles, "particles"))
+        u = _rows_contiguous(L.require_gpu_tensor(particles, "particles", promote=True))
         base_gram_induce_x = self.kernel.base_kernel(x1=self.x_induce, x2=x)  # k(Z, x) (M, N*)
         if noise is None:
             noise = self.sample_predictive_noise(particles=particles, x=x)
-        noise = L.require_gpu_tensor(noise, "noise")
+        noise = L.require_gpu_tensor(noise, "noise", promote=True)
         mk = self.approximation_dimension
         pt = _ops.gemm_tn(self.scaled_eigenvectors, base_gram_induce_x)  # (M_k, N*) = V~^T k(Z,x)
         out = noise[mk:, :].contiguous().clone()

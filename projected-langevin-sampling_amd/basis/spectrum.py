@@ -6,8 +6,13 @@ every eigenvector (and a rotation inside a cluster of equal eigenvalues): ranks 
 different counts M_k at a threshold that cuts through rounding-level eigenvalues, or hold coordinates in different gauges
 that `gather_particles` / `save_pls` would then mix silently.  So:
 
-* ``shared_spectrum``: when torch.distributed is initialised, rank ``src`` runs the eigh and broadcasts (lambda, V)
-  -- M (M + 1) doubles, 8 MB at M = 1024 -- every rank keeps the SAME bits, whatever its own Gram matrix rounded to;
+* ``shared_spectrum``: OPT-IN (``group=True`` for the default process group, or a ProcessGroup).  Rank ``src`` runs the
+  eigh and broadcasts (lambda, V) -- M (M + 1) doubles, 8 MB at M = 1024 -- and every rank keeps the SAME bits, whatever
+  its own Gram matrix rounded to.  Before a rank adopts another rank's spectrum the group checks that all ranks hold the
+  same matrix up to rounding (M and two weighted sums of k(Z,Z)/M, one fixed-size all-reduce): ranks that were handed
+  different inducing points or hyper-parameters get a RuntimeError instead of the eigenvectors of somebody else's Gram
+  matrix.  ``group=None`` (the default) is the reference's behaviour: a local eigh and no collective at all, so a basis
+  built by ONE rank of a running job (a rank-0 evaluation, a per-rank sweep) never waits for peers that do not come;
 * ``canonicalise_signs``: the largest-magnitude component of every eigenvector is made positive (ties: the first), so
   that two solvers which agree on the eigenvectors up to sign give the same matrix.  Applied to the device (rocSOLVER)
   route; the host LAPACK route keeps LAPACK's raw signs, the gauge the reference's CPU path and its goldens have;
@@ -33,12 +38,46 @@ def canonicalise_signs(eigenvectors: torch.Tensor) -> torch.Tensor:
     return eigenvectors * s[None, :]
 
 
+def _resolve_group(group):
+    """(active, process group or None for the default one).  None / False: no collective (the caller's own eigh); True: the
+    default process group; anything else: that ProcessGroup."""
+    if group is None or group is False:
+        return False, None
+    pg = None if group is True else group
+    active = dist.is_available() and dist.is_initialized() and dist.get_world_size(pg) > 1
+    return active, pg
+
+
 def _dist_active(group) -> bool:
-    """``group`` False opts out: a basis built by ONE rank of a running job (an evaluation on rank 0) must not enter a
-    collective the other ranks never reach."""
-    if group is False:
-        return False
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    return _resolve_group(group)[0]
+
+
+def assert_same_matrix(gram_scaled: torch.Tensor, group, rtol: float = 1e-9) -> None:
+    """Collective: every rank of ``group`` holds the same k(Z,Z) / M up to rounding.  One all-reduce of a fixed-size vector
+    (so ranks with different M meet in it instead of hanging in a broadcast of mismatched shapes): M, the plain sum and a
+    sum weighted by an incommensurate probe.  Raises on EVERY rank when any two disagree."""
+    active, pg = _resolve_group(group)
+    if not active:
+        return
+    g = gram_scaled.detach().to(torch.float64)
+    m = g.shape[0]
+    w = _probe_vector(m).to(g.device)
+    sig = torch.stack([torch.tensor(float(m), dtype=torch.float64, device=g.device), g.sum(), (w @ g @ w),
+                       g.abs().sum()]).cpu()
+    dev = _collective_device(pg, gram_scaled)
+    both = torch.cat([sig, -sig]).to(dev)
+    dist.all_reduce(both, op=dist.ReduceOp.MAX, group=pg)
+    both = both.cpu()
+    hi, lo = both[:4], -both[4:]
+    if float(hi[0]) != float(lo[0]):
+        raise RuntimeError(f"orthonormal basis: the ranks of the group hold different numbers of inducing points "
+                           f"({int(lo[0])} .. {int(hi[0])}, this rank {m}); a shared spectrum needs ONE k(Z,Z) -- build with "
+                           f"group=None for per-rank bases")
+    scale = float(hi[3]) if float(hi[3]) > 0 else 1.0
+    if float((hi[1:3] - lo[1:3]).abs().max()) > rtol * scale:
+        raise RuntimeError("orthonormal basis: the ranks of the group hold different k(Z,Z) / M (other inducing points or "
+                           "kernel hyper-parameters); a shared spectrum needs ONE matrix -- build with group=None for "
+                           "per-rank bases")
 
 
 def _collective_device(group, like: torch.Tensor) -> torch.device:
@@ -51,12 +90,16 @@ def _collective_device(group, like: torch.Tensor) -> torch.device:
 
 def shared_spectrum(gram_scaled: torch.Tensor, eigh_where: str, group=None, src: int = 0,
                     canonical_signs: Optional[bool] = None) -> Tuple[torch.Tensor, torch.Tensor]:
-    """(eigenvalues, eigenvectors) of ``gram_scaled`` = k(Z,Z) / M as float64 CPU tensors (ascending, like torch.linalg.eigh),
-    identical on every rank of ``group``.  ``eigh_where``: "cpu" (host LAPACK) or "cuda" (the device ``gram_scaled`` lives
-    on).  ``src`` is a rank of ``group``.  ``canonical_signs`` None = True for the device route, False for the host route."""
+    """(eigenvalues, eigenvectors) of ``gram_scaled`` = k(Z,Z) / M as float64 CPU tensors (ascending, like torch.linalg.eigh).
+    ``group`` None: this process's own eigh, no collective.  ``group`` True (default process group) or a ProcessGroup:
+    identical on every rank of the group, after a check that the ranks hold the same matrix (assert_same_matrix).
+    ``eigh_where``: "cpu" (host LAPACK) or "cuda" (the device ``gram_scaled`` lives on).  ``src`` is a rank of ``group``.
+    ``canonical_signs`` None = True for the device route, False for the host route."""
     assert eigh_where in ("cpu", "cuda")
     m = gram_scaled.shape[0]
-    active = _dist_active(group)
+    active, group = _resolve_group(group)
+    if active:
+        assert_same_matrix(gram_scaled, group if group is not None else True)
     rank = dist.get_rank(group) if active else 0
     if canonical_signs is None:
         canonical_signs = eigh_where == "cuda"
@@ -79,7 +122,8 @@ def shared_spectrum(gram_scaled: torch.Tensor, eigh_where: str, group=None, src:
 def assert_same_count(mk: int, group=None) -> None:
     """Every rank of a J-sharded run must keep the same number of eigen-directions (orthonormal.py:52-60): the particle
     matrices are concatenated along J (gather_particles) and reduced row by row (predictive_moments)."""
-    if not _dist_active(group):
+    active, group = _resolve_group(group)
+    if not active:
         return
     dev = _collective_device(group, torch.empty(0))
     lo = torch.tensor([mk, -mk], dtype=torch.int64, device=dev)

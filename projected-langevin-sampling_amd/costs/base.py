@@ -76,7 +76,7 @@ class PLSCost(ABC):
 
     def calculate_cost(self, untransformed_train_prediction_samples: torch.Tensor) -> torch.Tensor:
         """(N, J) -> (J,): sum_n cost(y_n, f_nj) (e.g. gaussian.py:63-73)."""
-        f = L.require_gpu_tensor(untransformed_train_prediction_samples, "untransformed_train_prediction_samples")
+        f = L.require_gpu_tensor(untransformed_train_prediction_samples, "untransformed_train_prediction_samples", promote=True)
         f = f if f.stride(-1) == 1 else f.contiguous()
         n, j = f.shape
         y = self.y_device()
@@ -97,7 +97,7 @@ class PLSCost(ABC):
         self, untransformed_train_prediction_samples: torch.Tensor, force_autograd: bool = False
     ) -> torch.Tensor:
         """(N, J) -> (N, J): d cost / d f (closed form or the autograd value, like the reference's dispatch)."""
-        f = L.require_gpu_tensor(untransformed_train_prediction_samples, "untransformed_train_prediction_samples")
+        f = L.require_gpu_tensor(untransformed_train_prediction_samples, "untransformed_train_prediction_samples", promote=True)
         f = f if f.stride(-1) == 1 else f.contiguous()
         n, j = f.shape
         y = self.y_device()
@@ -113,7 +113,8 @@ class PLSCost(ABC):
     def sample_observation_noise(self, number_of_particles: int, seed: int | None = None, j_offset: int = 0,
                                  normal_stream: str | None = None) -> torch.Tensor:
         """costs/base.py:86-115: one N(0, observation_noise^2) draw per particle (observation_noise is a STD here, SURVEY
-        H6).  The normals come from samplers.DEFAULT_NORMAL_STREAM: "device" = libplship's generator keyed by ``seed`` (or
+        H6).  The normals come from samplers.DEFAULT_NORMAL_STREAM ("auto": the reference's stream unless the run is
+        J-sharded): "device" = libplship's generator keyed by ``seed`` (or
         one draw from torch's global generator) and the GLOBAL particle index ``j_offset`` + column, so a J-sharded
         prediction gives every particle its own draw whatever the GPU count; "reference" = torch.normal on the host
         generator, the reference's stream."""
@@ -121,7 +122,7 @@ class PLSCost(ABC):
             return torch.zeros(number_of_particles, dtype=torch.float64, device="cuda")
         from .. import samplers
 
-        stream = normal_stream or samplers.DEFAULT_NORMAL_STREAM
+        stream = samplers.resolve_normal_stream(normal_stream, j_offset)
         if stream == "reference":
             generator = torch.Generator().manual_seed(seed) if seed is not None else None
             noise = torch.normal(

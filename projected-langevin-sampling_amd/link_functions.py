@@ -25,7 +25,7 @@ class PLSLinkFunction(ABC):
 
     def _native_transform(self, y: torch.Tensor, col_offset: torch.Tensor | None = None) -> torch.Tensor:
         """link(y + col_offset[None, :]) in one libplship kernel."""
-        L.require_gpu_tensor(y, "y")
+        y = L.require_gpu_tensor(y, "y", promote=True)
         y2 = y.reshape(1, -1) if y.dim() != 2 else y
         y2 = y2 if y2.stride(-1) == 1 else y2.contiguous()
         out = torch.empty(y2.shape, dtype=torch.float64, device=y.device)

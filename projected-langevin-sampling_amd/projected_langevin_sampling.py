@@ -3,6 +3,7 @@ from __future__ import annotations
 
 import torch
 
+from . import _lib as L
 from . import _ops
 from .basis.base import NoiseSpec, PLSBasis
 from .costs.base import PLSCost
@@ -38,6 +39,10 @@ class PLS:
         return self.basis.initialise_particles(number_of_particles=number_of_particles, noise_only=noise_only, seed=seed)
 
     def sample_observation_noise(self, number_of_particles: int, seed: int | None = None) -> torch.Tensor:
+        j_offset = getattr(self.basis, "j_offset", 0)
+        if j_offset and getattr(self.cost, "is_native", lambda: False)():
+            # (a J-sharded run: the draw of a particle is keyed by its GLOBAL column, so every shard holds its own draws)
+            return self.cost.sample_observation_noise(number_of_particles=number_of_particles, seed=seed, j_offset=j_offset)
         return self.cost.sample_observation_noise(number_of_particles=number_of_particles, seed=seed)
 
     def sample_predictive_noise(self, particles: torch.Tensor, x: torch.Tensor):
@@ -76,6 +81,12 @@ class PLS:
         (the loop body of experiments/trainers.py:153-157).  Mutates and returns ``particles``."""
         if not self._fused():
             particles += self.calculate_particle_update(particles, step_size, noise=noise)
+            return particles
+        if particles.is_cuda and particles.dtype in L.PROMOTED_DTYPES:
+            # float32 particles (the reference's bases compute in the caller's dtype, basis/base.py:52-63): the step runs in
+            # float64 and the caller's tensor receives the rounded state, like `particles += update` would
+            state = self.step_(particles.double(), step_size, noise=noise)
+            particles.copy_(state)
             return particles
         if self._pong is None or self._pong.shape != particles.shape or self._pong.device != particles.device:
             self._pong = torch.empty_like(particles, memory_format=torch.contiguous_format)

@@ -35,15 +35,35 @@ def resolve_eigh_device(requested: str | None, matrix: torch.Tensor) -> str:
 
 
 #: where the standard normals that sample_multivariate_normal colours come from.
-#:   "device" (default): libplship's counter-based generator on the GPU (pls_normal_fill: Philox4x32-10 + Box-Muller), keyed
+#:   "auto" (default): "reference" for a run that is not J-sharded, "device" as soon as it is (``j_offset`` != 0, or
+#:       torch.distributed initialised with more than one rank).  The drop-in contract comes first: after ``set_seed(0)``
+#:       ``sample_multivariate_normal(zeros(2), eye(2), size=(2,), seed=0)`` returns the reference's pinned draws
+#:       (tests/test_samplers.py:19-26 of the reference), and a sharded run -- which the reference does not have -- gets
+#:       the stream that makes its result independent of the GPU count.
+#:   "reference": torch.normal on the host generator and a host -> device copy, the reference's stream, sample for sample
+#:       (samplers.py:30-40); 0.3 s of host time for 2 000 test points x 8 192 particles.
+#:   "device": libplship's counter-based generator on the GPU (pls_normal_fill: Philox4x32-10 + Box-Muller), keyed
 #:       by ``seed`` -- or, with ``seed=None``, by ONE 63-bit draw from torch's global CPU generator, so that the
 #:       reference's reproducibility contract (set_seed before a run) holds -- and by the GLOBAL particle column, so the
 #:       ranks of a J-sharded prediction draw different columns of one matrix and the result does not depend on the GPU
 #:       count.  (With the host stream every rank seeded alike would draw the SAME normals for different particles.)
-#:   "reference": torch.normal on the host generator and a host -> device copy, the reference's stream, sample for sample
-#:       (samplers.py:30-40) -- what the parity tests pin; 0.3 s of host time for 2 000 test points x 8 192 particles.
+#:       Set ``samplers.DEFAULT_NORMAL_STREAM = "device"`` for single-GPU runs that predict on thousands of points.
 #: Same law either way: N(mean, Q max(Lambda, 0) Q^T).
-DEFAULT_NORMAL_STREAM = "device"
+DEFAULT_NORMAL_STREAM = "auto"
+
+
+def resolve_normal_stream(requested: str | None, j_offset: int = 0) -> str:
+    """'device' or 'reference': the explicit request, else DEFAULT_NORMAL_STREAM; 'auto' = 'device' only for a J-sharded run"""
+    stream = requested or DEFAULT_NORMAL_STREAM
+    assert stream in ("auto", "device", "reference"), "normal_stream must be 'auto', 'device' or 'reference'"
+    if stream != "auto":
+        return stream
+    if j_offset:
+        return "device"
+    import torch.distributed as dist
+
+    sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return "device" if sharded else "reference"
 
 
 def spectral_factor(cov: torch.Tensor, eigh_device: str | None = None) -> torch.Tensor:
@@ -63,8 +83,7 @@ def spectral_factor(cov: torch.Tensor, eigh_device: str | None = None) -> torch.
 def standard_normals(n: int, size: Tuple[int], seed: int | None = None, normal_stream: str | None = None,
                      j_offset: int = 0) -> torch.Tensor:
     """(n, prod(size)) standard normals on the device from the chosen stream (DEFAULT_NORMAL_STREAM)."""
-    stream = normal_stream or DEFAULT_NORMAL_STREAM
-    assert stream in ("device", "reference"), "normal_stream must be 'device' or 'reference'"
+    stream = resolve_normal_stream(normal_stream, j_offset)
     j = 1
     for v in size:
         j *= int(v)

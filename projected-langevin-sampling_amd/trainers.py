@@ -121,6 +121,13 @@ def train_pls(
     orthonormal basis), the loop is software-pipelined: the launch of step t+1 also produces the energy the reference
     evaluates after step t, so every iteration is ONE kernel.  Results (particles, energy list, stop index, torch RNG
     state) are those of the plain loop: a step launched speculatively past the stop is discarded."""
+    if particles.is_cuda and particles.dtype in L.PROMOTED_DTYPES:
+        # float32 particles: the run is carried in float64 (one rounding at the end instead of one per step) and the caller's
+        # tensor receives the final state, which is also what is returned -- trainers.py:157 mutates its argument
+        state, energy_potentials = train_pls(pls, particles.double(), number_of_epochs, step_size, early_stopper_patience,
+                                             tqdm_desc, noises, energy_reduce)
+        particles.copy_(state)
+        return particles, energy_potentials
     reduce = energy_reduce if energy_reduce is not None else _mean_energy
     early_stopper = EarlyStopper(patience=early_stopper_patience)
     energy_potentials: List[float] = []

@@ -95,7 +95,7 @@ def _spectrum_worker(rank, world, port, out_dir):
         gram[3, 3] = torch.nextafter(gram[3, 3], torch.tensor(float("inf"), dtype=torch.float64))
     own = torch.linalg.eigh(gram)
     for canonical in (None, True):
-        lam, vec = S.shared_spectrum(gram, "cpu", canonical_signs=canonical)
+        lam, vec = S.shared_spectrum(gram, "cpu", canonical_signs=canonical, group=True)
         both = [torch.empty(41, 40, dtype=torch.float64) for _ in range(world)]
         dist.all_gather(both, torch.cat([lam[None, :], vec], dim=0))
         assert all(torch.equal(b, both[0]) for b in both), "ranks hold different spectra"
@@ -103,26 +103,44 @@ def _spectrum_worker(rank, world, port, out_dir):
             assert torch.equal(lam, own[0]) and torch.equal(vec, S.canonicalise_signs(own[1]) if canonical else own[1])
         # the same count on every rank at a threshold that sits ON an eigenvalue of rank 0's spectrum
         mk = int((lam > lam[7]).sum())
-        S.assert_same_count(mk)
-    # opt-out: a basis one rank builds on its own must not enter a collective
+        S.assert_same_count(mk, group=True)
+    # the default is the reference's behaviour: a local eigh, NO collective -- so a basis ONE rank builds on its own (a rank-0
+    # evaluation inside a running job) returns instead of waiting for peers that never come
+    if rank == 0:
+        lam_alone, vec_alone = S.shared_spectrum(gram, "cpu")
+        assert torch.equal(lam_alone, own[0]) and torch.equal(vec_alone, own[1])
+        S.assert_same_count(5)
     lam_own, vec_own = S.shared_spectrum(gram, "cpu", group=False)
     assert torch.equal(lam_own, own[0]) and torch.equal(vec_own, own[1])
     S.assert_same_count(rank, group=False)
     # ranks that disagree are told so (every rank raises: the reduction is symmetric)
     try:
-        S.assert_same_count(30 + rank)
+        S.assert_same_count(30 + rank, group=True)
         raise SystemExit("assert_same_count accepted different counts")
     except RuntimeError as e:
         assert "disagree" in str(e)
+    # ranks that were handed different matrices do not adopt rank 0's spectrum: other hyper-parameters ...
+    try:
+        S.shared_spectrum(gram * (1.0 + 0.01 * rank), "cpu", group=True)
+        raise SystemExit("shared_spectrum accepted different Gram matrices")
+    except RuntimeError as e:
+        assert "different k(Z,Z)" in str(e)
+    # ... or another number of inducing points (the broadcast would have hung on mismatched shapes)
+    try:
+        S.shared_spectrum(gram[: 40 - rank, : 40 - rank], "cpu", group=True)
+        raise SystemExit("shared_spectrum accepted different M")
+    except RuntimeError as e:
+        assert "different numbers of inducing points" in str(e)
     dist.barrier()
     dist.destroy_process_group()
     open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
 
 
 def test_one_spectrum_for_all_ranks(tmp_path):
-    """OrthonormalBasis under torch.distributed (basis/spectrum.py): rank 0 factorises k(Z,Z)/M and broadcasts, so a rank
-    whose eigh input differs by one ulp still ends with the same eigenvalues, eigenvectors and count, bit for bit
-    (reference: ONE process, ONE torch.linalg.eigh, orthonormal.py:46-68)."""
+    """OrthonormalBasis(group=True) under torch.distributed (basis/spectrum.py): rank 0 factorises k(Z,Z)/M and broadcasts,
+    so a rank whose eigh input differs by one ulp still ends with the same eigenvalues, eigenvectors and count, bit for bit
+    (reference: ONE process, ONE torch.linalg.eigh, orthonormal.py:46-68).  Sharing is opt-in: without ``group`` a rank
+    building alone does not hang, and ranks holding different matrices (or different M) are refused."""
     port = _free_port()
     mp.spawn(_spectrum_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(2))
@@ -145,8 +163,10 @@ def _subgroup_worker(rank, world, port, out_dir):
         want = torch.quantile(pred_full, torch.tensor(qs, dtype=torch.float64), dim=1).T
         got = D.sharded_row_quantiles(pred_full[:, j0:j1].contiguous(), qs, group=sub)
         assert torch.equal(got, want), rank
-        a = torch.randn(9, 9, generator=torch.Generator().manual_seed(3 + rank), dtype=torch.float64)  # different per rank
-        lam, vec = S.shared_spectrum(a @ a.T, "cpu", group=sub)
+        a = torch.randn(9, 9, generator=torch.Generator().manual_seed(3), dtype=torch.float64)
+        gram = a @ a.T
+        gram[2, 2] = gram[2, 2] * (1.0 + 1e-15 * rank)  # the same matrix up to rounding, different bits per rank
+        lam, vec = S.shared_spectrum(gram, "cpu", group=sub)
         both = [torch.empty(10, 9, dtype=torch.float64) for _ in range(2)]
         dist.all_gather(both, torch.cat([lam[None, :], vec], dim=0), group=sub)
         assert torch.equal(both[0], both[1])  # group rank 0 (global rank 1) decided

@@ -1428,7 +1428,7 @@ def test_prediction_vs_oracle(P):
 
 
 def test_device_normal_stream_of_the_predictive_sampler(P):
-    """samplers.DEFAULT_NORMAL_STREAM = "device" (the library default; this suite pins "reference"): the normals of the
+    """samplers.DEFAULT_NORMAL_STREAM = "device" (what "auto" resolves to for a J-sharded run): the normals of the
     predictive sampler come from libplship's generator on the GPU.  Same law as the reference's sampler -- mean and
     covariance of the draws against the analytic Q max(Lambda, 0) Q^T of an INDEFINITE covariance --, reproducible under
     set_seed, independent of how the particle columns are sharded over ranks (the host stream gives every rank seeded alike
@@ -2305,3 +2305,92 @@ def test_quantiles_beyond_one_lds_sort(P):
     got = _ops.row_quantiles(cu(bad), [0.5, 0.9]).cpu()
     assert torch.isnan(got[1]).all() and relerr(got[0], torch.quantile(s[0], torch.tensor([0.5, 0.9], dtype=s.dtype))) < 1e-14
     assert _ops.row_quantiles(cu(s[:, :16384].contiguous()), [0.5]).shape == (2, 1)
+
+
+def test_float32_callers_are_promoted_at_the_boundary(P):
+    """The reference's bases compute in whatever dtype the caller uses and its tests run in float32
+    (src/projected_langevin_sampling/basis/base.py:52-63, :99-102; README.md:254-265).  libplship computes in float64:
+    float32 inputs the library only reads are promoted on entry like x / z / y (kernel._dev) and results are float64; the
+    in-place entry points (PLS.step_, train_pls) run in float64 and write the rounded state back into the caller's tensor.
+    Anything else (integers) is refused with a TypeError that names the conversion."""
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float32)  # the README's loop as a float32 user would run it
+    try:
+        x = torch.linspace(-1, 1, 100)[:, None]
+        y = torch.sin(2 * math.pi * x[:, 0]) + 0.1 * torch.randn(100, generator=torch.Generator().manual_seed(0))
+        z = x[::10].clone()
+        assert x.dtype == torch.float32
+        kernel = P.pkg.PLSKernel(P.pkg.ARDKernel(torch.tensor([0.15]), 3.0), z)
+        basis = P.basis.OrthonormalBasis(kernel, z, x, verbose=False)
+        for cost in (P.costs.GaussianCost(0.5, y, P.links.IdentityLinkFunction()),
+                     P.costs.BernoulliCost((y > 0).float(), P.links.SigmoidLinkFunction())):
+            pls = P.pkg.PLS(basis, cost)
+            torch.manual_seed(0)
+            particles = pls.initialise_particles(number_of_particles=16, seed=0)
+            assert particles.dtype == torch.float64 and particles.is_cuda  # the library's own particles are float64
+            p32 = particles.float()  # ... a caller may hold them in float32 all the same
+            noise = torch.randn(particles.shape, generator=torch.Generator().manual_seed(1)).cuda()  # float32 injected noise
+            got = pls.calculate_particle_update(p32, 1e-3, noise=noise)
+            want = pls.calculate_particle_update(p32.double(), 1e-3, noise=noise.double())
+            assert got.dtype == torch.float64 and torch.equal(got, want)
+            e32, e64 = pls.calculate_energy_potential(p32), pls.calculate_energy_potential(p32.double())
+            assert e32 == e64
+            f = basis.calculate_untransformed_train_prediction_samples(p32)
+            assert f.dtype == torch.float64 and torch.equal(cost.calculate_cost(f.float()), cost.calculate_cost(f.float().double()))
+            # the reference's loop body on a float32 tensor (README.md:257-262): float32 += float64 update
+            loop32 = p32.clone()
+            for t in range(3):
+                loop32 += pls.calculate_particle_update(loop32, 1e-3, noise=noise)
+            assert loop32.dtype == torch.float32 and bool(torch.isfinite(loop32).all())
+            # in-place entry points: float64 arithmetic, the caller's float32 tensor mutated
+            s32, s64 = p32.clone(), p32.double()
+            assert pls.step_(s32, 1e-3, noise=noise) is s32
+            pls.step_(s64, 1e-3, noise=noise.double())
+            assert s32.dtype == torch.float32 and torch.equal(s32, s64.float())
+            t32, t64 = p32.clone(), p32.double()
+            noises = [torch.randn(particles.shape, generator=torch.Generator().manual_seed(2 + k), dtype=torch.float64).cuda()
+                      for k in range(5)]
+            out32, en32 = P.pkg.train_pls(pls, t32, 5, 1e-3, 1e9, noises=noises)
+            out64, en64 = P.pkg.train_pls(pls, t64, 5, 1e-3, 1e9, noises=noises)
+            assert out32 is t32 and t32.dtype == torch.float32 and torch.equal(t32, t64.float()) and en32 == en64
+        with pytest.raises(TypeError, match=r"\.double\(\)"):
+            pls.calculate_particle_update(torch.zeros(particles.shape, dtype=torch.int64, device="cuda"), 1e-3)
+        with pytest.raises(TypeError, match=r"float64"):  # a buffer the library writes is never promoted behind the caller's back
+            basis.fused_step(cost, particles, 1e-3, out=torch.empty(particles.shape, dtype=torch.float32, device="cuda"))
+    finally:
+        torch.set_default_dtype(prev)
+
+
+def test_the_shipped_normal_stream_is_the_references(P, G):
+    """samplers.DEFAULT_NORMAL_STREAM = "auto": an unsharded run draws the reference's host stream, sample for sample --
+    the pinned contract of the reference's tests/test_samplers.py:19-26 after set_seed(0) --, a J-sharded basis
+    (j_offset != 0) the device stream keyed by the global column, and PLS.sample_observation_noise forwards the shard's
+    offset so that every shard holds its own draws (the explicit-noise route of the reference's plotters)."""
+    from projected_langevin_sampling_amd import samplers
+    from projected_langevin_sampling_amd.utils import set_seed
+
+    assert samplers.DEFAULT_NORMAL_STREAM == "auto"
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float32)
+    try:
+        set_seed(0)
+        got = samplers.sample_multivariate_normal(torch.zeros(2), torch.eye(2), size=(2,), seed=0).cpu()
+        assert torch.allclose(got, torch.tensor([[1.5410, -2.1788], [-0.2934, 0.5684]], dtype=torch.float64), atol=1e-4)
+    finally:
+        torch.set_default_dtype(prev)
+    assert samplers.resolve_normal_stream(None) == "reference" and samplers.resolve_normal_stream(None, j_offset=64) == "device"
+    assert samplers.resolve_normal_stream("device") == "device"
+    pr = make_problem(120, 8, 24, 2, seed=3)
+    _, gb = build_onb(P, pr)
+    cost = P.costs.GaussianCost(0.3, pr["y"], P.links.IdentityLinkFunction())
+    pls = P.pkg.PLS(gb, cost)
+    full = cost.sample_observation_noise(24, seed=9, normal_stream="device")
+    gb.j_offset = 10
+    try:
+        shard = pls.sample_observation_noise(14, seed=9)  # (auto -> device: the basis is a shard)
+    finally:
+        gb.j_offset = 0
+    assert torch.equal(shard, full[10:24])
+    host = pls.sample_observation_noise(24, seed=9)  # unsharded: the reference's stream
+    want = torch.normal(mean=0.0, std=cost.observation_noise, size=(24,), generator=torch.Generator().manual_seed(9))
+    assert torch.allclose(host.cpu(), want.double(), rtol=1e-12)

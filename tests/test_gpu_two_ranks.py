@@ -73,7 +73,7 @@ def _worker(rank, world, port, out_dir):
     from projected_langevin_sampling_amd import distributed as D
 
     samplers.DEFAULT_NORMAL_STREAM = "device"
-    pkg, basis, cost, xs, j = _build("cuda")  # collective: rank 0 factorises, everybody receives the same bits
+    pkg, basis, cost, xs, j = _build("cuda", group=True)  # collective (opt-in): rank 0 factorises, everybody receives the same bits
     mk = basis.approximation_dimension
     j0, j1 = D.attach_shard(basis, j, rank, world)
     u0 = torch.randn(mk, j, generator=torch.Generator().manual_seed(5), dtype=torch.float64)
@@ -89,7 +89,7 @@ def _worker(rank, world, port, out_dir):
     path = os.path.join(out_dir, f"rank{rank}.pth")
     mid = _steps(basis, cost, u0[:, j0:j1].contiguous().cuda(), 0, 3)
     checkpoint.save_pls(pls, mid, path, noise_step=3, number_of_particles=j)
-    pkg2, basis2, cost2, _, _ = _build("cuda")
+    pkg2, basis2, cost2, _, _ = _build("cuda", group=True)
     D.attach_shard(basis2, j, rank, world)
     _, restored, _, _ = checkpoint.load_pls(pkg2.PLS(basis2, cost2), path)
     resumed = _steps(basis2, cost2, restored, 3, 3)

@@ -392,3 +392,58 @@ def test_sign_canonicalisation_and_spectrum_fingerprint(tmp_path, monkeypatch):
     checkpoint.save_pls(NoGauge(), u, path)
     assert "spectrum_fingerprint" not in torch.load(path)
     checkpoint.load_pls(other, path)  # ... and a file without one (the reference's own) loads into any basis
+
+
+def test_normal_stream_resolution_and_shard_offset_forwarding():
+    """samplers.resolve_normal_stream: the shipped default ("auto") is the reference's host stream for an unsharded run -- the
+    pinned contract of the reference's tests/test_samplers.py:19-26 -- and the device stream as soon as the run is J-sharded;
+    PLS.sample_observation_noise hands the shard's column offset to a native cost (costs/base.py:86-115 has no such
+    argument: a user-defined cost is called with the reference's signature)."""
+    from projected_langevin_sampling_amd import samplers
+
+    assert samplers.DEFAULT_NORMAL_STREAM == "auto"
+    assert samplers.resolve_normal_stream(None) == "reference"
+    assert samplers.resolve_normal_stream(None, j_offset=128) == "device"
+    assert samplers.resolve_normal_stream("reference", j_offset=128) == "reference"  # an explicit request wins
+    assert samplers.resolve_normal_stream("device") == "device"
+    with pytest.raises(AssertionError):
+        samplers.resolve_normal_stream("philox")
+
+    calls = []
+
+    class Basis:
+        j_offset = 0
+
+    class NativeCost:
+        observation_noise = 0.1
+
+        def is_native(self):
+            return True
+
+        def sample_observation_noise(self, number_of_particles, seed=None, j_offset=0):
+            calls.append(("native", number_of_particles, seed, j_offset))
+
+    class UserCost:
+        observation_noise = 0.1
+
+        def sample_observation_noise(self, number_of_particles, seed=None):  # the reference's signature
+            calls.append(("user", number_of_particles, seed))
+
+    b = Basis()
+    pkg.PLS(b, NativeCost()).sample_observation_noise(7, seed=3)
+    b.j_offset = 40
+    pkg.PLS(b, NativeCost()).sample_observation_noise(7, seed=3)
+    pkg.PLS(b, UserCost()).sample_observation_noise(7, seed=3)
+    assert calls == [("native", 7, 3, 0), ("native", 7, 3, 40), ("user", 7, 3)]
+
+
+def test_boundary_dtypes_without_a_gpu():
+    """_lib.require_gpu_tensor: host tensors are refused whatever their dtype (no CPU fallback); the TypeError for a wrong
+    dtype names the conversion (exercised on the GPU in tests/test_gpu_parity.py)."""
+    from projected_langevin_sampling_amd import _lib as L
+
+    with pytest.raises(L.PlsHipError, match="no CPU fallback"):
+        L.require_gpu_tensor(torch.zeros(2, dtype=torch.float32), "particles", promote=True)
+    with pytest.raises(TypeError):
+        L.require_gpu_tensor([1.0], "particles")
+    assert torch.float32 in L.PROMOTED_DTYPES and torch.float64 not in L.PROMOTED_DTYPES
