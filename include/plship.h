@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PLSHIP_ABI_VERSION 4
+#define PLSHIP_ABI_VERSION 5
 
 typedef enum {
   PLS_OK = 0,
@@ -249,6 +249,20 @@ typedef struct {
   double *energy_sums_prev;
   int32_t energy_flush;
   int32_t reserved;
+  /* Optional (ABI 5), orthonormal basis with at most 128 functions and a cost without the Gaussian algebra, problems in the
+   * launch-bound regime (the sizes of the reference's own experiments: N, J in the hundreds to thousands): the whole
+   * step -- projection, cost derivative, back-projection, the fixed-order sum over the row slabs, prior drift, noise, and with
+   * energy_in the energies of the input particles and their energy_sums -- is ONE launch (csrc/small_rank_step.h; option
+   * PLS_OPT_SMALL_RANK_STEP).  Its workgroups meet through pls_step_sync_words(j) 32-bit counters: handed in here they must
+   * be ZERO when first handed in and every call leaves them zero (calls that may run concurrently need different
+   * counters); NULL: the launch is preceded by a memset node over counters carved from the workspace. */
+  uint32_t *step_sync;
+  /* Optional output (ABI 5), steps with energy_in != NULL only: cdiv(j, 16) doubles, entry b = the sum of the per-particle
+   * energies of columns [16 b, 16 (b + 1)) added in ascending column order.  The one-launch step writes them for free (the
+   * workgroup that finishes a column block holds its sixteen energies), where energy_sums costs it a second hand-over
+   * between workgroups; every other route appends one small launch.  A training loop adds the entries in ascending order
+   * on the host.  May point to pinned host memory mapped into the device.  NULL: not written. */
+  double *energy_sums16;
 } pls_block_desc;
 
 const char *pls_last_error(void);
@@ -290,7 +304,12 @@ typedef enum pls_option {
   PLS_OPT_ENERGY_FUSED_FINISH = 11,
   /* 1 (default): the k-split kernel of narrow particle shards draws the Philox noise of its output block in front of its
    * k-loop, while the first operand rows travel; 0: in the epilogue, like the other tilings.  Same bits either way. */
-  PLS_OPT_KG_NOISE_PREGEN = 12
+  PLS_OPT_KG_NOISE_PREGEN = 12,
+  /* Steps of the orthonormal basis with at most 128 functions and a cost without the Gaussian algebra: 1 (default) = ONE
+   * launch (csrc/small_rank_step.h) while the problem is launch-bound (at most 4096 particles and 8 GFLOP per step), the
+   * slab kernels of csrc/small_rank.h + update launch beyond; 0 = never; 2 = wherever the kernel applies (A/B runs, tests).
+   * Results agree to rounding (another summation order over the data rows), not bit for bit. */
+  PLS_OPT_SMALL_RANK_STEP = 13
 } pls_option;
 /* Diagnostic: out[i] = op(x[i]) with the device exp (op 0) / log (op 1) the per-element kernels use (csrc/fmath.h), or
  * out[i] = x[i] / x[n + i] with their division (op 2: fast_div, IEEE special cases restored; op 3: fast_div_normal), so
@@ -313,7 +332,8 @@ typedef enum {
   PLS_TAG_OTHER = 7,
   PLS_TAG_SMALL_RANK_DRIFT = 8,      /* small_rank_kernel: F, d cost / d f and the back-projection in one pass (rank <= 128) */
   PLS_TAG_SMALL_RANK_VALUE = 9,      /* small_rank_kernel: F and the per-column cost sums in one pass */
-  PLS_TAG_TRI_SOLVE = 10             /* tri_solve_strip_kernel: V = Lc^-T Lc^-1 U, forward + backward substitution in one launch */
+  PLS_TAG_TRI_SOLVE = 10,            /* tri_solve_strip_kernel: V = Lc^-T Lc^-1 U, forward + backward substitution in one launch */
+  PLS_TAG_SMALL_RANK_STEP = 11       /* small_rank_step_kernel: the whole step (and its energies) of a small-rank basis in one launch */
 } pls_kernel_tag;
 int pls_timeline_begin(int32_t capacity);
 int pls_timeline_end(float *ms, int32_t *tags, int32_t capacity, int32_t *count);
@@ -477,6 +497,10 @@ int pls_onb_step(const pls_onb_desc *basis, const pls_cost_desc *cost, const dou
                  int64_t j, double eta, const pls_noise_desc *noise, double *out, int64_t ldo, int32_t out_mode,
                  int32_t force_generic, double *energy_in, void *workspace, size_t workspace_bytes, void *stream);
 
+/* out[b] = the sum of e[16 b .. min(j, 16 (b + 1))) in ascending order (pls_block_desc.energy_sums16 as a stand-alone launch). */
+int pls_sums16(const double *e, int64_t j, double *out, void *stream);
+/* Number of 32-bit counters behind pls_block_desc.step_sync for j particle columns. */
+size_t pls_step_sync_words(int64_t j);
 /* Bytes of pls_block_desc.energy_partials for a basis with `rows` functions (Mk, or M of the inducing-point basis) and j
  * particle columns. */
 size_t pls_energy_partials_bytes(int64_t rows, int64_t j);

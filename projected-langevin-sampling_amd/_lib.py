@@ -120,7 +120,8 @@ class CholDesc(C.Structure):
 class BlockDesc(C.Structure):
     _fields_ = [("block_cols", C.c_int64), ("eta", C.c_void_p), ("energy_sums", C.c_void_p), ("energy_sync", C.c_void_p),
                 ("energy_partials", C.c_void_p), ("energy_partials_prev", C.c_void_p), ("energy_prev", C.c_void_p),
-                ("energy_sums_prev", C.c_void_p), ("energy_flush", C.c_int32), ("reserved", C.c_int32)]
+                ("energy_sums_prev", C.c_void_p), ("energy_flush", C.c_int32), ("reserved", C.c_int32), ("step_sync", C.c_void_p),
+                ("energy_sums16", C.c_void_p)]
 
 
 _P, _I64, _I32, _U64, _D, _SZ = C.c_void_p, C.c_int64, C.c_int32, C.c_uint64, C.c_double, C.c_size_t
@@ -146,6 +147,8 @@ SIGNATURES = {
     "pls_row_quantiles": (C.c_int, [_P, _I64, _I64, _I64, _P, _I32, _P, _I64, _P]),
     "pls_counter_add": (C.c_int, [_P, _U64, _P]),
     "pls_normal_fill": (C.c_int, [_P, _I64, _I64, _I64, _U64, _U64, _I64, _P]),
+    "pls_step_sync_words": (_SZ, [_I64]),
+    "pls_sums16": (C.c_int, [_P, _I64, _P, _P]),
     "pls_onb_build_projection": (C.c_int, [_P, _I64, _P, _I64, _I64, _I64, _I64, _P, _I64, _P, _I64, _P]),
     "pls_onb_build_gaussian": (C.c_int, [_OD, _P, _P, _I64, _P, _P]),
     "pls_onb_forward": (C.c_int, [_OD, _P, _I64, _I64, _P, _I64, _P]),
@@ -190,7 +193,7 @@ SIGNATURES = {
     "pls_ipb_step_blocks": (C.c_int, [_ID, _CD, _P, _P, _I64, _I64, _BD, _ND, _P, _I64, _I32, _I32, _P, _P, _SZ, _P]),
 }
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib = None
 
@@ -226,9 +229,10 @@ OPT_TRI_BALANCE = 9
 OPT_IPB_STEP_OPERATOR = 10
 OPT_ENERGY_FUSED_FINISH = 11
 OPT_KG_NOISE_PREGEN = 12
+OPT_SMALL_RANK_STEP = 13
 TAG_NAMES = {1: "gemm_store", 2: "gemm_cost_deriv", 3: "gemm_cost_value", 4: "gemm_langevin_gaussian",
              5: "langevin_update", 6: "kernel_gram", 7: "other", 8: "small_rank_drift", 9: "small_rank_value",
-             10: "tri_solve"}
+             10: "tri_solve", 11: "small_rank_step"}
 
 
 class Timeline:

@@ -53,7 +53,8 @@ class BlockSpec:
     def __init__(self, block_cols: int, eta: torch.Tensor, energy_sums: int | None = None,
                  energy_sync: torch.Tensor | None = None, energy_partials: torch.Tensor | None = None,
                  energy_partials_prev: torch.Tensor | None = None, energy_prev: torch.Tensor | None = None,
-                 energy_sums_prev: int | None = None, energy_flush: bool = False):
+                 energy_sums_prev: int | None = None, energy_flush: bool = False, step_sync: torch.Tensor | None = None,
+                 energy_sums16: int | None = None):
         """``energy_sums`` (optional): raw address (device, or pinned host memory) of cdiv(J, 256) doubles that receive the
         256-column chunk sums of the per-particle energies from the launch that finishes the step's energy by-product
         (Gaussian/identity fast paths; see pls_block_desc)."""
@@ -76,6 +77,14 @@ class BlockSpec:
                 assert t.is_contiguous()
         self.energy_partials, self.energy_partials_prev, self.energy_prev = energy_partials, energy_partials_prev, energy_prev
         self.energy_sums_prev, self.energy_flush = energy_sums_prev, bool(energy_flush)
+        #: optional: device int32 counters (pls_step_sync_words(J) of them), zeroed once by the owner: the one-launch small-rank
+        #: step (pls_block_desc.step_sync) meets through them and leaves them zero
+        if step_sync is not None:
+            assert step_sync.device.type == "cuda" and step_sync.dtype == torch.int32 and step_sync.is_contiguous()
+        self.step_sync = step_sync
+        #: optional: raw address (device, or pinned host memory) of cdiv(J, 16) doubles that receive the sums of the energies over
+        #: each block of 16 columns (pls_block_desc.energy_sums16)
+        self.energy_sums16 = energy_sums16
 
     def desc(self) -> L.BlockDesc:
         d = L.BlockDesc()
@@ -87,6 +96,8 @@ class BlockSpec:
         d.energy_prev = None if self.energy_prev is None else self.energy_prev.data_ptr()
         d.energy_sums_prev = self.energy_sums_prev
         d.energy_flush = 1 if self.energy_flush else 0
+        d.step_sync = None if self.step_sync is None else self.step_sync.data_ptr()
+        d.energy_sums16 = self.energy_sums16
         return d
 
 

@@ -250,11 +250,57 @@ class OrthonormalBasis(PLSBasis):
         derivative is taken of (the reference recomputes F for the energy: projected_langevin_sampling.py:125-138)."""
         return bool(cost.is_native())
 
+    #: ranks up to which a cost without the Gaussian algebra takes the small-rank kernels (csrc/small_rank.h, small_rank_step.h)
+    SMALL_RANK_MAX = 128
+
     def supports_energy_sums(self, cost) -> bool:
         """True if the launch that finishes the step's energy by-product can also leave the 256-column chunk sums of the
-        energies (BlockSpec.energy_sums): the Gaussian/identity fast path."""
+        energies (BlockSpec.energy_sums): the Gaussian/identity fast path, and every native cost on a basis of at most 128
+        functions -- the one-launch small-rank step (pls_block_desc.step_sync) writes them itself, its fall-back for large
+        problems appends pls_chunk_sums."""
         cd = cost.desc() if cost.is_native() else None
-        return cd is not None and cd.cost == L.COST_GAUSSIAN and cd.link == L.LINK_IDENTITY
+        if cd is None:
+            return False
+        return (cd.cost == L.COST_GAUSSIAN and cd.link == L.LINK_IDENTITY) or self._one_launch_rank(cd)
+
+    def uses_sums16(self, cost) -> bool:
+        """True if a training loop should ask for the 16-column sums of the energies (BlockSpec.energy_sums16) instead of the
+        256-column chunk sums: the costs whose step is the one-launch small-rank kernel."""
+        return bool(cost.is_native()) and self._one_launch_rank(cost.desc())
+
+    def _one_launch_rank(self, cd) -> bool:
+        gaussian = cd.cost == L.COST_GAUSSIAN and cd.link == L.LINK_IDENTITY
+        return (not gaussian) and 1 <= self.approximation_dimension <= self.SMALL_RANK_MAX
+
+    def _step_sync(self, j: int, device) -> torch.Tensor:
+        """The zeroed arrival counters of the one-launch small-rank step (pls_block_desc.step_sync) for eager calls: one set per
+        stream (launches on one stream are ordered; two streams must not share counters), grown on demand.  A launch leaves
+        them zero; after a FAILED launch they are dropped (zero_step_sync) -- stale counts would make every later step wrong."""
+        words = int(L.load().pls_step_sync_words(j))
+        key = (str(device), L.stream_ptr())
+        pool = self.__dict__.setdefault("_sync_pool", {})
+        t = pool.get(key)
+        if t is None or t.numel() < words:
+            t = torch.zeros(max(words, 64), dtype=torch.int32, device=device)
+            pool[key] = t
+        return t
+
+    def zero_step_sync(self) -> None:
+        """Forget every counter set (after a failed or aborted launch): the next step allocates zeroed ones."""
+        self.__dict__.pop("_sync_pool", None)
+
+    def _eta_word(self, step_size: float, device) -> torch.Tensor:
+        """``step_size`` as a device word (pls_block_desc.eta), remembered per value: an eager caller steps with the same size
+        thousands of times, and a host -> device copy per call would cost more than the step."""
+        words = self.__dict__.setdefault("_eta_words", {})
+        key = (float(step_size), str(device))
+        t = words.get(key)
+        if t is None:
+            if len(words) >= 64:
+                words.clear()
+            t = torch.full((1,), float(step_size), dtype=torch.float64, device=device)
+            words[key] = t
+        return t
 
     def step_workspace_bytes(self, cost, j: int, with_energy: bool, force_generic: bool = False) -> int:
         """Bytes fused_step asks of its workspace for ``j`` columns (graph captures allocate their own buffer)."""
@@ -308,19 +354,32 @@ class OrthonormalBasis(PLSBasis):
             ws = self._pick_workspace(workspace, ws_bytes, u.device)
         nd = (noise if noise is not None else self._draw_noise_spec(None)).desc()
         mode = L.OUT_NEW_STATE if new_state else L.OUT_DELTA
-        if blocks is None:
-            L.check(
-                lib.pls_onb_step(desc, cd, y.data_ptr(), u.data_ptr(), L.ld(u), j, float(step_size), nd, out.data_ptr(), L.ld(out),
-                                 mode, 1 if force_generic else 0, L.ptr(input_energy), L.ptr(ws), ws_bytes, L.stream_ptr()),
-                "pls_onb_step",
-            )
-        else:
-            L.check(
-                lib.pls_onb_step_blocks(desc, cd, y.data_ptr(), u.data_ptr(), L.ld(u), j, blocks.desc(), nd, out.data_ptr(),
-                                        L.ld(out), mode, 1 if force_generic else 0, L.ptr(input_energy), L.ptr(ws), ws_bytes,
-                                        L.stream_ptr()),
-                "pls_onb_step_blocks",
-            )
+        bd = None if blocks is None else blocks.desc()
+        if not gaussian and 1 <= self.approximation_dimension <= self.SMALL_RANK_MAX:
+            # the one-launch small-rank step meets through zeroed counters: the basis' own (per stream) unless the caller's
+            # BlockSpec brings some -- without them the library puts a memset node in front of every launch
+            if bd is None:
+                bd = L.BlockDesc()
+                bd.block_cols, bd.eta = j, self._eta_word(step_size, u.device).data_ptr()
+            if not bd.step_sync:
+                bd.step_sync = self._step_sync(j, u.device).data_ptr()
+        try:
+            if bd is None:
+                L.check(
+                    lib.pls_onb_step(desc, cd, y.data_ptr(), u.data_ptr(), L.ld(u), j, float(step_size), nd, out.data_ptr(), L.ld(out),
+                                     mode, 1 if force_generic else 0, L.ptr(input_energy), L.ptr(ws), ws_bytes, L.stream_ptr()),
+                    "pls_onb_step",
+                )
+            else:
+                L.check(
+                    lib.pls_onb_step_blocks(desc, cd, y.data_ptr(), u.data_ptr(), L.ld(u), j, bd, nd, out.data_ptr(),
+                                            L.ld(out), mode, 1 if force_generic else 0, L.ptr(input_energy), L.ptr(ws), ws_bytes,
+                                            L.stream_ptr()),
+                    "pls_onb_step_blocks",
+                )
+        except L.PlsHipError:
+            self.zero_step_sync()
+            raise
         return out
 
     #: fused_step itself takes BlockSpec.energy_partials (the inducing-point basis only in whitened_step)
@@ -329,7 +388,8 @@ class OrthonormalBasis(PLSBasis):
     def supports_lagged_energies(self, cost) -> bool:
         """True if a training loop may let launch k + 1 finish the energies of launch k (BlockSpec.energy_partials ...): the
         Gaussian/identity fast path."""
-        return self.supports_energy_sums(cost)
+        cd = cost.desc() if cost.is_native() else None
+        return cd is not None and cd.cost == L.COST_GAUSSIAN and cd.link == L.LINK_IDENTITY
 
     def energy_partial_rows_bytes(self, j: int) -> int:
         return int(L.load().pls_energy_partials_bytes(self.approximation_dimension, j))
@@ -361,6 +421,43 @@ class OrthonormalBasis(PLSBasis):
                 L.check(rc, "pls_onb_step_blocks")
 
         launch.keep_alive = (desc, cd, y, eta, self)
+        return launch
+
+    def sums_step_launcher(self, cost, state: torch.Tensor, eta: torch.Tensor):
+        """The step of a training loop for a cost WITHOUT the Gaussian algebra on a basis of at most 128 functions, as a
+        PRE-BOUND call (see lagged_step_launcher for why): pls_onb_step_blocks with the energies of the input particles and their
+        16-column sums (BlockSpec.energy_sums16, straight into the caller's pinned slot) -- ONE launch per iteration in the
+        launch-bound regime (csrc/small_rank_step.h; the loop owns the counters and the workspace this binds), the slab
+        kernels + pls_sums16 beyond.  None for other bases / costs.
+        launch(u_ptr, ldu, out_ptr, ldo, seed, energy_ptr, sums_ptr)"""
+        cd = cost.desc()
+        if not self._one_launch_rank(cd):
+            return None
+        u = _rows_contiguous(L.require_gpu_tensor(state, "particles"))
+        j = u.shape[1]
+        y = cost.y_device()
+        lib = L.load()
+        desc = self._desc()
+        need_min = lib.pls_onb_step_workspace_bytes(desc, j, 128)
+        need_full = lib.pls_onb_step_workspace_bytes(desc, j, self._n)
+        ws_bytes = max(need_min, min(need_full, self.workspace_bytes))
+        ws = torch.empty((ws_bytes + 7) // 8, dtype=torch.float64, device=u.device)
+        sync = torch.zeros(max(int(lib.pls_step_sync_words(j)), 1), dtype=torch.int32, device=u.device)
+        blocks, nd = L.BlockDesc(), L.NoiseDesc()
+        blocks.block_cols, blocks.eta = j, L.require_gpu_tensor(eta, "eta").data_ptr()
+        blocks.step_sync = sync.data_ptr()
+        nd.kind, nd.step, nd.j_offset = L.NOISE_PHILOX, 0, int(self.j_offset)
+        fn = lib.pls_onb_step_blocks
+        y_ptr, ws_ptr, stream, mode = y.data_ptr(), ws.data_ptr(), L.stream_ptr(), L.OUT_NEW_STATE
+
+        def launch(u_ptr, ldu, out_ptr, ldo, seed, energy_ptr, sums_ptr):
+            nd.seed = seed
+            blocks.energy_sums16 = sums_ptr
+            rc = fn(desc, cd, y_ptr, u_ptr, ldu, j, blocks, nd, out_ptr, ldo, mode, 0, energy_ptr, ws_ptr, ws_bytes, stream)
+            if rc:
+                L.check(rc, "pls_onb_step_blocks")
+
+        launch.keep_alive = (desc, cd, y, ws, sync, eta, self)
         return launch
 
     def step_launcher(self, cost, state: torch.Tensor, step_size: float):

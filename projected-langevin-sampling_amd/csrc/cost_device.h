@@ -43,7 +43,11 @@ __host__ inline CostP make_costp(const pls_cost_desc *d) {
 __device__ inline double clipd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
 
 // link_functions.py:30-80.  *slope receives d link / d f as torch autograd sees it (0 outside the clip).
+// (No floating-point contraction in link_eval / cost_value / cost_deriv: a kernel that evaluates value AND derivative shares
+// their common subexpressions, and whether `a * b + c` becomes one fma depends on how many uses the product has -- left to the
+// compiler, asking a step for the energy of its input could move the step by an ulp.)
 __device__ inline double link_eval(int link, double f, double jit, double *slope) {
+#pragma clang fp contract(off)
   switch (link) {
     case PLS_LINK_IDENTITY:  // :54-55
       *slope = 1.0;
@@ -70,6 +74,7 @@ __device__ inline double link_eval(int link, double f, double jit, double *slope
 
 // cost(y, f) for one (n, j) entry; summed over n by the callers.
 __device__ inline double cost_value(const CostP &c, double y, double f) {
+#pragma clang fp contract(off)
   double slope;
   double p = link_eval(c.link, f, c.jitter, &slope);
   switch (c.cost) {
@@ -83,8 +88,14 @@ __device__ inline double cost_value(const CostP &c, double y, double f) {
       // binary labels (the usual case) need ONE logarithm; the other term of the general formula is +-0 * finite
       // (p is clipped away from 0 and 1), so these returns are bit-identical to it.  In the row-walking epilogues y
       // is uniform across the wave, so the branch really skips the second log.
-      if (y == 1.0) return -fast_log(p);
-      if (y == 0.0) return -fast_log(1.0 - p);
+      // (one select, ONE logarithm for any mix of the two labels among the lanes of a wave: in the fused small-rank kernels
+      // a register holds four different data rows, and `if (y == 1) ... if (y == 0) ...` evaluated both logarithms whenever
+      // the four rows did not carry the same label)
+      // (with a positive jitter p and 1 - p lie in [jitter, 1 - jitter]: the logarithm without its three special cases)
+      if (y == 1.0 || y == 0.0) {
+        const double a = (y == 1.0) ? p : 1.0 - p;
+        return (c.jitter > 0.0 && c.jitter < 0.5) ? -fast_log_unit(a) : -fast_log(a);
+      }
       return -fast_log(p) * y - fast_log(1.0 - p) * (1.0 - y);
     case PLS_COST_STUDENT_T: {  // student_t.py:57-72, p0 = dof, p1 = scale
       double e = p - y;
@@ -102,6 +113,7 @@ __device__ inline double cost_value(const CostP &c, double y, double f) {
 
 // d cost / d f for one entry.
 __device__ inline double cost_deriv(const CostP &c, double y, double f) {
+#pragma clang fp contract(off)
   double slope;
   double p = link_eval(c.link, f, c.jitter, &slope);
   const bool ref = (c.mode == PLS_DERIV_REFERENCE);

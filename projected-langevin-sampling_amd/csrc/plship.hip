@@ -24,6 +24,9 @@
 #include "philox.h"
 #include "small_rank.h"
 #include "small_rank_launch.h"
+#include "small_rank_step.h"
+#include "small_rank_step_launch.h"
+#include "step_params.h"
 
 namespace plship {
 
@@ -84,57 +87,6 @@ struct EpiGaussianQuad {
     }
   }
 };
-
-struct NoiseP {
-  int kind;
-  const double *xi;
-  int64_t ldxi;
-  uint64_t seed, step;
-  int64_t j_offset;
-  const uint64_t *step_base;  // optional device counter added to `step` at run time (graph replays)
-  int64_t block_cols;         // > 0: the columns are blocks of independent runs (pls_block_desc); Philox column = column inside the block
-  __device__ uint64_t live_step() const { return step_base ? step + *step_base : step; }
-  __device__ int64_t global_column(int64_t col) const { return j_offset + (block_cols > 0 ? col % block_cols : col); }
-};
-
-// step size of a column: one scalar, or one per column block (pls_block_desc; the batched step-size search)
-struct EtaP {
-  double eta;
-  const double *blocks;  // device array, NULL = the scalar
-  int64_t block_cols;
-  __device__ double at(int64_t col) const { return blocks ? blocks[col / block_cols] : eta; }
-};
-
-static EtaP make_etap(double eta, const pls_block_desc *b) {
-  EtaP e{eta, nullptr, 0};
-  if (b) {
-    e.blocks = b->eta;
-    e.block_cols = b->block_cols;
-  }
-  return e;
-}
-
-static NoiseP make_noisep(const pls_noise_desc *n, const pls_block_desc *blocks = nullptr) {
-  NoiseP p;
-  p.block_cols = blocks ? blocks->block_cols : 0;
-  if (!n) {
-    p.kind = PLS_NOISE_NONE;
-    p.xi = nullptr;
-    p.ldxi = 0;
-    p.seed = p.step = 0;
-    p.j_offset = 0;
-    p.step_base = nullptr;
-    return p;
-  }
-  p.kind = n->kind;
-  p.xi = n->xi;
-  p.ldxi = n->ldxi;
-  p.seed = n->seed;
-  p.step = n->step;
-  p.j_offset = n->j_offset;
-  p.step_base = n->step_base;
-  return p;
-}
 
 // Gaussian/identity fast path: acc = (B U)_ij;  out = [U +] -eta*(acc - c_i)/sigma2 - eta*U_ij/lam_i + sqrt(2 eta)*xi_ij
 struct EpiLangevinGaussian {
@@ -1491,6 +1443,7 @@ static std::atomic<int64_t> g_ipb_explicit_inverse{0};  // pls_set_option(PLS_OP
 static std::atomic<int64_t> g_kg_noise_pregen{1};      // pls_set_option(PLS_OPT_KG_NOISE_PREGEN): Philox noise in front of the k-split kernel's k-loop
 static std::atomic<int64_t> g_energy_fused_finish{1};   // pls_set_option(PLS_OPT_ENERGY_FUSED_FINISH): honour pls_block_desc.energy_sync
 static std::atomic<int64_t> g_ipb_step_operator{1};     // pls_set_option(PLS_OPT_IPB_STEP_OPERATOR): 1 = Pt route when the descriptor has it
+static std::atomic<int64_t> g_small_rank_step{1};  // pls_set_option(PLS_OPT_SMALL_RANK_STEP): 0 never, 1 launch-bound problems, 2 wherever it applies
 static std::atomic<int64_t> g_solve_mode{1};  // pls_set_option(PLS_OPT_SOLVE_MODE): 0 block substitution, 1 inverse-factor products where available
 int64_t solve_mode() { return g_solve_mode.load(); }
 
@@ -1680,6 +1633,16 @@ __global__ __launch_bounds__(256) void chunk_sums_kernel(const double *__restric
   if (threadIdx.x == 0) out[blockIdx.x] = t;
 }
 
+// out[b] = e[16 b] + e[16 b + 1] + ... (ascending) over the columns of block b that exist
+__global__ __launch_bounds__(256) void sums16_kernel(const double *__restrict__ e, int64_t j, double *out) {
+  const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (b * 16 >= j) return;
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) s += (b * 16 + k < j) ? e[b * 16 + k] : 0.0;
+  out[b] = s;
+}
+
 }  // namespace plship
 
 using namespace plship;
@@ -1803,6 +1766,8 @@ int pls_abi_version(void) { return PLSHIP_ABI_VERSION; }
 
 size_t pls_tri_scratch_bytes(int64_t m, int64_t j) { return (m > 0 && j > 0) ? kg_tri_scratch_bytes(m, j) : 0; }
 
+size_t pls_step_sync_words(int64_t j) { return j > 0 ? small_rank_step_sync_words(j) : 0; }
+
 size_t pls_energy_partials_bytes(int64_t rows, int64_t j) {
   return (rows > 0 && j > 0) ? (size_t)(2 * cdiv(rows, 128)) * j * sizeof(double) : 0;
 }
@@ -1849,6 +1814,10 @@ int pls_set_option(int32_t option, int64_t value) {
       PLS_REQUIRE(value == 0 || value == 1, "set_option: noise pre-generation must be 0 or 1");
       g_kg_noise_pregen.store(value);
       return PLS_OK;
+    case PLS_OPT_SMALL_RANK_STEP:
+      PLS_REQUIRE(value >= 0 && value <= 2, "set_option: small-rank step mode must be 0 (never), 1 (launch-bound) or 2 (always)");
+      g_small_rank_step.store(value);
+      return PLS_OK;
     default: return fail(PLS_ERR_INVALID_ARGUMENT, "set_option: unknown option %d", (int)option);
   }
 }
@@ -1873,6 +1842,7 @@ int64_t pls_get_option(int32_t option) {
     case PLS_OPT_IPB_STEP_OPERATOR: return g_ipb_step_operator.load();
     case PLS_OPT_ENERGY_FUSED_FINISH: return g_energy_fused_finish.load();
     case PLS_OPT_KG_NOISE_PREGEN: return g_kg_noise_pregen.load();
+    case PLS_OPT_SMALL_RANK_STEP: return g_small_rank_step.load();
     default: return -1;
   }
 }
@@ -1957,6 +1927,13 @@ int pls_block_means(const double *e, int64_t j, int64_t block_cols, double *out,
   PLS_REQUIRE(cdiv(j, block_cols) <= 0x7fffffff, "block_means: too many blocks");
   hipLaunchKernelGGL(block_means_kernel, dim3((unsigned)cdiv(j, block_cols)), dim3(256), 0, S(stream), e, j, block_cols, out);
   return check_launch("block_means");
+}
+
+int pls_sums16(const double *e, int64_t j, double *out, void *stream) {
+  PLS_REQUIRE(e && out && j >= 0, "sums16: bad arguments");
+  if (j == 0) return PLS_OK;
+  hipLaunchKernelGGL(sums16_kernel, dim3((unsigned)cdiv(cdiv(j, 16), 256)), dim3(256), 0, S(stream), e, j, out);
+  return check_launch("sums16");
 }
 
 int pls_chunk_sums(const double *e, int64_t j, double *out, void *stream) {
@@ -2167,21 +2144,114 @@ static int64_t onb_pick_chunk(int64_t n, size_t left, int64_t j, int64_t min_row
   return c < min_rows ? min_rows : c;
 }
 
+// workspace of the one-launch small-rank step: the slabs' partial drifts and cost sums, then (callers that hand in no
+// pls_block_desc.step_sync) the arrival counters
+static size_t sr_step_workspace_bytes(int64_t mk, int64_t j, int64_t n) {
+  if (mk < 1 || mk > 128) return 0;
+  return align_up(small_rank_step_slab_bytes(j, n, (int)mk), 256) + align_up(small_rank_step_sync_words(j) * sizeof(uint32_t), 256);
+}
+
 size_t pls_onb_step_workspace_bytes(const pls_onb_desc *basis, int64_t j, int64_t n_chunk) {
   if (!basis || j <= 0) return 0;
   if (n_chunk <= 0 || n_chunk > basis->n) n_chunk = basis->n;
   // D slabs (split-K of the back-projection, each mk x j) + cost partial rows of the energy by-product + G chunk
-  return (size_t)onb_max_slabs(basis->mk, j, basis->n) * align_up((size_t)basis->mk * j * sizeof(double), 256) +
-         onb_energy_partial_bytes(n_chunk, j) + (size_t)n_chunk * j * sizeof(double);
+  const size_t general = (size_t)onb_max_slabs(basis->mk, j, basis->n) * align_up((size_t)basis->mk * j * sizeof(double), 256) +
+                         onb_energy_partial_bytes(n_chunk, j) + (size_t)n_chunk * j * sizeof(double);
+  const size_t one_launch = sr_step_workspace_bytes(basis->mk, j, basis->n);
+  return general > one_launch ? general : one_launch;
+}
+
+// The one-launch step (csrc/small_rank_step.h) applies to the orthonormal basis with <= 128 functions whose back-projection
+// operand the LDS-DMA can stream (16-byte aligned rows); option 1 takes it while the problem is launch-bound -- few enough
+// particle columns for one workgroup per 16 of them, and a step of at most 8 GFLOP (0.1 ms of matrix pipe): beyond, the
+// slab kernels of small_rank.h share every tile of the operand between four column groups, which is what counts there.
+static bool sr_step_route(const pls_onb_desc *b, int64_t j) {
+  const int64_t mode = g_small_rank_step.load();
+  if (mode == 0 || !small_rank_ok(b->At, b->ldat, b->mk)) return false;
+  if (mode >= 2) return true;
+  return j <= 4096 && 4.0 * (double)b->n * (double)b->mk * (double)j <= 8e9;
+}
+
+static int sr_step_launch(const pls_onb_desc *basis, const CostP &cp, const double *y, const double *U, int64_t ldu, int64_t j,
+                          const EtaP &etap, const NoiseP &nz, double *out, int64_t ldo, int out_mode, double *energy_in,
+                          const pls_block_desc *blocks, void *workspace, size_t workspace_bytes, hipStream_t st, bool *taken) {
+  *taken = false;
+  int64_t rows = 0;
+  int64_t ns = small_rank_step_splits(j, basis->n, (int)basis->mk, &rows);
+#ifdef PLS_SRS_PROBE
+  if (const char *f = getenv("PLS_SRS_FORCE_NS")) {
+    ns = atoi(f);
+    rows = (cdiv(basis->n, ns) + 63) / 64 * 64;
+    ns = cdiv(basis->n, rows);
+  }
+#endif
+  double *esums = (blocks && energy_in) ? blocks->energy_sums : nullptr;
+  const size_t slab_bytes = ns > 1 ? align_up((size_t)cdiv(j, 16) * ns * ((size_t)basis->mk + 1) * 16 * sizeof(double), 256) : 0;
+  const bool need_sync = ns > 1 || esums != nullptr;
+  uint32_t *sync = blocks ? blocks->step_sync : nullptr;
+  const size_t sync_bytes = small_rank_step_sync_words(j) * sizeof(uint32_t);
+  const size_t need = slab_bytes + ((need_sync && !sync) ? align_up(sync_bytes, 256) : 0);
+  if (need > 0 && (!workspace || workspace_bytes < need)) return PLS_OK;  // (the general route states its own needs)
+  if (need_sync && !sync) {  // counters from the workspace: zeroed by a memset node in front of the launch
+    sync = reinterpret_cast<uint32_t *>(static_cast<char *>(workspace) + slab_bytes);
+    hipError_t e = hipMemsetAsync(sync, 0, sync_bytes, st);
+    if (e != hipSuccess) return fail(PLS_ERR_HIP, "onb_step: hipMemsetAsync: %s", hipGetErrorString(e));
+  }
+  const int64_t ncb = cdiv(j, 16);
+  SrStepP p{};
+  p.Lb = basis->At;
+  p.ldlb = basis->ldat;
+  p.U = U;
+  p.ldu = ldu;
+  p.y = y;
+  p.lam = basis->lam;
+  p.N = basis->n;
+  p.J = j;
+  p.K = (int)basis->mk;
+  p.rows_per_split = rows;
+  p.nsplit = (int)ns;
+  p.cp = cp;
+  p.out = out;
+  p.ldo = ldo;
+  p.add_u = out_mode;
+  p.etap = etap;
+  p.nz = nz;
+  p.cb_sync = sync;
+  p.chunk_sync = sync ? sync + ncb : nullptr;
+  p.slab = static_cast<double *>(workspace);
+  p.vslab = p.slab ? p.slab + ncb * ns * basis->mk * 16 : nullptr;
+  p.e = energy_in;
+  p.esums = esums;
+  p.sums16 = (blocks && energy_in) ? blocks->energy_sums16 : nullptr;
+#ifdef PLS_SRS_PROBE
+  p.debug_stop = getenv("PLS_SRS_STOP") ? atoi(getenv("PLS_SRS_STOP")) : 0;
+#endif
+  *taken = true;
+  return energy_in ? launch_small_rank_step_value(p, st) : launch_small_rank_step(p, st);
 }
 
 // pls_block_desc.energy_sums on the routes whose kernels do not leave them as a by-product (the generic N x M x J step, the
 // inducing-point step outside whitened coordinates): one small launch over the finished per-particle energies, so that a
 // caller who asked for the sums gets them whatever route the descriptor and the options select.
 static int finish_energy_sums(const pls_block_desc *blocks, const double *energy_in, int64_t j, hipStream_t st) {
-  if (!blocks || !blocks->energy_sums || !energy_in) return PLS_OK;
-  hipLaunchKernelGGL(chunk_sums_kernel, dim3((unsigned)cdiv(j, 256)), dim3(256), 0, st, energy_in, j, blocks->energy_sums);
-  return check_launch("chunk_sums");
+  if (!blocks || !energy_in) return PLS_OK;
+  if (blocks->energy_sums) {
+    hipLaunchKernelGGL(chunk_sums_kernel, dim3((unsigned)cdiv(j, 256)), dim3(256), 0, st, energy_in, j, blocks->energy_sums);
+    if (int rc = check_launch("chunk_sums")) return rc;
+  }
+  if (blocks->energy_sums16) {
+    hipLaunchKernelGGL(sums16_kernel, dim3((unsigned)cdiv(cdiv(j, 16), 256)), dim3(256), 0, st, energy_in, j, blocks->energy_sums16);
+    if (int rc = check_launch("sums16")) return rc;
+  }
+  return PLS_OK;
+}
+
+// pls_block_desc.energy_sums16 on the routes that finish energy_in themselves (the Gaussian/identity fast paths; not with lagged
+// energies, whose values arrive one launch later)
+static int finish_sums16(const pls_block_desc *blocks, const double *energy_in, int64_t j, hipStream_t st) {
+  if (!blocks || !energy_in || !blocks->energy_sums16 || blocks->energy_partials) return PLS_OK;
+  hipLaunchKernelGGL(sums16_kernel, dim3((unsigned)cdiv(cdiv(j, 16), 256)), dim3(256), 0, st, energy_in, j, blocks->energy_sums16);
+  return check_launch("sums16");
 }
 
 static int validate_blocks(const pls_block_desc *b, int64_t j) {
@@ -2224,11 +2294,18 @@ static int onb_step_impl(const pls_onb_desc *basis, const pls_cost_desc *cost, c
   hipStream_t st = S(stream);
   if (onb_fast_path(basis, cost, force_generic)) {
     const FastOp op{basis->B, basis->ldb, basis->c, basis->lam, basis->mk, 1.0 / cost->p[0], 0.5 / cost->p[0], basis->c + basis->mk};
-    return fast_step_launch(op, U, ldu, j, etap, nz, out, ldo, out_mode, energy_in, workspace, workspace_bytes, st, "onb_step",
-                            blocks ? blocks->energy_sums : nullptr, blocks ? blocks->energy_sync : nullptr, make_lag(blocks));
+    rc = fast_step_launch(op, U, ldu, j, etap, nz, out, ldo, out_mode, energy_in, workspace, workspace_bytes, st, "onb_step",
+                          blocks ? blocks->energy_sums : nullptr, blocks ? blocks->energy_sync : nullptr, make_lag(blocks));
+    return rc ? rc : finish_sums16(blocks, energy_in, j, st);
   }
   PLS_REQUIRE(!blocks || (!blocks->energy_partials && !blocks->energy_partials_prev),
               "onb_step: lagged energies (energy_partials) exist on the Gaussian/identity fast path only");
+  if (sr_step_route(basis, j)) {  // launch-bound problems: the whole step, its energies and their chunk sums in ONE launch
+    bool taken = false;
+    rc = sr_step_launch(basis, cp, y, U, ldu, j, etap, nz, out, ldo, out_mode, energy_in, blocks, workspace, workspace_bytes, st,
+                        &taken);
+    if (rc || taken) return rc;
+  }
   // workspace: [D slabs][cost partial rows (energy by-product)][G chunk]; the chunk length follows from what is left
   const size_t d_bytes = align_up((size_t)basis->mk * j * sizeof(double), 256);
   const int64_t max_slabs = onb_max_slabs(basis->mk, j, basis->n);
@@ -2534,6 +2611,8 @@ static int ipb_step_impl(const pls_ipb_desc *basis, const pls_cost_desc *cost, c
                             2 * mj, st, "ipb_step", blocks ? blocks->energy_sums : nullptr, blocks ? blocks->energy_sync : nullptr);
     }
     if (rc) return rc;
+    rc = finish_sums16(blocks, energy_in, j, st);
+    if (rc) return rc;
     EpiIpbFinish fin{out, ldo, U, ldu, out_mode, make_etap(eta, blocks), e_inj, ld_inj};
     return launch_gemm_any(basis->LcT, basis->ldlct, Wd, j, basis->m, j, basis->m, fin, st, 0, 1,
                            TriScratch{basis->tri_scratch, basis->tri_scratch_bytes});
@@ -2760,9 +2839,10 @@ static int ipb_whitened_step_impl(const pls_ipb_desc *basis, const pls_cost_desc
   PLS_REQUIRE(Sw && out && out != Sw && j >= 0 && lds >= j && ldo >= j && eta >= 0.0, "ipb_whitened_step: bad arguments");
   PLS_REQUIRE(out_mode == 0 || out_mode == 1, "ipb_whitened_step: out_mode must be 0 or 1");
   if (j == 0) return PLS_OK;
-  return fast_step_launch(ipb_whitened_op(basis), Sw, lds, j, make_etap(eta, blocks), make_noisep(noise, blocks), out, ldo,
-                          out_mode, energy_in, workspace, workspace_bytes, S(stream), "ipb_whitened_step",
-                          blocks ? blocks->energy_sums : nullptr, blocks ? blocks->energy_sync : nullptr, make_lag(blocks));
+  rc = fast_step_launch(ipb_whitened_op(basis), Sw, lds, j, make_etap(eta, blocks), make_noisep(noise, blocks), out, ldo,
+                        out_mode, energy_in, workspace, workspace_bytes, S(stream), "ipb_whitened_step",
+                        blocks ? blocks->energy_sums : nullptr, blocks ? blocks->energy_sync : nullptr, make_lag(blocks));
+  return rc ? rc : finish_sums16(blocks, energy_in, j, S(stream));
 }
 
 int pls_ipb_whitened_step(const pls_ipb_desc *basis, const pls_cost_desc *cost, const double *Sw, int64_t lds, int64_t j,

@@ -47,13 +47,21 @@ class CapturedSteps:
         # the capture freezes the workspace ADDRESS: it owns the buffer (the basis' own scratch is reallocated whenever a
         # later eager call asks for more bytes, e.g. an energy evaluation between two replays)
         self._ws = _own_workspace(basis, cost, particles, with_energy=False, force_generic=force_generic)
+        # ... and, for the same reason, the step-size word and the arrival counters of the one-launch small-rank step
+        # (pls_block_desc.step_sync): the basis keeps such counters per stream for eager calls, a capture brings its own
+        from .basis.base import BlockSpec
+
+        self._eta = torch.full((1,), float(step_size), dtype=torch.float64, device=particles.device)
+        self._step_sync = torch.zeros(max(int(L.load().pls_step_sync_words(particles.shape[1])), 1), dtype=torch.int32,
+                                      device=particles.device)
+        blocks = BlockSpec(max(int(particles.shape[1]), 1), self._eta, step_sync=self._step_sync)
 
         def body():
             cur, nxt = self.particles, self._pong
             for s in range(self.k):
                 spec = NoiseSpec(seed=seed, step=s, j_offset=basis.j_offset, step_base=self.counter)
                 basis.fused_step(cost, cur, float(step_size), out=nxt, new_state=True, noise=spec, force_generic=force_generic,
-                                 workspace=self._ws)
+                                 workspace=self._ws, blocks=blocks)
                 cur, nxt = nxt, cur
             if cur is not self.particles:
                 self.particles.copy_(cur)
@@ -115,11 +123,14 @@ class CapturedTraining:
         self._nchunk = (j + 255) // 256
         self._sums = torch.zeros(steps_per_replay, self._nchunk, dtype=torch.float64, device=particles.device)
         self._sync = torch.zeros(self._nchunk, dtype=torch.int32, device=particles.device)  # (pls_block_desc.energy_sync)
+        # (pls_block_desc.step_sync: the one-launch small-rank step's counters, owned by the capture like its workspace)
+        self._step_sync = torch.zeros(max(int(L.load().pls_step_sync_words(j)), 1), dtype=torch.int32, device=particles.device)
         # lagged energies (trainers.LAGGED_ENERGIES): launch s + 1 of the replay finishes the energies of launch s at its start,
         # one small finishing launch closes the replay
         from . import trainers as _tr
 
-        self._lagged = bool(self._fused_sums and _tr.LAGGED_ENERGIES and getattr(pls.basis, "fused_step_takes_lagged_energies", False))
+        self._lagged = bool(self._fused_sums and _tr.LAGGED_ENERGIES and getattr(pls.basis, "fused_step_takes_lagged_energies", False)
+                            and getattr(pls.basis, "supports_lagged_energies", lambda c: False)(pls.cost))
         if self._lagged:
             pbytes = pls.basis.energy_partial_rows_bytes(j)
             self._parts = [torch.empty((pbytes + 7) // 8, dtype=torch.float64, device=particles.device) for _ in range(2)]
@@ -149,7 +160,8 @@ class CapturedTraining:
                 elif self._fused_sums:
                     from .basis.base import BlockSpec
 
-                    blocks = BlockSpec(cur.shape[1], self._eta, energy_sums=self._sums[s].data_ptr(), energy_sync=self._sync)
+                    blocks = BlockSpec(cur.shape[1], self._eta, energy_sums=self._sums[s].data_ptr(), energy_sync=self._sync,
+                                       step_sync=self._step_sync)
                     basis.fused_step(cost, cur, self.step_size, out=nxt, new_state=True, noise=spec, input_energy=self._e,
                                      workspace=self._ws, blocks=blocks)
                 else:

@@ -210,8 +210,8 @@ def _step_is_launch_bound(pls: PLS, j: int) -> bool:
     """estimated duration of one step of j particles (at half the fp64 MFMA peak) below LAUNCH_BOUND_STEP_SECONDS"""
     basis = pls.basis
     mk = int(basis.approximation_dimension)
-    if getattr(basis, "supports_energy_sums", lambda c: False)(pls.cost):
-        flop = 2.0 * mk * mk * j  # Gaussian/identity: one M_k x M_k x J contraction
+    if getattr(basis, "supports_lagged_energies", lambda c: False)(pls.cost):
+        flop = 2.0 * mk * mk * j  # Gaussian/identity fast path: one M_k x M_k x J contraction
     else:
         n = int(getattr(pls.cost, "y_train").shape[0])
         flop = 4.0 * n * mk * j  # F = A^T U and A G

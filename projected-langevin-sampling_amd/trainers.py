@@ -33,8 +33,11 @@ class EarlyStopper:
 
 
 def mean_from_chunk_sums(sums, count: int) -> float:
-    """Mean energy from the 256-column chunk sums the step's finishing launch leaves (pls_block_desc.energy_sums): the
-    chunks added in ascending order, divided by the particle count -- what pls_block_means computes, bit for bit."""
+    """Mean energy from the 256-column chunk sums the step's finishing launch leaves (pls_block_desc.energy_sums: what
+    pls_block_means computes, bit for bit) or from the 16-column sums of the one-launch small-rank step
+    (pls_block_desc.energy_sums16): the entries added in ascending order, divided by the particle count."""
+    if isinstance(sums, np.ndarray) and sums.shape[0] > 16:
+        return float(np.cumsum(sums)[-1]) / count  # (a cumulative sum is strictly sequential: the loop below, vectorised)
     total = 0.0
     for v in sums:
         total += float(v)
@@ -73,6 +76,11 @@ class _LoopSpace:
         """step + energy by-product + mean as a pre-bound call (basis.step_launcher), or None"""
         make = None if self.whitened else getattr(self.pls.basis, "step_launcher", None)
         return None if make is None else make(self.pls.cost, state, step_size)
+
+    def sums_launcher(self, state, eta_dev):
+        """step + energies + their chunk sums as a pre-bound call (basis.sums_step_launcher: the one-launch small-rank step), or None"""
+        make = None if self.whitened else getattr(self.pls.basis, "sums_step_launcher", None)
+        return None if make is None else make(self.pls.cost, state, eta_dev)
 
     def lagged_launcher(self, state, eta_dev):
         """the lagged Gaussian step as a pre-bound call (basis.lagged_step_launcher), or None"""
@@ -215,7 +223,10 @@ def _train_pls_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs: in
     # the energies -- straight in pinned host memory -- so an iteration is the step kernel and ONE small launch (round 2: a
     # finishing launch plus a mean launch, 15 us of a 280 us iteration); other costs keep the separate mean launch
     fused_sums = _supports_energy_sums(pls)
-    nchunk = (j + 255) // 256 if fused_sums else 1
+    # (costs without the Gaussian algebra on a small basis: the one-launch step leaves the sums of 16 columns each -- for free,
+    # where the 256-column chunk sums cost it a second hand-over between workgroups, csrc/small_rank_step.h)
+    sums16 = bool(fused_sums and getattr(pls.basis, "uses_sums16", lambda c: False)(pls.cost))
+    nchunk = ((j + 15) // 16 if sums16 else (j + 255) // 256) if fused_sums else 1
     host = torch.empty(NB * nchunk, dtype=torch.float64).pin_memory()
     host_ptr = host.data_ptr()  # (hipHostMalloc'ed by torch: host and device addresses coincide)
     # Fused chunk sums: no event per launch.  An event record puts a barrier packet between the finishing launch and the
@@ -246,12 +257,18 @@ def _train_pls_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs: in
             # generator in batches -- the same stream of draws as one per step, and the generator is left exactly where the
             # plain loop leaves it (below)
             fast = space.lagged_launcher(bufs[0], eta_dev)
+    sums = None
+    if fused_sums and fast is None and not lagged and noises is None and pls.cost.is_native() \
+            and all(b.dim() == 2 and b.stride(1) == 1 for b in bufs):
+        # costs without the Gaussian algebra on a small basis: ONE launch per iteration leaves the new state, the energies of its
+        # input and their chunk sums in the pinned slot (csrc/small_rank_step.h), bound once like the lagged Gaussian step
+        sums = space.sums_launcher(bufs[0], eta_dev)
     general = None
     if not fused_sums and noises is None and pls.cost.is_native() and all(b.dim() == 2 and b.stride(1) == 1 for b in bufs):
         # (other costs: the same host-side trim around pls_onb_step + pls_block_means; the mean's pinned slot is polled like
         # the chunk sums instead of waited for through an event)
         general = space.general_launcher(bufs[0], step_size)
-    if fast is not None or general is not None:
+    if fast is not None or general is not None or sums is not None:
         buf_ptr, buf_ld = [b.data_ptr() for b in bufs], [L.ld(b) for b in bufs]
         e_ptr = [e.data_ptr() for e in e_dev]
         part_ptr = [p_.data_ptr() for p_ in parts] if fast is not None else None
@@ -279,6 +296,14 @@ def _train_pls_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs: in
                 fast(buf_ptr[a], buf_ld[a], buf_ptr[b], buf_ld[b], keys[k], part_ptr[0], None, None, None)
             launched += 1
             return
+        if sums is not None:  # launch k: U_{k+1} from U_k, E(U_k) and its chunk sums (slot k) from the same launch
+            if k >= len(keys):
+                keys.extend(torch.randint(0, 2**62, (256,), dtype=torch.int64).tolist())
+            a, b = k % NB, (k + 1) % NB
+            host_np_bits[a * nchunk:(a + 1) * nchunk] = UNWRITTEN
+            sums(buf_ptr[a], buf_ld[a], buf_ptr[b], buf_ld[b], keys[k], e_ptr[a], host_ptr + 8 * nchunk * a)
+            launched += 1
+            return
         if general is not None:  # launch k: U_{k+1} from U_k, E(U_k) as a by-product, its mean into slot k
             if k >= len(keys):
                 keys.extend(torch.randint(0, 2**62, (256,), dtype=torch.int64).tolist())
@@ -299,7 +324,8 @@ def _train_pls_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs: in
             space.step(bufs[k % NB], step_size, bufs[(k + 1) % NB], spec, None, blocks=blocks)
         elif fused_sums:  # one column block = all particles, its step size from a device word, chunk sums to the host slot
             host_bits[(k % NB) * nchunk:(k % NB + 1) * nchunk] = UNWRITTEN
-            blocks = BlockSpec(j, eta_dev, energy_sums=host_ptr + 8 * nchunk * (k % NB), energy_sync=sync)
+            slot = host_ptr + 8 * nchunk * (k % NB)
+            blocks = BlockSpec(j, eta_dev, energy_sums16=slot) if sums16 else BlockSpec(j, eta_dev, energy_sums=slot, energy_sync=sync)
             space.step(bufs[k % NB], step_size, bufs[(k + 1) % NB], spec, e_dev[k % NB], blocks=blocks)
         else:
             space.step(bufs[k % NB], step_size, bufs[(k + 1) % NB], spec, e_dev[k % NB])
@@ -312,10 +338,10 @@ def _train_pls_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs: in
 
     def read_energy(slot: int) -> float:
         if mean is not None:  # J-sharded run (distributed.EnergyMean): the local SUM goes to the ranks' host-side exchange
-            local = mean_from_chunk_sums(host_np[slot * nchunk:(slot + 1) * nchunk].tolist(), 1) if fused_sums else float(host_np[slot]) * j
+            local = mean_from_chunk_sums(host_np[slot * nchunk:(slot + 1) * nchunk], 1) if fused_sums else float(host_np[slot]) * j
             return mean.reduce_local_sum(local)
         if fused_sums:
-            return mean_from_chunk_sums(host_np[slot * nchunk:(slot + 1) * nchunk].tolist(), j)
+            return mean_from_chunk_sums(host_np[slot * nchunk:(slot + 1) * nchunk], j)
         return float(host_np[slot])
 
     def wait_for(slot: int) -> None:
@@ -355,7 +381,7 @@ def _train_pls_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs: in
                 last = space.energy(bufs[T % NB])
                 energy_potential = _mean_energy(last) if mean is None else mean.reduce_local_sum(last.sum().item())
             if early_stopper.should_stop(loss=energy_potential, step_size=step_size):
-                if fast is not None or general is not None:
+                if fast is not None or general is not None or sums is not None:
                     keys_used = t + 1
                 elif launched > t + 1:
                     torch.set_rng_state(rng_states[t + 1])
@@ -366,7 +392,7 @@ def _train_pls_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs: in
         # up to `depth` launches are still queued: they write the pinned slots and the rotating buffers, which must not go
         # back to torch's allocators (on ANY exit: a raising early stopper, a failed launch) before they have drained
         torch.cuda.current_stream().synchronize()
-    if fast is not None or general is not None:  # leave torch's generator where one draw per executed step leaves it
+    if fast is not None or general is not None or sums is not None:  # leave torch's generator where one draw per executed step leaves it
         torch.set_rng_state(rng_start)
         if keys_used > 0:
             torch.randint(0, 2**62, (keys_used,), dtype=torch.int64)

@@ -66,6 +66,9 @@ def test_options_validate_without_touching_the_gpu():
     assert lib.pls_set_option(L.OPT_KG_NOISE_PREGEN, 0) == 0 and lib.pls_set_option(L.OPT_KG_NOISE_PREGEN, 1) == 0
     assert lib.pls_get_option(L.OPT_IPB_STEP_OPERATOR) == 1 and lib.pls_set_option(L.OPT_IPB_STEP_OPERATOR, 3) != 0
     assert lib.pls_set_option(L.OPT_IPB_STEP_OPERATOR, 0) == 0 and lib.pls_set_option(L.OPT_IPB_STEP_OPERATOR, 1) == 0
+    assert lib.pls_get_option(L.OPT_SMALL_RANK_STEP) == 1 and lib.pls_set_option(L.OPT_SMALL_RANK_STEP, 3) != 0
+    assert lib.pls_set_option(L.OPT_SMALL_RANK_STEP, 2) == 0 and lib.pls_set_option(L.OPT_SMALL_RANK_STEP, 1) == 0
+    assert lib.pls_step_sync_words(512) == 32 + 2 and lib.pls_step_sync_words(17) == 2 + 1 and lib.pls_step_sync_words(0) == 0
     assert lib.pls_tri_scratch_bytes(1024, 1024) == 16384 + 8 * 16 * 2 * 4096 * 8 and lib.pls_tri_scratch_bytes(0, 5) == 0
 
 
@@ -79,7 +82,7 @@ def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(L.OnbDesc) == 10 * 8
     assert ctypes.sizeof(L.IpbDesc) == 29 * 8  # (ABI 4: + tri_scratch, tri_scratch_bytes, Pt, ldpt)
     assert ctypes.sizeof(L.CholDesc) == 15 * 8
-    assert ctypes.sizeof(L.BlockDesc) == 9 * 8
+    assert ctypes.sizeof(L.BlockDesc) == 11 * 8  # (ABI 5: + step_sync, energy_sums16)
     assert L.CostDesc.p.offset == 16 and L.CostDesc.jitter.offset == 48
 
 
@@ -95,7 +98,7 @@ def test_struct_layouts_match_what_a_c_compiler_makes_of_the_header(tmp_path):
     L = pkg._lib
     structs = {"pls_cost_desc": (L.CostDesc, "jitter"), "pls_noise_desc": (L.NoiseDesc, "step_base"),
                "pls_onb_desc": (L.OnbDesc, "c"), "pls_ipb_desc": (L.IpbDesc, "q_inv_noise"),
-               "pls_chol_desc": (L.CholDesc, "ldlinvt"), "pls_block_desc": (L.BlockDesc, "energy_sums")}
+               "pls_chol_desc": (L.CholDesc, "ldlinvt"), "pls_block_desc": (L.BlockDesc, "energy_sums16")}
     src = tmp_path / "layout.c"
     body = "".join(f'  printf("{n} %zu %zu\\n", sizeof({n}), offsetof({n}, {last}));\n' for n, (_, last) in structs.items())
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "plship.h"\nint main(void) {\n' + body + "  return 0;\n}\n")

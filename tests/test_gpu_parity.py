@@ -465,17 +465,21 @@ def step_tolerance(ob, oc, u, eta, noise, want, solve_cond=1.0):
 SHAPES = [(512, 32, 64, 3), (100, 10, 64, 1), (1000, 40, 3, 5), (333, 17, 1, 2), (2100, 130, 260, 4)]
 
 
-@pytest.fixture(params=["small_rank", "two_gemm"])
+@pytest.fixture(params=["small_rank", "two_gemm", "one_launch"])
 def rank_path(request, P):
-    """Bases with <= 128 functions take the fused small-rank kernels by default; `two_gemm` switches them off so the
-    same cases also run through the GEMM + epilogue path (pls_set_option, include/plship.h)."""
+    """Bases with <= 128 functions take the small-rank kernels by default: the one-launch step of csrc/small_rank_step.h while the
+    problem is launch-bound, the slab kernels of csrc/small_rank.h + update launch beyond.  `one_launch` forces the former
+    wherever it applies, `small_rank` the latter, `two_gemm` switches both off so the same cases also run through the GEMM +
+    epilogue path (pls_set_option, include/plship.h)."""
     lib = P.pkg._lib.load()
     L = P.pkg._lib
-    prev = lib.pls_get_option(L.OPT_SMALL_RANK_MAX)
-    assert prev == 128
-    L.check(lib.pls_set_option(L.OPT_SMALL_RANK_MAX, 128 if request.param == "small_rank" else 0), "pls_set_option")
+    prev = (lib.pls_get_option(L.OPT_SMALL_RANK_MAX), lib.pls_get_option(L.OPT_SMALL_RANK_STEP))
+    assert prev == (128, 1)
+    L.check(lib.pls_set_option(L.OPT_SMALL_RANK_MAX, 0 if request.param == "two_gemm" else 128), "pls_set_option")
+    L.check(lib.pls_set_option(L.OPT_SMALL_RANK_STEP, 2 if request.param == "one_launch" else 0), "pls_set_option")
     yield request.param
-    L.check(lib.pls_set_option(L.OPT_SMALL_RANK_MAX, prev), "pls_set_option")
+    L.check(lib.pls_set_option(L.OPT_SMALL_RANK_MAX, prev[0]), "pls_set_option")
+    L.check(lib.pls_set_option(L.OPT_SMALL_RANK_STEP, prev[1]), "pls_set_option")
 
 
 @pytest.mark.parametrize("n,m,j,d", SHAPES)

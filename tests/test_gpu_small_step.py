@@ -1,0 +1,240 @@
+"""The one-launch small-rank step (csrc/small_rank_step.h; pls_block_desc.step_sync / energy_sums16,
+PLS_OPT_SMALL_RANK_STEP) on the GPU: against the CPU oracle on the same seeded inputs (TOL as in test_gpu_parity.py), against
+the slab kernels + update launch it replaces in the launch-bound regime, and its own contracts -- several row slabs per
+column block meeting through the arrival counters, counters left zero, the same bits from launch to launch, the energy
+sums it delivers, the memset fall-back for callers without counters, column blocks with their own step sizes.
+Reference path: projected_langevin_sampling.py:107-138, basis/orthonormal.py:98-159, experiments/trainers.py:149-158."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import pls_oracle as O
+
+from test_gpu_parity import FUZZ_SEED, TOL, build_onb, cu, make_costs, make_problem, relerr, step_tolerance  # noqa: E402
+from test_gpu_parity import P, _f64_default  # noqa: F401,E402  (fixtures)
+
+
+@pytest.fixture
+def route(P):
+    """set(mode): PLS_OPT_SMALL_RANK_STEP for the duration of a test (0 slab kernels, 1 default, 2 one launch wherever it applies)"""
+    L = P.pkg._lib
+    lib = L.load()
+    prev = lib.pls_get_option(L.OPT_SMALL_RANK_STEP)
+
+    def set_mode(mode):
+        L.check(lib.pls_set_option(L.OPT_SMALL_RANK_STEP, mode), "pls_set_option")
+
+    yield set_mode
+    L.check(lib.pls_set_option(L.OPT_SMALL_RANK_STEP, prev), "pls_set_option")
+
+
+def _timeline_names(P, fn):
+    with P.pkg._lib.Timeline(64) as tl:
+        fn()
+    return sorted(tl.summary())
+
+
+# (n, m, j, d): one slab / ragged J and odd rank / several slabs of a narrow rank / several slabs of a wide rank with a row tail /
+# a rank of exactly 128 / fewer rows than one round of tiles
+SHAPES = [(100, 10, 64, 1), (333, 17, 37, 2), (3000, 30, 40, 2), (1530, 120, 200, 4), (900, 140, 48, 3), (40, 12, 5, 1)]
+
+
+@pytest.mark.parametrize("n,m,j,d", SHAPES)
+def test_one_launch_step_against_the_oracle_and_the_slab_kernels(P, route, n, m, j, d):
+    pr = make_problem(n, m, j, d, seed=3 * n + m + FUZZ_SEED)
+    ob, gb = build_onb(P, pr, threshold=1e-7)
+    mk = ob.approximation_dimension
+    if mk > 128:
+        pytest.skip(f"{mk} functions kept: not a small-rank basis")
+    u = pr["u"][:mk].contiguous()
+    xi = torch.randn(mk, j, generator=pr["gen"])
+    eta = 1e-3
+    checked = 0
+    for name, oc, gc in make_costs(P, pr["y"], pr["fstar"], pr["gen"]):
+        if name == "gaussian/identity":
+            continue  # (the B = A A^T fast path: not this kernel's business; gaussian/square below is the generic Gaussian)
+        want = O.PLS(ob, oc).calculate_particle_update(u.clone(), eta, noise=xi)
+        tol = step_tolerance(ob, oc, u, eta, xi, want)
+        if tol >= 1e-8:
+            continue
+        checked += 1
+        spec = P.basis.NoiseSpec(injected=cu(xi))
+        e_new = torch.full((j,), float("nan"), device="cuda")
+        route(2)
+        names = _timeline_names(P, lambda: gb.fused_step(gc, cu(u), eta, noise=spec, input_energy=e_new))
+        assert names == ["small_rank_step"], f"{name}: launches {names}"
+        got = gb.fused_step(gc, cu(u), eta, noise=spec)
+        got_e = gb.fused_step(gc, cu(u), eta, noise=spec, input_energy=e_new)
+        assert torch.equal(got, got_e), "the energy by-product must not move the step"
+        assert relerr(got, want) < tol, name
+        e_want = oc.calculate_cost(ob.calculate_untransformed_train_prediction_samples(u)) + 0.5 * ((u * u) / ob.eigenvalues[:, None]).sum(dim=0)
+        assert relerr(e_new, e_want) < 1e-9, name
+        route(0)
+        e_old = torch.empty(j, device="cuda")
+        old = gb.fused_step(gc, cu(u), eta, noise=spec, input_energy=e_old)
+        assert relerr(got, old) < 1e-11 and relerr(e_new, e_old) < 1e-11, name
+        route(2)
+        # new state instead of the update; Philox noise: the stream of the other routes, bit for bit (same counters)
+        ph = P.basis.NoiseSpec(seed=77, step=5, j_offset=3)
+        a = gb.fused_step(gc, cu(u), eta, noise=ph, new_state=True)
+        route(0)
+        b = gb.fused_step(gc, cu(u), eta, noise=ph, new_state=True)
+        assert relerr(a, b) < 1e-11, name
+        nz_new = a - cu(u) - gb.fused_step(gc, cu(u), eta, noise=P.basis.NoiseSpec(none=True))
+        route(2)
+        nz_old = a - cu(u) - gb.fused_step(gc, cu(u), eta, noise=P.basis.NoiseSpec(none=True))
+        assert relerr(nz_new, nz_old) < 1e-9
+    assert checked >= 5, f"only {checked} (cost, link) pairs were checked"
+
+
+def test_slabs_meet_through_counters_that_are_left_zero_and_the_bits_do_not_move(P, route):
+    """Several row slabs per column block: the last arriver adds them in ascending order whoever it is -- the same bits from
+    launch to launch --, the caller's counters are zero again after every launch, and a basis keeps one counter set per stream."""
+    pr = make_problem(6000, 40, 96, 3, seed=41 + FUZZ_SEED)
+    _, gb = build_onb(P, pr)
+    mk = gb.approximation_dimension
+    _, _, gc = make_costs(P, pr["y"], pr["fstar"], pr["gen"])[2]  # bernoulli/sigmoid
+    u = cu(pr["u"][:mk].contiguous())
+    route(2)
+    lib = P.pkg._lib.load()
+    words = int(lib.pls_step_sync_words(96))
+    assert words == 6 + 1
+    sync = torch.zeros(words, dtype=torch.int32, device="cuda")
+    eta = torch.full((1,), 1e-3, device="cuda")
+    spec = P.basis.NoiseSpec(seed=9, step=1)
+    outs = []
+    for rep in range(6):
+        e = torch.empty(96, device="cuda")
+        s16 = torch.full((6,), float("nan"), device="cuda")
+        s256 = torch.full((1,), float("nan"), device="cuda")
+        blocks = P.basis.BlockSpec(96, eta, step_sync=sync, energy_sums16=s16.data_ptr(), energy_sums=s256.data_ptr())
+        out = gb.fused_step(gc, u, 0.0, noise=spec, input_energy=e, blocks=blocks)
+        assert int(sync.abs().sum()) == 0, "the launch must leave its counters zero"
+        outs.append((out, e, s16, s256))
+    for out, e, s16, s256 in outs[1:]:
+        assert torch.equal(out, outs[0][0]) and torch.equal(e, outs[0][1]) and torch.equal(s16, outs[0][2]) and torch.equal(s256, outs[0][3])
+    out, e, s16, s256 = outs[0]
+    # the sums it delivers: 16 columns each in ascending order; the 256-column chunk in the library's fixed order
+    want16 = torch.stack([e[16 * b:16 * b + 16].cpu().cumsum(0)[-1] for b in range(6)])
+    assert torch.equal(s16.cpu(), want16)
+    chunk = torch.empty(1, device="cuda")
+    P.pkg._lib.check(lib.pls_chunk_sums(e.data_ptr(), 96, chunk.data_ptr(), P.pkg._lib.stream_ptr()), "pls_chunk_sums")
+    assert torch.equal(s256, chunk)
+    alone = torch.empty(6, device="cuda")
+    P.pkg._lib.check(lib.pls_sums16(e.data_ptr(), 96, alone.data_ptr(), P.pkg._lib.stream_ptr()), "pls_sums16")
+    assert torch.equal(alone, s16)
+    # the basis' own counters: one set per stream, zero after use, dropped after a failed launch
+    gb.zero_step_sync()
+    a = gb.fused_step(gc, u, 1e-3, noise=spec)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        b = gb.fused_step(gc, u, 1e-3, noise=spec)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.equal(a, out)
+    pool = gb._sync_pool
+    assert len(pool) == 2 and all(int(t.abs().sum()) == 0 for t in pool.values())
+    # stale counters (a launch that died half way): every later step would be wrong -- zero_step_sync is the repair
+    key = next(iter(pool))
+    pool[key][0] = 1
+    bad = gb.fused_step(gc, u, 1e-3, noise=spec)
+    torch.cuda.synchronize()
+    gb.zero_step_sync()
+    good = gb.fused_step(gc, u, 1e-3, noise=spec)
+    assert torch.equal(good, out) and not torch.equal(bad, out)
+
+
+def test_callers_without_counters_get_a_memset_in_front_of_the_launch(P, route):
+    """pls_onb_step straight through the C ABI, no pls_block_desc: the counters come out of the workspace and a memset node
+    zeroes them -- whatever the workspace held."""
+    pr = make_problem(5000, 24, 70, 2, seed=8 + FUZZ_SEED)
+    _, gb = build_onb(P, pr)
+    mk = gb.approximation_dimension
+    _, _, gc = make_costs(P, pr["y"], pr["fstar"], pr["gen"])[1]  # poisson/square
+    u = cu(1.0 + 0.1 * pr["u"][:mk].contiguous())
+    L = P.pkg._lib
+    lib = L.load()
+    route(2)
+    desc, cd, y = gb._desc(), gc.desc(), gc.y_device()
+    nbytes = int(lib.pls_onb_step_workspace_bytes(desc, 70, 5000))
+    ws = torch.full(((nbytes + 7) // 8,), float("nan"), device="cuda")  # (NaN bit patterns where the counters will be)
+    nd = P.basis.NoiseSpec(seed=4, step=0).desc()
+    out = torch.empty_like(u)
+    e = torch.empty(70, device="cuda")
+    for rep in range(2):
+        names = _timeline_names(P, lambda: L.check(lib.pls_onb_step(desc, cd, y.data_ptr(), u.data_ptr(), L.ld(u), 70, 1e-3, nd, out.data_ptr(),
+                                                                      L.ld(out), L.OUT_NEW_STATE, 0, e.data_ptr(), ws.data_ptr(), nbytes,
+                                                                      L.stream_ptr()), "pls_onb_step"))
+        assert names == ["small_rank_step"]
+    want_e = torch.empty(70, device="cuda")
+    want = gb.fused_step(gc, u, 1e-3, noise=P.basis.NoiseSpec(seed=4, step=0), new_state=True, input_energy=want_e)
+    assert torch.equal(out, want) and torch.equal(e, want_e)
+    # a workspace too small for the slabs: the call falls back to the general route's own message
+    small = torch.empty(16, device="cuda")
+    rc = lib.pls_onb_step(desc, cd, y.data_ptr(), u.data_ptr(), L.ld(u), 70, 1e-3, nd, out.data_ptr(), L.ld(out), L.OUT_NEW_STATE, 0,
+                          None, small.data_ptr(), 128, L.stream_ptr())
+    assert rc != 0 and b"workspace" in lib.pls_last_error()
+
+
+def test_column_blocks_with_their_own_step_sizes(P, route):
+    """The S candidates of a step-size search as S column blocks of one launch (experiments/runners.py:331-446): every block
+    equals a stand-alone run of block_cols particles with its step size and its own noise stream; a frozen block (eta = 0)
+    does not move."""
+    pr = make_problem(800, 16, 90, 2, seed=13 + FUZZ_SEED)
+    _, gb = build_onb(P, pr)
+    mk = gb.approximation_dimension
+    _, _, gc = make_costs(P, pr["y"], pr["fstar"], pr["gen"])[2]
+    u = cu(pr["u"][:mk].contiguous())
+    route(2)
+    etas = torch.tensor([1e-3, 0.0, 4e-3], device="cuda")
+    spec = P.basis.NoiseSpec(seed=21, step=3)
+    e = torch.empty(90, device="cuda")
+    blocks = P.basis.BlockSpec(30, etas)
+    got = gb.fused_step(gc, u, 0.0, noise=spec, new_state=True, input_energy=e, blocks=blocks)
+    for b, eta in enumerate([1e-3, 0.0, 4e-3]):
+        ub = u[:, 30 * b:30 * b + 30].contiguous()
+        eb = torch.empty(30, device="cuda")
+        alone = gb.fused_step(gc, ub, eta, noise=spec, new_state=True, input_energy=eb)
+        assert torch.equal(got[:, 30 * b:30 * b + 30], alone), b
+        assert torch.equal(e[30 * b:30 * b + 30], eb), b
+    assert torch.equal(got[:, 30:60], u[:, 30:60])
+
+
+def test_training_loop_is_one_launch_per_iteration_and_equals_the_plain_loop(P, route):
+    """train_pls for a cost without the Gaussian algebra on a small basis: every iteration of the pipelined loop is ONE launch
+    (step, energies of its input, their 16-column sums into the pinned slot the host polls); same particles, energies, stop
+    index and torch generator state as the plain loop (step, then a separate energy pass), early stop included."""
+    pr = make_problem(600, 20, 48, 2, seed=5 + FUZZ_SEED)
+    ob, gb = build_onb(P, pr)
+    mk = ob.approximation_dimension
+    name, oc, gc = make_costs(P, pr["y"], pr["fstar"], pr["gen"])[2]
+    pls = P.pkg.PLS(gb, gc)
+    u0 = cu(pr["u"][:mk].contiguous())
+    route(1)
+    with P.pkg._lib.Timeline(256) as tl:
+        torch.manual_seed(3)
+        P.pkg.train_pls(pls, u0.clone(), 30, 2e-6, 1e9)
+    summary = tl.summary()
+    assert set(summary) <= {"small_rank_step", "small_rank_value", "other"}, summary
+    assert summary["small_rank_step"]["launches"] >= 30  # (speculative launches past the last iteration are allowed)
+    for patience in (1e9, 5e-6):
+        runs = {}
+        for mode in ("pipelined", "plain"):
+            if mode == "plain":
+                gb.supports_input_energy = lambda c: False
+            try:
+                torch.manual_seed(44)
+                out, energies = P.pkg.train_pls(pls, u0.clone(), 25, 2e-6, patience)
+                runs[mode] = (out, energies, torch.get_rng_state())
+            finally:
+                if mode == "plain":
+                    del gb.supports_input_energy
+        assert len(runs["pipelined"][1]) == len(runs["plain"][1])
+        assert torch.equal(runs["pipelined"][0], runs["plain"][0])
+        assert np.allclose(runs["pipelined"][1], runs["plain"][1], rtol=1e-11)
+        assert torch.equal(runs["pipelined"][2], runs["plain"][2])
+    assert len(runs["plain"][1]) < 25, "the short patience must stop the run"
