@@ -117,7 +117,9 @@ int main() {
                 err / scale, eerr);
     worst = std::fmax(worst, std::fmax(err / scale, eerr));
   }
-  // error behaviour across the boundary: a too-small workspace is reported, not crashed on
+  // error behaviour across the boundary: a too-small workspace is reported, not crashed on.  (The one-launch small-rank step
+  // needs no workspace at this size -- one row slab per column block --, so the slab kernels are selected for this call.)
+  pls_set_option(PLS_OPT_SMALL_RANK_STEP, 0);
   pls_cost_desc cost{};
   cost.cost = PLS_COST_GAUSSIAN, cost.link = PLS_LINK_IDENTITY, cost.p[0] = sigma2, cost.jitter = 1e-10;
   const int rc = pls_onb_step(&basis, &cost, dy, dU, j, j, eta, &noise, dout, j, 0, 1, nullptr, ws, 16, st);
@@ -126,6 +128,7 @@ int main() {
     return 4;
   }
   std::printf("workspace error reported: %s\n", pls_last_error());
+  pls_set_option(PLS_OPT_SMALL_RANK_STEP, 1);
   // the factorisation behind gpytorch.solve (inducing_point.py:89-93, :130-132) from plain C++: K = Q Q^T + m I (SPD, M = 200:
   // two 128-blocks, the second one partial), K = Lc Lc^T on the device, V = K^-1 U by block substitution, residual on the host
   {

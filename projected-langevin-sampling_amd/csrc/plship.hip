@@ -1429,10 +1429,14 @@ static int validate_cost(const pls_cost_desc *c) {
   return PLS_OK;
 }
 
-static int validate_noise(const pls_noise_desc *n, int64_t rows) {
+static int validate_noise(const pls_noise_desc *n, int64_t rows, int64_t j) {
   if (!n) return PLS_OK;
   PLS_REQUIRE(n->kind >= PLS_NOISE_NONE && n->kind <= PLS_NOISE_PHILOX, "unknown noise kind %d", n->kind);
-  if (n->kind == PLS_NOISE_INJECTED) PLS_REQUIRE(n->xi != nullptr && n->ldxi > 0, "injected noise needs xi and ldxi");
+  if (n->kind == PLS_NOISE_INJECTED) {
+    PLS_REQUIRE(n->xi != nullptr && n->ldxi > 0, "injected noise needs xi and ldxi");
+    // (the kernels read xi[row * ldxi + column] for every particle column: a narrower matrix would be read out of bounds)
+    PLS_REQUIRE(n->ldxi >= j, "injected noise: leading dimension %lld < %lld particle columns", (long long)n->ldxi, (long long)j);
+  }
   (void)rows;
   return PLS_OK;
 }
@@ -2095,7 +2099,7 @@ int pls_onb_particle_update(const pls_onb_desc *basis, const double *U, int64_t 
                             int64_t j, double eta, const pls_noise_desc *noise, double *dU, int64_t lddu, void *stream) {
   int rc = validate_onb(basis);
   if (rc) return rc;
-  rc = validate_noise(noise, basis->mk);
+  rc = validate_noise(noise, basis->mk, j);
   if (rc) return rc;
   PLS_REQUIRE(U && G && dU && j >= 0 && ldu >= j && ldg >= j && lddu >= j, "onb_particle_update: bad arguments");
   PLS_REQUIRE(eta >= 0.0, "onb_particle_update: step size must be >= 0");
@@ -2269,7 +2273,7 @@ static int onb_step_impl(const pls_onb_desc *basis, const pls_cost_desc *cost, c
   if (rc) return rc;
   rc = validate_cost(cost);
   if (rc) return rc;
-  rc = validate_noise(noise, basis->mk);
+  rc = validate_noise(noise, basis->mk, j);
   if (rc) return rc;
   rc = validate_blocks(blocks, j);
   if (rc) return rc;
@@ -2527,7 +2531,7 @@ int pls_ipb_particle_update(const pls_ipb_desc *basis, const double *U, int64_t 
                             void *workspace, size_t workspace_bytes, void *stream) {
   int rc = validate_ipb(basis);
   if (rc) return rc;
-  rc = validate_noise(noise, basis->m);
+  rc = validate_noise(noise, basis->m, j);
   if (rc) return rc;
   PLS_REQUIRE(U && G && dU && j >= 0 && ldu >= j && ldg >= j && lddu >= j, "ipb_particle_update: bad arguments");
   PLS_REQUIRE(eta >= 0.0, "ipb_particle_update: step size must be >= 0");
@@ -2561,7 +2565,7 @@ static int ipb_step_impl(const pls_ipb_desc *basis, const pls_cost_desc *cost, c
   if (rc) return rc;
   rc = validate_cost(cost);
   if (rc) return rc;
-  rc = validate_noise(noise, basis->m);
+  rc = validate_noise(noise, basis->m, j);
   if (rc) return rc;
   rc = validate_blocks(blocks, j);
   if (rc) return rc;
@@ -2822,7 +2826,7 @@ static int ipb_whitened_step_impl(const pls_ipb_desc *basis, const pls_cost_desc
   if (rc) return rc;
   rc = validate_cost(cost);
   if (rc) return rc;
-  rc = validate_noise(noise, basis->m);
+  rc = validate_noise(noise, basis->m, j);
   if (rc) return rc;
   rc = validate_blocks(blocks, j);
   if (rc) return rc;

@@ -1253,8 +1253,11 @@ def test_error_behaviour(P):
         pls.calculate_energy_potential(bad)
     with pytest.raises(P.pkg._lib.PlsHipError):  # no CPU fallback
         pls.calculate_particle_update(torch.zeros(gb.approximation_dimension, 4, dtype=torch.float64), 1e-3)
-    with pytest.raises(P.pkg._lib.PlsHipError):
-        pls.calculate_particle_update(torch.zeros(gb.approximation_dimension, 4, dtype=torch.float32, device="cuda"), 1e-3)
+    # float32 particles are promoted like x / z / y (the reference's bases compute in the caller's dtype); anything else is told
+    # which conversion to make (tests: test_float32_callers_are_promoted_at_the_boundary)
+    assert pls.calculate_particle_update(torch.zeros(gb.approximation_dimension, 4, dtype=torch.float32, device="cuda"), 1e-3).dtype == torch.float64
+    with pytest.raises(TypeError):
+        pls.calculate_particle_update(torch.zeros(gb.approximation_dimension, 4, dtype=torch.int32, device="cuda"), 1e-3)
     L = P.pkg._lib
     rc = L.load().pls_gemm_tn(None, 1, None, 1, None, 1, 1, 1, 1, 1.0, 0.0, None)
     assert rc == 1 and b"NULL" in L.load().pls_last_error()
