@@ -285,12 +285,41 @@ def self_launch(n_ranks: int) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+def profiler_grid_line(args):
+    """`--config profiler-grid`: the reference's only timing harness (experiments/profiler/main.py:50-82, :141-169; grid of
+    profiler/config.yaml:1-22) -- one timed block per grid point = basis construction + cost + PLS + particle initialisation +
+    T x `particles += pls.calculate_particle_update(particles, 1e-10)` through the drop-in API -- with the CPU oracle timed in
+    the same run.  Not BASELINE.json's metric (that is the default --config c2): printed as its own JSON line."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    import profiler_grid
+
+    sys.argv = [sys.argv[0], "--repeats", "5"] + (["--out", os.environ["PLS_PROFILER_GRID_OUT"]] if os.environ.get("PLS_PROFILER_GRID_OUT") else [])
+    summary = profiler_grid.main()
+    rows = summary["rows"]
+    default = [r for r in rows if (r["n"], r["m"], r["t"], r["j"]) == (100, 10, 10, 100)]
+    line = {
+        "metric": "construct + T steps of the reference's profiler protocol (experiments/profiler/main.py:50-82), seconds per block",
+        "config": {"workload": "experiments/profiler/config.yaml grid: N, J 100..1000, M, T 10..100 around N=100, M=10, T=10, J=100; "
+                               "Gaussian/identity and Bernoulli/sigmoid", "dtype": "f64"},
+        "n_gpus": 1, "grid_points": len(rows), "cpu_threads": summary["cpu_threads"], "cpu_model": summary["cpu_model"],
+        "default_point": {r["cost"]: {"gpu": r["gpu"], "cpu_oracle": r["cpu"], "gpu_over_cpu_total": r["gpu_total_over_cpu_total"]}
+                          for r in default},
+        "gpu_over_cpu_total": {"min": min(r["gpu_total_over_cpu_total"] for r in rows),
+                               "max": max(r["gpu_total_over_cpu_total"] for r in rows)},
+        "points_where_the_gpu_block_is_slower_than_the_cpu_oracle": summary["points_where_the_gpu_block_is_slower_than_the_cpu_oracle"],
+        "higher_is_better": False, "data": "synthetic (the reference's Curve1 regression data)",
+    }
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS) + ["profiler-grid"],
+                    help="c2 = configs[1] of BASELINE.json (the headline); profiler-grid = the reference's own timing protocol "
+                         "(experiments/profiler/config.yaml) through tools/profiler_grid.py, GPU beside the CPU oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workspace-gb", type=float, default=8.0, help="cap of the per-step G-chunk workspace")
     ap.add_argument("--converge-steps", type=int, default=4000,
@@ -309,6 +338,8 @@ def main():
                     help="development aid: run rank 0's particle shard of an N-GPU job on ONE GPU (no collectives); "
                          "the JSON line is marked emulated and is not a scaling result")
     args = ap.parse_args()
+    if args.config == "profiler-grid":
+        return profiler_grid_line(args)
     cfg = CONFIGS[args.config]
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -52,8 +52,11 @@ class OrthonormalBasis(PLSBasis):
         self.kernel = kernel
         self.x_induce = x_induce  # (M, D)
         m = x_induce.shape[0]
-        self.base_gram_induce = self.kernel.base_kernel(x1=x_induce, x2=x_induce)  # k(Z,Z) (M, M)   :36-38
-        base_gram_induce_train = self.kernel.base_kernel(x1=x_induce, x2=x_train)  # k(Z,X) (M, N)   :39-41
+        # (inputs go to the device ONCE: each host -> device copy costs ~14 us, and at the sizes of the reference's own
+        # benchmark -- experiments/profiler/config.yaml: 10 inducing points, 100 data points -- copies ARE the construction)
+        z_dev, x_dev = _dev(x_induce), _dev(x_train)
+        self.base_gram_induce = self.kernel.base_kernel(x1=z_dev, x2=z_dev)  # k(Z,Z) (M, M)   :36-38
+        base_gram_induce_train = self.kernel.base_kernel(x1=z_dev, x2=x_dev)  # k(Z,X) (M, N)   :39-41
         dev = self.base_gram_induce.device
         t_lap = lap("gram_s", t_lap)
         if spectrum is None:
@@ -84,10 +87,21 @@ class OrthonormalBasis(PLSBasis):
 
         assert_same_count(mk, group)  # (also with spectrum=: gather_particles / predictive_moments need one M_k)
         scaled = torch.multiply(torch.reciprocal(torch.sqrt(mk * eigenvalues))[None, :], eigenvectors)  # :63-68
-        self.eigenvalues = _dev(eigenvalues)
-        self.eigenvectors = _dev(eigenvectors)
-        self.scaled_eigenvectors = _dev(scaled)  # (M, Mk)
-        self._scaled_eigenvectors_lam = _dev(scaled * eigenvalues[None, :])  # V~ diag(lambda), prediction only
+        # one upload for the four host results (eigenvalues, eigenvectors, V~, V~ diag(lambda)), carved into views that each
+        # start on a 128-byte line
+        parts = [eigenvalues.reshape(-1), eigenvectors.reshape(-1), scaled.reshape(-1), (scaled * eigenvalues[None, :]).reshape(-1)]
+        offs, total = [], 0
+        for t in parts:
+            offs.append(total)
+            total += (t.numel() + 15) // 16 * 16
+        flat = torch.zeros(max(total, 1), dtype=torch.float64)
+        for t, o in zip(parts, offs):
+            flat[o:o + t.numel()] = t
+        flat = _dev(flat)
+        self.eigenvalues = flat[offs[0]:offs[0] + mk]
+        self.eigenvectors = flat[offs[1]:offs[1] + m * mk].view(m, mk)
+        self.scaled_eigenvectors = flat[offs[2]:offs[2] + m * mk].view(m, mk)  # (M, Mk)
+        self._scaled_eigenvectors_lam = flat[offs[3]:offs[3] + m * mk].view(m, mk)  # V~ diag(lambda), prediction only
         n = base_gram_induce_train.shape[1]
         self._n = n
         self._A = alloc_matrix(mk, n, dev)
@@ -288,6 +302,7 @@ class OrthonormalBasis(PLSBasis):
     def zero_step_sync(self) -> None:
         """Forget every counter set (after a failed or aborted launch): the next step allocates zeroed ones."""
         self.__dict__.pop("_sync_pool", None)
+        self.__dict__.pop("_eager", None)  # (the eager step binds a counter set)
 
     def _eta_word(self, step_size: float, device) -> torch.Tensor:
         """``step_size`` as a device word (pls_block_desc.eta), remembered per value: an eager caller steps with the same size
@@ -422,6 +437,62 @@ class OrthonormalBasis(PLSBasis):
 
         launch.keep_alive = (desc, cd, y, eta, self)
         return launch
+
+    def eager_step(self, cost, particles: torch.Tensor, step_size: float) -> torch.Tensor | None:
+        """dU of one step with the library's own noise for the drop-in loop `particles += pls.calculate_particle_update(...)`
+        (README.md:257-262, experiments/profiler/main.py:77-82): fused_step(cost, particles, step_size) with everything that
+        does not change from call to call bound once per (cost, J, step size, stream) -- descriptors, workspace, counters.
+        At the reference's own benchmark sizes a step is a 5 us kernel, and building the call afresh (~20 us of Python) is
+        what an iteration costs.  One draw from torch's global generator per call, like fused_step.  None: not applicable
+        (the caller takes fused_step)."""
+        if not (particles.is_cuda and particles.dtype == torch.float64 and particles.dim() == 2 and particles.stride(1) == 1):
+            return None
+        j = particles.shape[1]
+        if j == 0:
+            return None
+        y = cost.y_device()
+        key = (id(cost), j, float(step_size), L.stream_ptr(), y.data_ptr(), y._version, getattr(cost, "observation_noise", None),
+               self.j_offset, self.workspace_bytes, type(cost), type(cost.link_function), getattr(cost.link_function, "jitter", None))
+        bound = self.__dict__.get("_eager")
+        if bound is None or bound[0] != key:
+            cd = cost.desc()
+            gaussian = cd.cost == L.COST_GAUSSIAN and cd.link == L.LINK_IDENTITY
+            if gaussian:
+                self.prepare_gaussian(y)
+            lib = L.load()
+            desc = self._desc(with_gaussian=gaussian)
+            nd = L.NoiseDesc()
+            nd.kind, nd.step, nd.j_offset = L.NOISE_PHILOX, 0, int(self.j_offset)
+            if gaussian:
+                ws, ws_bytes, bd = None, 0, None
+            else:
+                need_min = lib.pls_onb_step_workspace_bytes(desc, j, 128)
+                need_full = lib.pls_onb_step_workspace_bytes(desc, j, self._n)
+                ws_bytes = max(need_min, min(need_full, self.workspace_bytes))
+                ws = torch.empty((ws_bytes + 7) // 8, dtype=torch.float64, device=particles.device)
+                bd = None
+                if self._one_launch_rank(cd):
+                    bd = L.BlockDesc()
+                    bd.block_cols, bd.eta = j, self._eta_word(step_size, particles.device).data_ptr()
+                    bd.step_sync = self._step_sync(j, particles.device).data_ptr()
+            bound = (key, (lib, desc, cd, y, nd, ws, ws_bytes, bd, self._B, self._c))
+            self._eager = bound
+        lib, desc, cd, y, nd, ws, ws_bytes, bd, _, _ = bound[1]
+        nd.seed = int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())
+        out = torch.empty_like(particles, memory_format=torch.contiguous_format)
+        ldu = particles.stride(0) if particles.shape[0] > 1 else max(j, particles.stride(0))
+        ws_ptr = None if ws is None else ws.data_ptr()
+        if bd is None:
+            rc = lib.pls_onb_step(desc, cd, y.data_ptr(), particles.data_ptr(), ldu, j, float(step_size), nd, out.data_ptr(), j,
+                                  L.OUT_DELTA, 0, None, ws_ptr, ws_bytes, key[3])
+        else:
+            rc = lib.pls_onb_step_blocks(desc, cd, y.data_ptr(), particles.data_ptr(), ldu, j, bd, nd, out.data_ptr(), j, L.OUT_DELTA, 0,
+                                         None, ws_ptr, ws_bytes, key[3])
+        if rc:
+            self.zero_step_sync()
+            self.__dict__.pop("_eager", None)
+            L.check(rc, "pls_onb_step")
+        return out
 
     def sums_step_launcher(self, cost, state: torch.Tensor, eta: torch.Tensor):
         """The step of a training loop for a cost WITHOUT the Gaussian algebra on a basis of at most 128 functions, as a

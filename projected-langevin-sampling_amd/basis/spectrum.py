@@ -106,7 +106,9 @@ def shared_spectrum(gram_scaled: torch.Tensor, eigh_where: str, group=None, src:
     packed = None
     if not active or rank == src:
         g = gram_scaled.detach().to(torch.float64)
-        lam, vec = torch.linalg.eigh(g.cpu() if eigh_where == "cpu" else g)  # orthonormal.py:46-48
+        from ..samplers import host_eigh
+
+        lam, vec = host_eigh(g) if eigh_where == "cpu" else torch.linalg.eigh(g)  # orthonormal.py:46-48
         lam, vec = lam.cpu(), vec.cpu()
         if canonical_signs:
             vec = canonicalise_signs(vec)

@@ -66,6 +66,11 @@ class PLS:
             assert (
                 particles.shape[0] == self.basis.approximation_dimension
             ), f"Particles have shape {particles.shape} but requires ({self.basis.approximation_dimension}, J) dimension."
+            if noise is None:  # the drop-in loop's call: everything but the addresses bound once (basis.eager_step)
+                eager = getattr(self.basis, "eager_step", None)
+                update = eager(self.cost, particles, step_size) if eager is not None else None
+                if update is not None:
+                    return update
             spec = NoiseSpec(injected=noise) if noise is not None else None
             return self.basis.fused_step(self.cost, particles, step_size, noise=spec)
         cost_derivative = self.calculate_cost_derivative(particles=particles)

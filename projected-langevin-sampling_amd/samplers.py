@@ -24,14 +24,47 @@ from .kernel import _dev
 #: matrix; the SAMPLE differs (another eigenvector gauge).
 DEFAULT_EIGH_DEVICE = "auto"
 
+#: ... except for SMALL matrices: under "auto" an n x n matrix with n <= this goes to host LAPACK wherever it lives.  The
+#: reference's own benchmark builds bases of 10 .. 100 inducing points (experiments/profiler/config.yaml:6-10), where the
+#: device call is all latency: rocSOLVER 0.6 ms at n = 10 and 2.0 ms at n = 60 .. 100 against 0.02 / 0.2 .. 0.6 ms on one
+#: host thread plus a 0.05 ms round trip (profiles/r05_profiler_grid.txt).  Also the reference's CPU gauge, for free.
+EIGH_HOST_BELOW = 128
+
 
 def resolve_eigh_device(requested: str | None, matrix: torch.Tensor) -> str:
-    """'cpu' or 'cuda' for an eigh of `matrix`: the explicit request, else DEFAULT_EIGH_DEVICE, 'auto' = where it lives"""
+    """'cpu' or 'cuda' for an eigh of `matrix`: the explicit request, else DEFAULT_EIGH_DEVICE; 'auto' = where it lives,
+    small matrices (EIGH_HOST_BELOW) on the host"""
     where = requested or DEFAULT_EIGH_DEVICE
     assert where in ("auto", "cpu", "cuda"), "eigh_device must be 'auto', 'cpu' or 'cuda'"
     if where == "auto":
-        where = "cuda" if matrix.is_cuda else "cpu"
+        where = "cuda" if (matrix.is_cuda and matrix.shape[-1] > EIGH_HOST_BELOW) else "cpu"
     return where
+
+
+class one_host_thread:
+    """Context: torch's intra-op pool narrowed to one thread.  A small LAPACK call (an eigh of a 50 x 50 matrix: 0.2 ms) is
+    pure overhead for a thread pool -- 130 ms measured with 8 threads on an 8-core container, 98 ms with the 128 threads
+    torch assumes on a GPU box whose cgroup grants 16 cores."""
+
+    def __enter__(self):
+        self.prev = torch.get_num_threads()
+        if self.prev != 1:
+            torch.set_num_threads(1)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev != 1:
+            torch.set_num_threads(self.prev)
+        return False
+
+
+def host_eigh(matrix: torch.Tensor):
+    """torch.linalg.eigh on the host; small matrices (n <= 256) on one thread"""
+    m = matrix.cpu()
+    if m.shape[-1] <= 256:
+        with one_host_thread():
+            return torch.linalg.eigh(m)
+    return torch.linalg.eigh(m)
 
 
 #: where the standard normals that sample_multivariate_normal colours come from.
@@ -74,7 +107,7 @@ def spectral_factor(cov: torch.Tensor, eigh_device: str | None = None) -> torch.
     Cholesky factor -- with whatever jitter -- has that law."""
     where = resolve_eigh_device(eigh_device, cov)
     c64 = cov.detach().to(torch.float64)
-    eigenvalues, eigenvectors = torch.linalg.eigh(c64.cpu() if where == "cpu" else _dev(c64))  # samplers.py:27
+    eigenvalues, eigenvectors = host_eigh(c64) if where == "cpu" else torch.linalg.eigh(_dev(c64))  # samplers.py:27
     eigenvalues = torch.clip(eigenvalues, 0, None)
     # (Q sqrt(Lambda))^T stored k-major: L[k][i] = Q[i][k] * sqrt(lam_k)
     return _dev((eigenvectors * torch.sqrt(eigenvalues)[None, :]).T)

@@ -255,3 +255,51 @@ def test_training_loop_is_one_launch_per_iteration_and_equals_the_plain_loop(P, 
         assert np.allclose(runs["pipelined"][1], runs["plain"][1], rtol=1e-11)
         assert torch.equal(runs["pipelined"][2], runs["plain"][2])
     assert 2 <= len(runs["plain"][1]) < 40, "the unstable run must stop somewhere in the middle"
+
+
+def test_the_drop_in_loop_takes_a_pre_bound_step_and_nothing_changes(P, route):
+    """`particles += pls.calculate_particle_update(particles, step_size)` (README.md:257-262, experiments/profiler/main.py:77-82)
+    goes through basis.eager_step -- descriptors, workspace and counters bound once per (cost, J, step size, stream) --: the same
+    updates as fused_step with the same draws from torch's generator, bit for bit, for the Gaussian fast path and for the
+    one-launch step; a new step size, observation noise or target vector binds afresh."""
+    pr = make_problem(400, 14, 52, 2, seed=23 + FUZZ_SEED)
+    _, gb = build_onb(P, pr)
+    mk = gb.approximation_dimension
+    u0 = cu(pr["u"][:mk].contiguous())
+    costs = make_costs(P, pr["y"], pr["fstar"], pr["gen"])
+    for name, _, gc in (costs[0], costs[2]):  # gaussian/identity, bernoulli/sigmoid
+        pls = P.pkg.PLS(gb, gc)
+        torch.manual_seed(7)
+        a = u0.clone()
+        for step in (1e-4, 1e-4, 3e-4, 3e-4):
+            a += pls.calculate_particle_update(a, step)
+        state_a = torch.get_rng_state()
+        torch.manual_seed(7)
+        b = u0.clone()
+        for step in (1e-4, 1e-4, 3e-4, 3e-4):
+            b += gb.fused_step(gc, b, step)
+        assert torch.equal(a, b) and torch.equal(state_a, torch.get_rng_state()), name
+        assert gb._eager[0][2] == 3e-4
+    # rebinding: observation noise (a field of the cost descriptor) and a new target vector
+    gauss = costs[0][2]
+    pls = P.pkg.PLS(gb, gauss)
+    torch.manual_seed(8)
+    first = pls.calculate_particle_update(u0, 1e-4)
+    pls.observation_noise = 2.0 * gauss.observation_noise
+    torch.manual_seed(8)
+    second = pls.calculate_particle_update(u0, 1e-4)
+    torch.manual_seed(8)
+    assert torch.equal(second, gb.fused_step(gauss, u0, 1e-4)) and not torch.equal(first, second)
+    gauss.y_train = gauss.y_train + 1.0
+    torch.manual_seed(8)
+    third = pls.calculate_particle_update(u0, 1e-4)
+    torch.manual_seed(8)
+    assert torch.equal(third, gb.fused_step(gauss, u0, 1e-4)) and not torch.equal(third, second)
+    # a strided view of a wider tensor and float32 particles still work (the latter through fused_step's promotion)
+    wide = cu(torch.randn(mk, 80, generator=pr["gen"]))
+    torch.manual_seed(9)
+    v = pls.calculate_particle_update(wide[:, 3:55], 1e-4)
+    torch.manual_seed(9)
+    assert torch.equal(v, gb.fused_step(gauss, wide[:, 3:55].contiguous(), 1e-4))
+    torch.manual_seed(9)
+    assert pls.calculate_particle_update(u0.float(), 1e-4).dtype == torch.float64

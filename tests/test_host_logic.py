@@ -325,6 +325,22 @@ def test_eigh_device_resolution():
     with pytest.raises(AssertionError):
         samplers.resolve_eigh_device("tpu", m)
 
+    class OnDevice:  # (no GPU here: what resolve_eigh_device looks at)
+        is_cuda = True
+
+        def __init__(self, n):
+            self.shape = (n, n)
+
+    # "auto": small matrices go to host LAPACK wherever they live (the reference's benchmark sizes: all latency on the device)
+    assert samplers.EIGH_HOST_BELOW == 128
+    assert samplers.resolve_eigh_device("auto", OnDevice(100)) == "cpu" and samplers.resolve_eigh_device("auto", OnDevice(128)) == "cpu"
+    assert samplers.resolve_eigh_device("auto", OnDevice(129)) == "cuda" and samplers.resolve_eigh_device("cuda", OnDevice(10)) == "cuda"
+    # the host call narrows torch's thread pool for small matrices and puts it back
+    before = torch.get_num_threads()
+    g = torch.randn(20, 20, dtype=torch.float64)
+    lam, vec = samplers.host_eigh(g @ g.T)
+    assert torch.get_num_threads() == before and torch.allclose((vec * lam) @ vec.T, g @ g.T, atol=1e-10)
+
 
 def test_sign_canonicalisation_and_spectrum_fingerprint(tmp_path, monkeypatch):
     """basis/spectrum.py: two eigensolvers that agree up to the sign of every eigenvector give ONE canonical matrix; the
