@@ -470,6 +470,7 @@ def main():
         torch.cuda.synchronize()
 
     region_ms = [0.0]  # device time of the last run's timed region (HIP events on the launch stream)
+    rank_dt = [0.0]    # wall time of the last run's timed region on every rank (rank order)
 
     def run(force_generic: bool, steps: int, warmup: int, timeline: bool):
         nonlocal ping, pong
@@ -500,10 +501,12 @@ def main():
         region_ms[0] = ev0.elapsed_time(ev1)
         if tl:
             tl.__exit__(None, None, None)
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = t.item()
+        rank_dt[:] = [dt]
+        if dist.is_initialized():
+            every = [None] * world
+            dist.all_gather_object(every, dt)  # (after the barrier: not in the timed region)
+            rank_dt[:] = every
+            dt = max(every)
         assert torch.isfinite(ping).all().item(), "particles diverged"
         return dt, (tl.summary() if tl else {})
 
@@ -512,6 +515,7 @@ def main():
     dt, tl = run(force_generic=True, steps=args.steps, warmup=args.warmup, timeline=True)
     ms_per_step = dt / args.steps * 1e3
     value = args.steps / dt
+    headline_rank_ms = [d / args.steps * 1e3 for d in rank_dt]
     log(f"like-for-like path: {ms_per_step:.2f} ms/step")
     # dominant kernels of the step: the two GEMM launches, or (rank <= 128) the one fused small-rank launch
     dom = ("small_rank_drift",) if "small_rank_drift" in tl else ("gemm_cost_deriv", "gemm_store")
@@ -592,6 +596,18 @@ def main():
                    "setup_breakdown": setup},
         "roofline": roofline,
     }
+    if dist.is_initialized():
+        # who ran: the process group as the ranks see it, and every rank's own clock over the headline region (`ms_per_step` is
+        # the slowest rank's)
+        seen = [None] * world
+        dist.all_gather_object(seen, {"rank": rank, "local_rank": local_rank, "device_index": device_index,
+                                      "device": torch.cuda.get_device_name(device_index),
+                                      "uuid": str(getattr(torch.cuda.get_device_properties(device_index), "uuid", ""))})
+        out["backend"] = str(dist.get_backend())
+        out["ranks_seen"] = seen
+        out["per_rank_ms_per_step"] = {"min": min(headline_rank_ms), "max": max(headline_rank_ms),
+                                       "slowest_rank": int(max(range(world), key=lambda r: headline_rank_ms[r])),
+                                       "all": [round(v, 4) for v in headline_rank_ms]}
     if gram_roofline is not None:
         out["roofline_gram"] = gram_roofline
     # ---- sustained: the same like-for-like step for >= 10 s, in windows of 50 steps (does the clock hold?) ----
@@ -882,6 +898,78 @@ def main():
         }
         log(f"inducing-point basis: {dti * 1e3:.2f} ms/step")
         del ipb, a, b
+    # ---- a multi-rank line proves its own shards (distributed.py:1-7: "1/2/4/8-GPU runs give identical particles").  After the
+    # timed sections every rank advances ITS columns of one seeded particle matrix by K fast-path steps and K like-for-like
+    # steps (library noise keyed by the GLOBAL column); the shards are gathered and rank 0 recomputes every shard on its own
+    # GPU -- the same column block, the same column offset, hence the same kernels: bit for bit or the line says so -- and the
+    # whole matrix unsharded (other tile shapes for a wider matrix: equal to rounding) ----
+    if dist.is_initialized() or shard_world > 1:
+        t_chk = time.perf_counter()
+        seed_chk = 97531
+        k_fast = 20 if cfg["cost"] == "gaussian" else 0
+        k_like = max(2, min(20, int(10.0 / max(ms_per_step * 1e-3 * shard_world, 1e-6))))
+        u_chk = torch.normal(0.0, 1.0, size=(mk, j_total), generator=torch.Generator().manual_seed(1), dtype=torch.float64)
+
+        def advance(u0, j_off):
+            prev = basis.j_offset
+            basis.j_offset = j_off
+            try:
+                cur, nxt = u0.contiguous().cuda(), None
+                nxt = torch.empty_like(cur)
+                for t in range(k_fast + k_like):
+                    basis.fused_step(cost, cur, eta, out=nxt, new_state=True, force_generic=t >= k_fast,
+                                     noise=NoiseSpec(seed=seed_chk, step=t, j_offset=j_off))
+                    cur, nxt = nxt, cur
+                e = basis.fused_particle_energy(cost, cur)
+                torch.cuda.synchronize()
+                return cur, e
+            finally:
+                basis.j_offset = prev
+
+        mine, e_mine = advance(u_chk[:, j0:j1], j0)
+        collective_ok = None
+        if dist.is_initialized():  # one real collective on device memory whatever the world size (RCCL under "nccl")
+            on_dev = "nccl" in str(dist.get_backend()).lower()
+            ones = torch.ones(4, dtype=torch.float64, device="cuda" if on_dev else "cpu")
+            dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+            collective_ok = bool((ones == float(world)).all().item())
+        if dist.is_initialized() and world > 1:
+            on_host = "nccl" not in str(dist.get_backend()).lower()  # (gloo gathers host tensors)
+            got_u = D.gather_particles(mine.cpu() if on_host else mine, j_total).cuda()
+            got_e = D.gather_particles((e_mine.cpu() if on_host else e_mine)[None, :], j_total).cuda()[0]
+            mean_e = D.mean_over_particles(e_mine.cpu() if on_host else e_mine, j_total)
+        else:
+            got_u, got_e, mean_e = mine, e_mine, None
+        if rank == 0:
+            max_abs, e_equal, shards = 0.0, True, []
+            for r in range(shard_world):
+                a, b = D.shard_bounds(j_total, r, shard_world)
+                if not dist.is_initialized() and r != 0:
+                    continue  # (an emulated shard run holds rank 0's columns only)
+                ref_u, ref_e = advance(u_chk[:, a:b], a)
+                lo = a if got_u.shape[1] == j_total else 0
+                d = float((got_u[:, lo:lo + (b - a)] - ref_u).abs().max().item())
+                max_abs = max(max_abs, d)
+                e_equal = e_equal and bool(torch.equal(got_e[lo:lo + (b - a)], ref_e))
+                shards.append({"rank": r, "columns": [a, b], "max_abs_diff": d})
+            whole_u, whole_e = advance(u_chk, 0)
+            cols = slice(0, j_total) if got_u.shape[1] == j_total else slice(j0, j1)
+            rel_unsharded = float(((got_u - whole_u[:, cols]).abs().max() / whole_u.abs().max()).item())
+            out["shard_check"] = {
+                "steps": {"gaussian_fast_path": k_fast, "like_for_like": k_like},
+                "max_abs_diff": max_abs, "energies_equal": e_equal, "shards": shards,
+                "max_rel_diff_vs_one_unsharded_matrix": rel_unsharded,
+                "mean_energy_all_reduce": mean_e, "all_reduce_of_ones_equals_world": collective_ok,
+                "mean_energy_rank0_recomputed": float(whole_e.double().sum().item() / j_total),
+                "seconds": time.perf_counter() - t_chk,
+                "note": "every rank advances its columns of one seeded particle matrix; gathered over the process group; rank 0 "
+                        "recomputes each shard (same columns, same global column offset: same kernels, bit for bit) and the "
+                        "unsharded matrix (wider tiles: equal to rounding)",
+            }
+            log(f"shard check: {k_fast} + {k_like} steps, max |diff| {max_abs:.1e}, energies equal {e_equal}, vs unsharded {rel_unsharded:.1e}")
+            assert max_abs == 0.0 and e_equal, "the ranks' shards are not the particles rank 0 computes for the same columns"
+        del u_chk, mine, e_mine, got_u, got_e
+        barrier()
     # ---- the reference's profiler protocol (experiments/profiler/main.py:41-82, :141-169): construction of kernel, basis,
     # cost and PLS, particle initialisation and T steps `particles += pls.calculate_particle_update(particles, eta)` timed
     # as ONE block ----

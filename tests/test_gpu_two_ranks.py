@@ -187,3 +187,32 @@ def test_two_ranks_on_one_gpu_equal_the_unsharded_run(tmp_path):
             assert torch.allclose(o["var"], s_whole.var(dim=1), rtol=1e-10)
     finally:
         torch.set_default_dtype(prev)
+
+
+def test_bench_line_of_two_ranks_checks_its_own_shards(tmp_path):
+    """`PLS_BENCH_BACKEND=gloo python bench.py --gpus 2` on the one card of this box (the control flow of the driver's
+    multi-GPU run, RCCL replaced by gloo): the JSON line carries the process group as the ranks saw it, every rank's own
+    clock, and a shard check -- the ranks' gathered particles are, bit for bit, what rank 0 computes for the same columns
+    (distributed.py:1-7), energies included."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PLS_BENCH_BACKEND="gloo")
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline", "--sustained-steps", "0", "--profiler-steps", "0", "--ipb-steps", "0",
+                          "--converge-steps", "0"], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert run.returncode == 0, run.stderr[-3000:]
+    line = json.loads(run.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["backend"] == "gloo"
+    assert [r["rank"] for r in line["ranks_seen"]] == [0, 1]
+    per = line["per_rank_ms_per_step"]
+    assert len(per["all"]) == 2 and per["min"] <= per["max"] and per["slowest_rank"] in (0, 1)
+    assert abs(per["max"] - line["ms_per_step"]) < 1e-6 * line["ms_per_step"]  # the line's value is the slowest rank's
+    chk = line["shard_check"]
+    assert chk["max_abs_diff"] == 0.0 and chk["energies_equal"] is True and chk["all_reduce_of_ones_equals_world"] is True
+    assert [s["columns"] for s in chk["shards"]] == [[0, 4096], [4096, 8192]]
+    assert chk["steps"]["gaussian_fast_path"] == 20 and chk["steps"]["like_for_like"] >= 2
+    assert chk["max_rel_diff_vs_one_unsharded_matrix"] < 1e-12
+    assert abs(chk["mean_energy_all_reduce"] - chk["mean_energy_rank0_recomputed"]) <= 1e-12 * abs(chk["mean_energy_rank0_recomputed"])
