@@ -268,7 +268,11 @@ typedef struct {
 const char *pls_last_error(void);
 int pls_abi_version(void);
 
-/* Process-wide tuning options (the defaults are what bench.py measures; tests flip them to reach both code paths).
+/* Route options (the defaults are what bench.py measures; tests flip them to reach both code paths).  NOTHING here is
+ * process-wide: every option is a value of the CALLING THREAD (each thread starts from the defaults), and a launch takes the
+ * routes of the thread that makes the call -- two bases driven from two host threads can choose differently, and a test
+ * that flips an option disturbs no other thread.  (The per-launch timeline of pls_timeline_begin / _end and the text behind
+ * pls_last_error are per thread as well.)
  *   PLS_OPT_SMALL_RANK_MAX: bases with at most this many functions (0..128, default 128) take the fused small-rank
  *   kernels (F, d cost / d f and the back-projection in ONE pass: the N x J matrices F and G are never written);
  *   larger ranks, or 0, take the two-GEMM path.  Results agree to rounding, not bit for bit. */

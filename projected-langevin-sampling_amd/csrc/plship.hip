@@ -38,6 +38,15 @@ extern "C" void pls_debug_set_stamp_buffer(unsigned long long *p) { g_stamp_buff
 thread_local std::string g_last_error;
 thread_local Timeline g_tl;
 
+// A route option (pls_set_option): one value PER CALLING THREAD, starting from the default -- a launch takes the routes of
+// the thread that makes the call, so two bases driven by two host threads can choose differently and nothing is process-wide
+// ("no global state, thread-compatible per context").
+struct RouteOption {
+  int64_t v;
+  int64_t load() const { return v; }
+  void store(int64_t x) { v = x; }
+};
+
 // ---------------------------------------------------------------------------------------------------------------
 // GEMM epilogues that need the cost functions / the noise generator
 // ---------------------------------------------------------------------------------------------------------------
@@ -545,8 +554,8 @@ static int64_t plan_split_k(int64_t I, int64_t J, int64_t K, int64_t *kchunk) {
 }
 
 // ---- few output tiles: 64 x 64 tiles with the k range split over wave groups inside the workgroup (gemm_tn_f64_kg.h) ----
-static std::atomic<int64_t> g_ksplit_mode{1};          // pls_set_option(PLS_OPT_KSPLIT_MODE): 0 off, 1 auto, 2 / 3 force 2 / 1 k-groups
-static std::atomic<int64_t> g_ksplit_max_tiles{256};   // pls_set_option(PLS_OPT_KSPLIT_MAX_TILES): 128 x 128 tiles below which it is taken
+static thread_local RouteOption g_ksplit_mode{1};          // pls_set_option(PLS_OPT_KSPLIT_MODE): 0 off, 1 auto, 2 / 3 force 2 / 1 k-groups
+static thread_local RouteOption g_ksplit_max_tiles{256};   // pls_set_option(PLS_OPT_KSPLIT_MAX_TILES): 128 x 128 tiles below which it is taken
 
 enum GemmCfg { CFG_BIG = 0, CFG_SMALL = 1, CFG_KG1 = 2, CFG_KG2 = 3 };
 
@@ -588,7 +597,7 @@ static int launch_gemm_kg(GemmShape g, const Epi &epi, hipStream_t st) {
 
 // Balanced triangular product (gemm_tn_f64_kg_tri_kernel): tile rows paired, every pair shared by two workgroups with equal
 // loads, the heavy tile finished by whichever arrives second.  scratch: the caller's, zero flag words on entry and on exit.
-static std::atomic<int64_t> g_tri_balance{1};  // pls_set_option(PLS_OPT_TRI_BALANCE): 0 off (one tile per workgroup), 1 on
+static thread_local RouteOption g_tri_balance{1};  // pls_set_option(PLS_OPT_TRI_BALANCE): 0 off (one tile per workgroup), 1 on
 
 struct TriScratch {
   void *ptr = nullptr;
@@ -638,7 +647,7 @@ static int launch_gemm_any(const double *L, int64_t ldl, const double *R, int64_
 }
 
 // ---- a row count that is not a multiple of 128: equal-height tiles, 16-row blocks dealt to the wave rows (gemm_tn_f64_rows.h) ----
-static std::atomic<int64_t> g_row_blocks_mode{1};  // pls_set_option(PLS_OPT_ROW_BLOCKS): 0 off (the round-2 pieces), 1 on
+static thread_local RouteOption g_row_blocks_mode{1};  // pls_set_option(PLS_OPT_ROW_BLOCKS): 0 off (the round-2 pieces), 1 on
 
 static bool gemm_rows_ok(const double *L, int64_t ldl, const double *R, int64_t ldr, int64_t I, int64_t J, int64_t K, int64_t ldc,
                          int64_t nsplit) {
@@ -1442,13 +1451,13 @@ static int validate_noise(const pls_noise_desc *n, int64_t rows, int64_t j) {
 }
 
 // ---- small projection ranks: fused kernels (small_rank.h) -------------------------------------------------------
-static std::atomic<int64_t> g_small_rank_max{128};  // pls_set_option(PLS_OPT_SMALL_RANK_MAX)
-static std::atomic<int64_t> g_ipb_explicit_inverse{0};  // pls_set_option(PLS_OPT_IPB_EXPLICIT_INVERSE)
-static std::atomic<int64_t> g_kg_noise_pregen{1};      // pls_set_option(PLS_OPT_KG_NOISE_PREGEN): Philox noise in front of the k-split kernel's k-loop
-static std::atomic<int64_t> g_energy_fused_finish{1};   // pls_set_option(PLS_OPT_ENERGY_FUSED_FINISH): honour pls_block_desc.energy_sync
-static std::atomic<int64_t> g_ipb_step_operator{1};     // pls_set_option(PLS_OPT_IPB_STEP_OPERATOR): 1 = Pt route when the descriptor has it
-static std::atomic<int64_t> g_small_rank_step{1};  // pls_set_option(PLS_OPT_SMALL_RANK_STEP): 0 never, 1 launch-bound problems, 2 wherever it applies
-static std::atomic<int64_t> g_solve_mode{1};  // pls_set_option(PLS_OPT_SOLVE_MODE): 0 block substitution, 1 inverse-factor products where available
+static thread_local RouteOption g_small_rank_max{128};  // pls_set_option(PLS_OPT_SMALL_RANK_MAX)
+static thread_local RouteOption g_ipb_explicit_inverse{0};  // pls_set_option(PLS_OPT_IPB_EXPLICIT_INVERSE)
+static thread_local RouteOption g_kg_noise_pregen{1};      // pls_set_option(PLS_OPT_KG_NOISE_PREGEN): Philox noise in front of the k-split kernel's k-loop
+static thread_local RouteOption g_energy_fused_finish{1};   // pls_set_option(PLS_OPT_ENERGY_FUSED_FINISH): honour pls_block_desc.energy_sync
+static thread_local RouteOption g_ipb_step_operator{1};     // pls_set_option(PLS_OPT_IPB_STEP_OPERATOR): 1 = Pt route when the descriptor has it
+static thread_local RouteOption g_small_rank_step{1};  // pls_set_option(PLS_OPT_SMALL_RANK_STEP): 0 never, 1 launch-bound problems, 2 wherever it applies
+static thread_local RouteOption g_solve_mode{1};  // pls_set_option(PLS_OPT_SOLVE_MODE): 0 block substitution, 1 inverse-factor products where available
 int64_t solve_mode() { return g_solve_mode.load(); }
 
 static bool small_rank_ok(const double *Lb, int64_t ldlb, int64_t kdim) {

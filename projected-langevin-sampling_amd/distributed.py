@@ -61,7 +61,11 @@ class EnergyMean:
       * otherwise (several hosts, or board=False): a blocking all-reduce of one double per iteration on the group.
 
     Slot t % 16 is reused at iteration t + 16, which a rank only reaches after every rank has published -- hence finished
-    reading -- iteration t + 15 > t.  ``timeout_s`` bounds the wait for a rank that died."""
+    reading -- iteration t + 15 > t.  A rank that leaves its loop through an exception says so on the board (``abort``: one
+    word per rank behind the ring; trainers.py calls it on the way out), and its peers raise within a fraction of a second
+    instead of polling for a value that will never come; ``timeout_s`` bounds the wait for a rank that died without a word.
+    The board relies on x86-64's store ordering (value, then sequence number, two plain stores): on other hosts it is not
+    used and the exchange is the all-reduce."""
 
     RING = 16
 
@@ -73,9 +77,19 @@ class EnergyMean:
         self.world = dist.get_world_size(group) if on else 1
         self.rank = dist.get_rank(group) if on else 0
         self._t = 0
-        self._seq = self._val = self._map = None
+        self._seq = self._val = self._map = self._abort = None
+        self._dead = None  # why this exchange can no longer be used (an abort seen or sent)
         if self.world > 1 and board is not False:
-            self._open_board(required=board is True)
+            import platform
+
+            if platform.machine().lower() in ("x86_64", "amd64"):
+                self._open_board(required=board is True)
+            elif board is True:
+                raise RuntimeError("EnergyMean(board=True): the shared-memory board needs x86-64's store ordering")
+
+    def _on_device(self) -> bool:
+        """Tensors of a collective live on the GPU under RCCL ("nccl", also as part of a composite backend string)"""
+        return "nccl" in str(dist.get_backend(self.group)).lower()
 
     def _open_board(self, required: bool) -> None:
         """Collective over the group.  Every step that can fail locally (creating, mapping the file) is followed by an
@@ -89,7 +103,7 @@ class EnergyMean:
 
         def all_agree(ok: bool) -> bool:
             flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
-            if dist.get_backend(self.group) == "nccl":
+            if self._on_device():
                 flag = flag.cuda()
             dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
             return bool(flag.item())
@@ -101,7 +115,8 @@ class EnergyMean:
                 raise RuntimeError("EnergyMean(board=True): the ranks of the group do not share one host with /dev/shm")
             return
         name = [None]
-        nbytes = 2 * self.RING * self.world * 8
+        nwords = 2 * self.RING * self.world + self.world  # sequence numbers, values, one abort word per rank
+        nbytes = nwords * 8
         if self.rank == 0:
             try:
                 path = f"/dev/shm/pls_energy_{os.getpid()}_{uuid.uuid4().hex[:12]}"
@@ -112,24 +127,28 @@ class EnergyMean:
                 name[0] = None
         dist.broadcast_object_list(name, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
         mapped = None
-        if name[0] is not None:
-            try:
-                mapped = np.memmap(name[0], dtype=np.int64, mode="r+", shape=(2, self.RING, self.world))
-            except (OSError, ValueError):
-                mapped = None
-        ok = all_agree(mapped is not None)  # (also the point after which the file's name can go: everybody has mapped it, or given up)
-        if self.rank == 0 and name[0] is not None:
-            try:
-                os.unlink(name[0])
-            except OSError:
-                pass
+        try:
+            if name[0] is not None:
+                try:
+                    mapped = np.memmap(name[0], dtype=np.int64, mode="r+", shape=(nwords,))
+                except (OSError, ValueError):
+                    mapped = None
+            ok = all_agree(mapped is not None)  # (also the point after which the file's name can go: everybody has mapped it, or given up)
+        finally:  # whatever happened above -- a failed collective included -- the name does not stay behind in /dev/shm
+            if self.rank == 0 and name[0] is not None:
+                try:
+                    os.unlink(name[0])
+                except OSError:
+                    pass
         if not ok:
             if required:
                 raise RuntimeError("EnergyMean(board=True): the board could not be created or mapped on every rank")
             return
         self._map = mapped
-        self._seq = mapped[0]
-        self._val = mapped[1].view(np.float64)
+        ring = self.RING * self.world
+        self._seq = mapped[:ring].reshape(self.RING, self.world)
+        self._val = mapped[ring:2 * ring].view(np.float64).reshape(self.RING, self.world)
+        self._abort = mapped[2 * ring:]
 
     @property
     def uses_board(self) -> bool:
@@ -143,9 +162,11 @@ class EnergyMean:
         iteration, in the same order."""
         if self.world == 1:
             return float(local_sum) / self.number_of_particles
+        if self._dead is not None:
+            raise RuntimeError(f"EnergyMean: {self._dead}")
         if self._seq is None:
             s = torch.tensor([float(local_sum)], dtype=torch.float64)
-            if dist.get_backend(self.group) == "nccl":
+            if self._on_device():
                 s = s.cuda()
             dist.all_reduce(s, op=dist.ReduceOp.SUM, group=self.group)
             return s.item() / self.number_of_particles
@@ -159,6 +180,10 @@ class EnergyMean:
         spins, t0 = 0, None
         while not bool((row == tag).all()):
             spins += 1
+            if spins % 64 == 0 and bool(self._abort.any()):
+                gone = [r for r in range(self.world) if self._abort[r]]
+                self._dead = f"rank(s) {gone} left the training loop through an exception at or before iteration {t}"
+                raise RuntimeError(f"EnergyMean: {self._dead}")
             if spins % 4096 == 0:
                 t0 = t0 or time.monotonic()
                 if time.monotonic() - t0 > self.timeout_s:
@@ -170,6 +195,17 @@ class EnergyMean:
             total += float(self._val[slot, r])
         self._t = t + 1
         return total / self.number_of_particles
+
+
+def _energy_mean_abort(self, reason: str = "") -> None:
+    """This rank leaves its loop through an exception: tell the board, so that the peers polling for its next value raise at
+    once (idempotent; a no-op without a board -- a blocking all-reduce fails through the process group's own time-out)."""
+    if self._abort is not None:
+        self._abort[self.rank] = 1
+    self._dead = self._dead or f"this rank aborted the exchange{': ' + reason if reason else ''}"
+
+
+EnergyMean.abort = _energy_mean_abort
 
 
 def predictive_moments(local_samples: torch.Tensor, number_of_particles: int, group=None) -> Tuple[torch.Tensor, torch.Tensor]:

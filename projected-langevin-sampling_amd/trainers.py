@@ -388,6 +388,11 @@ def _train_pls_in_flight(pls: PLS, particles: torch.Tensor, number_of_epochs: in
                 final = bufs[(t + 1) % NB]
                 break
             energy_potentials.append(energy_potential)
+    except BaseException as exc:
+        # a J-sharded run: the other ranks are polling for this rank's next energy sum -- tell them it will not come
+        if mean is not None and hasattr(mean, "abort"):
+            mean.abort(repr(exc)[:200])
+        raise
     finally:
         # up to `depth` launches are still queued: they write the pinned slots and the rotating buffers, which must not go
         # back to torch's allocators (on ANY exit: a raising early stopper, a failed launch) before they have drained

@@ -129,3 +129,34 @@ def test_product_package_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
                 assert "/root/reference" not in text, f
+
+
+def test_route_options_belong_to_the_calling_thread():
+    """pls_set_option: a value of the CALLING thread (no global state, thread-compatible per context) -- another
+    thread starts from the defaults, and what it sets stays with it."""
+    import threading
+
+    import projected_langevin_sampling_amd as pkg
+
+    L = pkg._lib
+    lib = L.load()
+    assert lib.pls_get_option(L.OPT_SMALL_RANK_STEP) == 1 and lib.pls_get_option(L.OPT_TRI_BALANCE) == 1
+    assert lib.pls_set_option(L.OPT_SMALL_RANK_STEP, 2) == 0 and lib.pls_set_option(L.OPT_TRI_BALANCE, 0) == 0
+    seen = {}
+
+    def other():
+        seen["start"] = (lib.pls_get_option(L.OPT_SMALL_RANK_STEP), lib.pls_get_option(L.OPT_TRI_BALANCE))
+        lib.pls_set_option(L.OPT_SMALL_RANK_STEP, 0)
+        lib.pls_set_option(L.OPT_SMALL_RANK_MAX, 64)
+        seen["end"] = (lib.pls_get_option(L.OPT_SMALL_RANK_STEP), lib.pls_get_option(L.OPT_SMALL_RANK_MAX))
+
+    t = threading.Thread(target=other)
+    t.start()
+    t.join()
+    try:
+        assert seen == {"start": (1, 1), "end": (0, 64)}
+        assert lib.pls_get_option(L.OPT_SMALL_RANK_STEP) == 2 and lib.pls_get_option(L.OPT_TRI_BALANCE) == 0
+        assert lib.pls_get_option(L.OPT_SMALL_RANK_MAX) == 128
+    finally:
+        lib.pls_set_option(L.OPT_SMALL_RANK_STEP, 1)
+        lib.pls_set_option(L.OPT_TRI_BALANCE, 1)

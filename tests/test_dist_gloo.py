@@ -221,13 +221,36 @@ def _energy_board_worker(rank, world, port, out_dir):
     assert all(torch.equal(everyone[0], e) for e in everyone), "every rank holds the same bits (the same stop decisions)"
     dist.barrier()
     assert not [f for f in os.listdir("/dev/shm") if f.startswith("pls_energy_")], "the board's file name is gone (rank 0 unlinks it)"
+    # a rank that leaves its loop through an exception (iteration 5) says so on the board: its peers raise at once instead of
+    # polling for ``timeout_s`` (600 s by default) -- the way out trainers._train_pls_in_flight takes
+    again = D.EnergyMean(j, board=True, timeout_s=120.0)
+    t0 = time.monotonic()
+    try:
+        for t in range(20):
+            if rank == 1 and t == 5:
+                again.abort("ValueError('a failing launch')")
+                raise ValueError("a failing launch")
+            again.reduce_local_sum(float(t))
+        raise SystemExit("the peers of an aborted rank went on")
+    except ValueError:
+        assert rank == 1
+    except RuntimeError as e:
+        assert rank != 1 and "rank(s) [1] left the training loop" in str(e), str(e)
+    assert time.monotonic() - t0 < 10.0, "peers must learn of the abort from the board, not from the time-out"
+    try:  # and the exchange stays unusable: nobody takes half a ring for a result
+        again.reduce_local_sum(0.0)
+        raise SystemExit("an aborted exchange accepted another value")
+    except RuntimeError:
+        pass
+    dist.barrier()
     dist.destroy_process_group()
     open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
 
 
 def test_energy_mean_over_a_shared_memory_board(tmp_path):
     """distributed.EnergyMean: the per-iteration exchange of the ranks' local energy sums through /dev/shm (ranks of one
-    node), against the sum in rank order and the all-reduce fallback; 3 ranks, 400 iterations, deliberately skewed ranks."""
+    node), against the sum in rank order and the all-reduce fallback; 3 ranks, 400 iterations, deliberately skewed ranks;
+    then a rank that raises at iteration 5: its peers fail within seconds (the abort word), not after the time-out."""
     port = _free_port()
     mp.spawn(_energy_board_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
     assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(3))
