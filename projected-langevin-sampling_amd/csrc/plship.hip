@@ -1710,9 +1710,14 @@ static int fast_step_launch(const FastOp &op, const double *U, int64_t ldu, int6
                             size_t workspace_bytes, hipStream_t st, const char *who, double *esums = nullptr,
                             uint32_t *esync = nullptr, const EnergyLag &lag = EnergyLag{}) {
   const bool big = pick_gemm_cfg(op.B, op.ldb, U, ldu, op.mk, j, op.mk) == CFG_BIG;
-  const int64_t parts = big ? 2 * cdiv(op.mk, 128) : cdiv(op.mk, 64);
+  const int64_t parts = big ? 2 * cdiv(op.mk, 128) : cdiv(op.mk, 64);  // partial rows THIS launch's tiling leaves
+  // A LAGGED buffer is finished by another launch, whose tiling may differ (the choice follows the alignment and leading
+  // dimension of its own particle tensor and the k-split options): such a buffer always holds 2 cdiv(mk, 128) rows -- what
+  // pls_energy_partials_bytes sizes it for -- and a launch that writes fewer zeroes the rest, so that whoever finishes it adds
+  // the same rows whatever either launch chose.
+  const int64_t lag_rows = 2 * cdiv(op.mk, 128);
   if (lag.flush) {  // no step: the partial rows of the LAST launch of a loop are finished by the finishing kernel
-    hipLaunchKernelGGL(gaussian_energy_finish_kernel, dim3((unsigned)cdiv(j, 256)), dim3(256), 0, st, lag.partials_prev, j, parts, j,
+    hipLaunchKernelGGL(gaussian_energy_finish_kernel, dim3((unsigned)cdiv(j, 256)), dim3(256), 0, st, lag.partials_prev, j, lag_rows, j,
                        lag.e_prev, op.yscale, op.yty, lag.sums_prev);
     return check_launch("gaussian_energy_finish");
   }
@@ -1725,8 +1730,12 @@ static int fast_step_launch(const FastOp &op, const double *U, int64_t ldu, int6
   }
   EpiLangevinGaussian e{out, ldo, U, ldu, op.c, op.lam, etap, op.inv_noise, out_mode, nz, epart, j, 2, big ? 128 : 64, {}, {}};
   e.pregen_flag = g_kg_noise_pregen.load() != 0;
-  if (lag.partials_prev) e.prev = EpiLangevinGaussian::Prev{lag.partials_prev, lag.e_prev, lag.sums_prev, op.yscale, op.yty, (int)parts};
+  if (lag.partials_prev) e.prev = EpiLangevinGaussian::Prev{lag.partials_prev, lag.e_prev, lag.sums_prev, op.yscale, op.yty, (int)lag_rows};
   const bool lagged = lag.partials_out != nullptr;  // (the NEXT launch, or a flush, finishes this launch's energies)
+  if (lagged && parts < lag_rows) {
+    hipError_t me = hipMemsetAsync(lag.partials_out + parts * j, 0, (size_t)(lag_rows - parts) * j * sizeof(double), st);
+    if (me != hipSuccess) return fail(PLS_ERR_HIP, "%s: hipMemsetAsync: %s", who, hipGetErrorString(me));
+  }
   const bool fused_finish = !lagged && energy_in && esync && g_energy_fused_finish.load() != 0;
   if (fused_finish)  // the step launch finishes the energies itself (pls_block_desc.energy_sync)
     e.fin = EpiLangevinGaussian::Finish{esync, energy_in, esums, op.yscale, op.yty, (int)parts, (int)cdiv(op.mk, big ? 128 : 64)};

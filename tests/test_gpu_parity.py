@@ -880,6 +880,46 @@ def test_fused_energy_finish_equals_the_finishing_launch(P, mk, j):
     assert torch.equal(out2, out1) and torch.equal(e2, e1) and torch.equal(s2, s1)
 
 
+
+def test_lagged_energies_do_not_depend_on_the_tilings_of_the_two_launches(P):
+    """Lagged energies: launch k + 1 finishes the partial rows launch k left -- and the two launches may take different tilings:
+    the choice follows the alignment and leading dimension of each launch's OWN particle tensor.  A loop whose first buffer is
+    the caller's tensor -- an offset slice of a wider one: unaligned, odd leading dimension -- while its other buffers are
+    fresh allocations, with the k-split kernel forced wherever the operands are aligned, at a rank where the two tilings leave
+    different numbers of partial rows (192 functions: 3 rows of 64 against 2 x 2 of 128).  Same energies, bit for bit, as the
+    loop whose launches finish their own."""
+    from projected_langevin_sampling_amd import trainers
+
+    L = P.pkg._lib
+    lib = L.load()
+    g = torch.Generator().manual_seed(12 + FUZZ_SEED)
+    mk, n, j = 192, 900, 96
+    basis = P.basis.OrthonormalBasis.from_projection(cu(torch.randn(mk, n, generator=g) / math.sqrt(n)), cu(torch.rand(mk, generator=g) + 0.5))
+    y = torch.randn(n, generator=g)
+    pls = P.pkg.PLS(basis, P.costs.GaussianCost(0.3, y, P.links.IdentityLinkFunction()))
+    wide = cu(torch.randn(mk, j + 3, generator=g))
+    prev_mode = lib.pls_get_option(L.OPT_KSPLIT_MODE)
+    L.check(lib.pls_set_option(L.OPT_KSPLIT_MODE, 2), "pls_set_option")
+    try:
+        runs = {}
+        for lagged in (False, True):
+            keep = trainers.LAGGED_ENERGIES
+            trainers.LAGGED_ENERGIES = lagged
+            try:
+                torch.manual_seed(5)
+                start = wide.clone()[:, 1:1 + j]  # stride(1) == 1, leading dimension j + 3 (odd), first element 8-byte aligned only
+                assert start.stride(0) == j + 3 and start.data_ptr() % 16 == 8
+                u, e = P.pkg.train_pls(pls, start, 9, 0.05, 1e9)
+                runs[lagged] = (u.clone(), e)
+            finally:
+                trainers.LAGGED_ENERGIES = keep
+        assert runs[True][1] == runs[False][1] and torch.equal(runs[True][0], runs[False][0])
+        want = [pls.calculate_energy_potential(runs[True][0])]
+        assert abs(runs[True][1][-1] - want[0]) <= 1e-10 * abs(want[0])
+    finally:
+        L.check(lib.pls_set_option(L.OPT_KSPLIT_MODE, prev_mode), "pls_set_option")
+
+
 @pytest.mark.parametrize("basis_kind,mk,j", [("onb", 96, 300), ("onb", 256, 1024), ("onb", 1024, 2048), ("ipb", 200, 520)])
 def test_lagged_energies_equal_the_finishing_forms(P, basis_kind, mk, j):
     """trainers.LAGGED_ENERGIES (pls_block_desc.energy_partials ...): launch k + 1 finishes the energies of launch k at its
