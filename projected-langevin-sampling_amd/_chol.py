@@ -29,19 +29,38 @@ class CholeskyFactor:
         self.Lc, self.LcT, self.Sf, self.Sb, self.jitter = lc, lct, sf, sb, jitter
         self.m = lc.shape[0]
         self.Linv = self.LinvT = None
-        self._tri_scratch = None
+        self._tri_scratch: dict = {}
+
+    #: bytes at the head of a scratch that hold the flag words of the balanced products (csrc/gemm_tn_f64_kg.h, kKgTriFlagBytes)
+    TRI_FLAG_BYTES = 16384
 
     def tri_scratch(self) -> torch.Tensor | None:
-        """Scratch of the balanced triangular products (pls_chol_desc.tri_scratch): allocated ONCE, zeroed, at the size
-        the largest product that takes the few-tiles kernel needs (fewer than 256 tiles of 128 x 128: <= 32 MB whatever M
-        is), so that its address never changes under a captured graph; None when M has a single 64-row tile row (nothing
-        to balance).  The library leaves its flag words zero after every call."""
-        if self._tri_scratch is None and self.m > 64:
+        """Scratch of the balanced triangular products (pls_chol_desc.tri_scratch): allocated once PER STREAM, zeroed, at the
+        size the largest product that takes the few-tiles kernel needs (fewer than 256 tiles of 128 x 128: <= 32 MB whatever
+        M is), so that its address never changes under a captured graph -- launches on one stream are ordered, an eager call
+        beside a graph replay on another stream must not share flag words --; None when M has a single 64-row tile row
+        (nothing to balance).  The library leaves the flag words zero after every call; after a FAILED call they are zeroed
+        again (reset_tri_scratch), because stale flags would make every later product silently wrong."""
+        if self.m <= 64:
+            return None
+        key = L.stream_ptr() if torch.cuda.is_available() else 0
+        sc = self._tri_scratch.get(key)
+        if sc is None:
             rows128 = (self.m + 127) // 128
             j_max = 128 * max(1, -(-256 // rows128))
             nbytes = int(L.load().pls_tri_scratch_bytes(self.m, j_max))
-            self._tri_scratch = torch.zeros((nbytes + 7) // 8, dtype=torch.float64, device=self.Lc.device)
-        return self._tri_scratch
+            sc = self._tri_scratch[key] = torch.zeros((nbytes + 7) // 8, dtype=torch.float64, device=self.Lc.device)
+        return sc
+
+    def reset_tri_scratch(self) -> None:
+        """Zero the flag words of every scratch (after a failed or aborted launch)."""
+        for sc in self._tri_scratch.values():
+            sc[: self.TRI_FLAG_BYTES // 8].zero_()
+
+    def _check(self, rc: int, what: str) -> None:
+        if rc != 0:
+            self.reset_tri_scratch()
+            L.check(rc, what)
 
     def build_inverse(self) -> "CholeskyFactor":
         """Linv = Lc^-1 and its transpose (pls_chol_build_inverse: the identity through the block forward substitution).
@@ -80,8 +99,8 @@ class CholeskyFactor:
         v = torch.empty((self.m, j), dtype=torch.float64, device=u.device)
         if j:
             ws = torch.empty((self.m, j), dtype=torch.float64, device=u.device) if self.Linv is not None else None
-            L.check(L.load().pls_chol_solve_ws(self.desc(), u.data_ptr(), L.ld(u), j, v.data_ptr(), max(j, 1), L.ptr(ws),
-                                               0 if ws is None else ws.numel() * 8, L.stream_ptr()), "pls_chol_solve_ws")
+            self._check(L.load().pls_chol_solve_ws(self.desc(), u.data_ptr(), L.ld(u), j, v.data_ptr(), max(j, 1), L.ptr(ws),
+                                                   0 if ws is None else ws.numel() * 8, L.stream_ptr()), "pls_chol_solve_ws")
         return v
 
     def forward_solve(self, rhs: torch.Tensor) -> torch.Tensor:
@@ -91,8 +110,8 @@ class CholeskyFactor:
         j = u.shape[1]
         y = torch.empty((self.m, j), dtype=torch.float64, device=u.device)
         if j:
-            L.check(L.load().pls_chol_forward_solve(self.desc(), u.data_ptr(), L.ld(u), j, y.data_ptr(), max(j, 1),
-                                                    L.stream_ptr()), "pls_chol_forward_solve")
+            self._check(L.load().pls_chol_forward_solve(self.desc(), u.data_ptr(), L.ld(u), j, y.data_ptr(), max(j, 1),
+                                                        L.stream_ptr()), "pls_chol_forward_solve")
         return y
 
     def colour(self, xi: torch.Tensor) -> torch.Tensor:

@@ -411,6 +411,12 @@ __host__ __device__ inline size_t kg_tri_scratch_bytes(int64_t I, int64_t J) {
 // its stores (s_waitcnt vmcnt(0)), the workgroup's barrier collects the waves, and ONE lane bumps the flag with an
 // agent-scope atomic; the reader learns of the partial sum from the value its own atomic add returned (or from an sc1 load
 // of the flag) and loads every byte of it with sc1 loads, which are served past the L1: no cache-wide operation anywhere.
+// The hand-over between workgroups below (write-through `sc1` stores, a drained store queue, one relaxed agent-scope atomic,
+// `sc1` loads past the L1) is written against the cache hierarchy of gfx942 / gfx950 (per-XCD L2s that are not coherent with
+// each other, write-through vector L1s): another target needs its own protocol, not a silent recompile.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "the inter-workgroup hand-over of libplship is written for gfx942 / gfx950"
+#endif
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 constexpr int kKgSc1 = 16;  // aux bit of the raw buffer instructions: sc1
 

@@ -35,6 +35,12 @@
 #include "philox.h"
 #include "step_params.h"
 
+// The hand-over between workgroups below (write-through `sc1` stores, a drained store queue, one relaxed agent-scope atomic,
+// `sc1` loads past the L1) is written against the cache hierarchy of gfx942 / gfx950 (per-XCD L2s that are not coherent with
+// each other, write-through vector L1s): another target needs its own protocol, not a silent recompile.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "the inter-workgroup hand-over of libplship is written for gfx942 / gfx950"
+#endif
 namespace plship {
 
 typedef double srs_double4_t __attribute__((ext_vector_type(4)));

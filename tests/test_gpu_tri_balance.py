@@ -192,3 +192,43 @@ def test_inducing_point_step_on_a_narrow_shard_against_the_oracle(P, j):
     assert relerr(results[1, 1], results[0, 1]) < 1e-10  # the folded operator against solve-then-multiply
     sc = gi._chol.tri_scratch()
     assert int(sc.view(torch.int32)[:4096].abs().sum()) == 0 and bool((sc.view(torch.int64)[2048:] != 0).any())
+
+
+def test_stale_flag_words_are_repaired_and_streams_do_not_share_a_scratch(P):
+    """The balanced products meet through flag words that must be zero on entry.  A factor keeps one scratch per stream (an
+    eager call beside a graph replay on another stream must not share flags); poisoned flags -- what a launch that died half
+    way leaves -- make a later product wrong, and the repair the error path of every solve applies (reset_tri_scratch)
+    puts it right."""
+    from projected_langevin_sampling_amd._chol import cholesky_factor
+
+    g = torch.Generator().manual_seed(31)
+    m, j = 512, 192
+    a = torch.randn(m, m, generator=g)
+    k = cu(a @ a.T / m + torch.eye(m))
+    f = cholesky_factor(k).build_inverse()
+    u = _aligned(torch.randn(m, j, generator=g))
+    with balance(P, 1):
+        want = f.solve(u)
+        assert relerr(k @ want, u) < 1e-10
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            other = f.solve(u)
+        torch.cuda.synchronize()
+        assert torch.equal(other, want) and len(f._tri_scratch) == 2
+        assert len({sc.data_ptr() for sc in f._tri_scratch.values()}) == 2
+        mine = f.tri_scratch()
+        flags = mine.view(torch.int32)[: f.TRI_FLAG_BYTES // 4]
+        assert int(flags.abs().sum()) == 0
+        flags.fill_(1)  # every pair already "has a partial sum waiting": the first arriver adds garbage instead of publishing
+        bad = f.solve(u)
+        torch.cuda.synchronize()
+        assert not torch.equal(bad, want), "poisoned flags are expected to corrupt the product (else this test tests nothing)"
+        f.reset_tri_scratch()
+        assert int(flags.abs().sum()) == 0
+        assert torch.equal(f.solve(u), want)
+        # the error path: a refused call zeroes the flags before it re-raises
+        flags.fill_(1)
+        with pytest.raises(P.pkg._lib.PlsHipError):
+            f._check(1, "a failing launch")
+        assert int(flags.abs().sum()) == 0

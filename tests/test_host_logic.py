@@ -463,3 +463,42 @@ def test_boundary_dtypes_without_a_gpu():
     with pytest.raises(TypeError):
         L.require_gpu_tensor([1.0], "particles")
     assert torch.float32 in L.PROMOTED_DTYPES and torch.float64 not in L.PROMOTED_DTYPES
+
+
+def test_the_partial_sum_exchange_of_the_balanced_products_is_tested_across_xcds():
+    """csrc/gemm_tn_f64_kg.h, gemm_tn_f64_kg_tri_kernel: the two workgroups that share a pair of tile rows meet through
+    write-through slots and one agent-scope atomic -- a protocol that must hold when they sit on DIFFERENT XCDs (whose L2s are
+    not coherent with each other).  Blocks are dealt round-robin over the eight XCDs (blockIdx % 8 labels the XCD group), so a
+    host-side replay of the kernel's block -> (virtual row, tile column) map says which SHAPES of
+    tests/test_gpu_tri_balance.py put the two roles of a pair into different groups: the GPU test must contain such shapes
+    by design, not by accident of a remap."""
+    from test_gpu_tri_balance import SHAPES
+
+    def tile_coords(bid, nti, ntj):  # gemm_tile_coords of csrc/gemm_tn_f64.h
+        nwg = nti * ntj
+        xcd, q, r = bid & 7, nwg >> 3, nwg & 7
+        base = xcd * (q + 1) if xcd < r else r * (q + 1) + (xcd - r) * q
+        ident = base + (bid >> 3)
+        gi_max = 8
+        group = gi_max * ntj
+        g = ident // group
+        first_i = g * gi_max
+        gi = min(nti - first_i, gi_max)
+        in_g = ident - g * group
+        return first_i + in_g % gi, in_g // gi
+
+    split = {}
+    for (m, j) in SHAPES:
+        nti, ntj = (m + 63) // 64, (j + 63) // 64
+        pairs = (nti + 1) // 2
+        where = {}
+        for bid in range(2 * pairs * ntj):
+            vrow, tj = tile_coords(bid, 2 * pairs, ntj)
+            assert 0 <= vrow < 2 * pairs and 0 <= tj < ntj
+            assert (vrow, tj) not in where, "the map must be a bijection"
+            where[(vrow, tj)] = bid & 7
+        assert len(where) == 2 * pairs * ntj
+        split[(m, j)] = sum(1 for p in range(pairs) for tj in range(ntj) if where[(2 * p, tj)] != where[(2 * p + 1, tj)])
+    crossing = {k: v for k, v in split.items() if v > 0}
+    assert len(crossing) >= 3, f"shapes whose pairs cross XCD groups: {crossing}"
+    assert all(split[k] > 0 for k in ((192, 192), (200, 130), (1088, 320))), split  # (the ones the round-4 review replayed)
