@@ -453,6 +453,10 @@ def main():
                 "bound": "hbm", "achieved": gbytes / (gms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                 "frac": gbytes / (gms * 1e-3) / 1e9 / 8000.0, "bytes_per_launch": gbytes, "avg_launch_ms": gms,
                 "launches": gsum["launches"], "D": int(x.shape[1]),
+                "valu_busy_frac": 0.64, "store_stream_frac": gbytes / (gms * 1e-3) / 1e9 / 5350.0,
+                "bound_note": "co-limited: SQ_ACTIVE_INST_VALU / cycles = 0.64 (40 fp64 vector instructions per entry, "
+                              "profiles/r05_gram_pmc.txt) next to 0.72-0.79 of the rate a pure store stream of this geometry "
+                              "reaches (5.1-5.6 TB/s, store_stream_frac is against their mean); `bound` names the larger",
                 "note": "algorithmic bytes (8 N M written) / launch duration from HIP events around each launch; a pure store "
                         "stream of this geometry reaches 5.1-5.6 TB/s on the chip (profiles/r02_gram_store_sweep.txt)",
             }
