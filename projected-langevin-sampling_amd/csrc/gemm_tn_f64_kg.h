@@ -146,6 +146,7 @@ __device__ __forceinline__ void kg_contract(const GemmShape &g, int64_t i0, int6
     pre();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (what the barrier needs anyway: the rows have landed)
     __syncthreads();
+    PLS_STAMP_AT(1);
     hook();
     hooked = true;
     read_frag(0, 0, fa, fb);
@@ -304,6 +305,7 @@ __global__ __launch_bounds__(256 * KG, 4) void gemm_tn_f64_kg_kernel(GemmShape g
       return;
     }
   }
+  PLS_STAMP_AT(0);
   int tile_i, tile_j;
   gemm_tile_coords(blockIdx.x, g.nti, g.ntj, tile_i, tile_j);
   const int64_t i0 = (int64_t)tile_i * 64, j0 = (int64_t)tile_j * 64;
@@ -342,6 +344,7 @@ __global__ __launch_bounds__(256 * KG, 4) void gemm_tn_f64_kg_kernel(GemmShape g
     kg_contract<KG>(g, i0, j0, kbeg, kend, lds, acc);
   }
 
+  PLS_STAMP_AT(2);
   // ---- hand-over between the k-groups, then the epilogue on the sum ----
   if constexpr (KG == 1) {
     const int lane = threadIdx.x & 63;
@@ -364,10 +367,14 @@ __global__ __launch_bounds__(256 * KG, 4) void gemm_tn_f64_kg_kernel(GemmShape g
     if constexpr (kPregen) {
       if (pregen) {
         kg_finish2(g, epi, fin, i0, j0, tile_i, split, lds, &pz, &px, pcl, pil);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PLS_STAMP_AT(3);
         return;
       }
     }
     kg_finish2(g, epi, fin, i0, j0, tile_i, split, lds);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PLS_STAMP_AT(3);
   }
 #else
   (void)g, (void)epi;

@@ -31,8 +31,36 @@
 namespace plship {
 
 #ifdef PLS_STAMP
-unsigned long long *g_stamp_buffer = nullptr;  // diagnostic build only (tools/stamp_probe.py)
+unsigned long long *g_stamp_buffer = nullptr;  // diagnostic build only (tools/stamp_probe.py, tools/kg_stamp_probe.py)
 extern "C" void pls_debug_set_stamp_buffer(unsigned long long *p) { g_stamp_buffer = p; }
+// an empty launch of a given geometry: what a launch costs before its first instruction (tools/kg_stamp_probe.py)
+__global__ void debug_empty_kernel(unsigned long long *stamps) {
+  if (stamps && threadIdx.x == 0) {
+    unsigned long long t_;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
+    stamps[blockIdx.x] = t_;
+  }
+}
+// s_memtime ticks per tick of the constant-rate wall clock (hipDeviceAttributeWallClockRate kHz): out[0] = s_memtime ticks,
+// out[1] = wall-clock ticks over a ~20 us spin of one wave
+__global__ void debug_calibrate_kernel(unsigned long long *out) {
+  unsigned long long t0, t1;
+  const unsigned long long w0 = wall_clock64();
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+  unsigned long long w1 = w0;
+  while (w1 - w0 < 2000) w1 = wall_clock64();
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+  if (threadIdx.x == 0) {
+    out[0] = t1 - t0;
+    out[1] = w1 - w0;
+  }
+}
+extern "C" void pls_debug_calibrate(unsigned long long *out, void *stream) {
+  hipLaunchKernelGGL(debug_calibrate_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), out);
+}
+extern "C" void pls_debug_empty_launch(int grid, int block, int lds_bytes, unsigned long long *stamps, void *stream) {
+  hipLaunchKernelGGL(debug_empty_kernel, dim3(grid), dim3(block), lds_bytes, reinterpret_cast<hipStream_t>(stream), stamps);
+}
 #endif
 
 thread_local std::string g_last_error;
@@ -583,6 +611,9 @@ static int launch_gemm_kg(GemmShape g, const Epi &epi, hipStream_t st) {
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds_bytes, lds_ready)) return rc;
   g.nti = (int)cdiv(g.I, 64);
   g.ntj = (int)cdiv(g.J, 64);
+#ifdef PLS_STAMP
+  g.stamps = g_stamp_buffer;
+#endif
   const int64_t nwg = (int64_t)g.nti * g.ntj;
   if (nwg <= 0) return PLS_OK;
   if (nwg > 0x7fffffff) return fail(PLS_ERR_INVALID_ARGUMENT, "gemm: too many tiles");

@@ -13,6 +13,18 @@ def short(n):
     m = re.search(r"gemm_tn_f64_kernel<(\d+), (\d+).*?plship::(\w+)", n)
     if m:
         return f"gemm_tn_f64<{m.group(1)}x{m.group(2)}>::{m.group(3)}"
+    m = re.search(r"gemm_tn_f64_kg_tri_kernel<.*?plship::(\w+)", n)  # (round 4 folded every k-split launch into one name)
+    if m:
+        return f"gemm_tn_f64_kg_tri::{m.group(1)}"
+    m = re.search(r"gemm_tn_f64_kg_kernel<(\d+).*?plship::(\w+)", n)
+    if m:
+        return f"gemm_tn_f64_kg<{m.group(1)}>::{m.group(2)}"
+    m = re.search(r"gemm_tn_f64_rows_kernel<.*?plship::(\w+)", n)
+    if m:
+        return f"gemm_tn_f64_rows::{m.group(1)}"
+    m = re.search(r"small_rank_step_kernel<(\d+), (-?\d+), (-?\d+), (true|false|0|1)>", n)
+    if m:
+        return f"small_rank_step_kernel<KB={m.group(1)},cost={m.group(2)},link={m.group(3)},energies={m.group(4)}>"
     m = re.search(r"small_rank_kernel<(\d+), (\d+), (-?\d+), (-?\d+)>", n)
     if m:
         mode = {"0": "drift", "1": "value", "2": "drift+value"}[m.group(2)]
@@ -51,6 +63,9 @@ for k, d in rows.items():
         per_xcd = ent["GRBM_GUI_ACTIVE"] / 8.0
         ent["mfma_pipe_utilisation"] = per_simd / per_xcd
         ent["clock_ghz"] = per_xcd / (ent["_dur_ms"] * 1e6)
+    if "SQ_ACTIVE_INST_VALU" in ent and "GRBM_GUI_ACTIVE" in ent:
+        # quad-cycles the vector ALU (MFMA included: the same issue port for fp64) is busy, per SIMD, against the launch's cycles
+        ent["valu_busy_frac"] = ent["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / (ent["GRBM_GUI_ACTIVE"] / 8.0)
     if "TCC_HIT_sum" in ent:
         ent["l2_hit_rate"] = ent["TCC_HIT_sum"] / (ent["TCC_HIT_sum"] + ent["TCC_MISS_sum"])
     summary[k] = ent
