@@ -280,6 +280,7 @@ struct EpiLangevinGaussian {
     int nparts;
   } prev;
   int pregen_flag;  // 1: the k-split kernel draws the noise in front of its k-loop (PLS_OPT_KG_NOISE_PREGEN; launch-uniform)
+  int zero_row = -1;  // >= 0: the 64-row tilings also write zeros into this partial row (lagged buffers: one layout)
 
   __device__ __forceinline__ bool prev_owner(int tile_i, int tile_j) const {
     return prev.part != nullptr && tile_i == 0 && (((int64_t)tile_j * bj) & 255) == 0;
@@ -500,6 +501,9 @@ struct EpiLangevinGaussian {
             store_partial(epart + (int64_t)(2 * tile_i + 1) * ldp + j, 0.0);
           } else {
             store_partial(epart + (int64_t)tile_i * ldp + j, tot);
+            // (a lagged buffer holds 2 cdiv(mk, 128) rows whatever tiling wrote it: the 64-row tiles leave one row fewer when
+            // mk mod 128 is in 1 .. 64, and the workgroups of tile row 0 zero it -- no memset node in front of the launch)
+            if (zero_row >= 0 && tile_i == 0) store_partial(epart + (int64_t)zero_row * ldp + j, 0.0);
           }
         }
       }
@@ -1763,10 +1767,7 @@ static int fast_step_launch(const FastOp &op, const double *U, int64_t ldu, int6
   e.pregen_flag = g_kg_noise_pregen.load() != 0;
   if (lag.partials_prev) e.prev = EpiLangevinGaussian::Prev{lag.partials_prev, lag.e_prev, lag.sums_prev, op.yscale, op.yty, (int)lag_rows};
   const bool lagged = lag.partials_out != nullptr;  // (the NEXT launch, or a flush, finishes this launch's energies)
-  if (lagged && parts < lag_rows) {
-    hipError_t me = hipMemsetAsync(lag.partials_out + parts * j, 0, (size_t)(lag_rows - parts) * j * sizeof(double), st);
-    if (me != hipSuccess) return fail(PLS_ERR_HIP, "%s: hipMemsetAsync: %s", who, hipGetErrorString(me));
-  }
+  if (lagged && parts < lag_rows) e.zero_row = (int)parts;  // (lag_rows - parts is 0 or 1)
   const bool fused_finish = !lagged && energy_in && esync && g_energy_fused_finish.load() != 0;
   if (fused_finish)  // the step launch finishes the energies itself (pls_block_desc.energy_sync)
     e.fin = EpiLangevinGaussian::Finish{esync, energy_in, esums, op.yscale, op.yty, (int)parts, (int)cdiv(op.mk, big ? 128 : 64)};
