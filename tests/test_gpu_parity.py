@@ -171,16 +171,20 @@ def test_eigh_on_the_gpu_gives_the_same_basis_up_to_the_gauge(P):
     assert relerr(bases[1].eigenvalues, bases[0].eigenvalues) < 1e-10
     ops = [(b._A.T * b.eigenvalues[None, :]) @ b._A for b in bases]
     assert relerr(ops[1], ops[0]) < 1e-8
-    # the library default outside the test suite ("auto": where the Gram matrix lives = the device) is the cuda route
+    # the library default outside the test suite is "auto": matrices of at most samplers.EIGH_HOST_BELOW rows go to host LAPACK
+    # (at the reference's benchmark sizes the device call is all latency), larger ones where the Gram matrix lives = the device
     from projected_langevin_sampling_amd import samplers
 
-    prev = samplers.DEFAULT_EIGH_DEVICE
+    prev = (samplers.DEFAULT_EIGH_DEVICE, samplers.EIGH_HOST_BELOW)
     try:
         samplers.DEFAULT_EIGH_DEVICE = "auto"
-        auto = P.basis.OrthonormalBasis(P.pkg.PLSKernel(gk, pr["z"]), pr["z"], pr["x"], 1e-10, verbose=False)
+        small = P.basis.OrthonormalBasis(P.pkg.PLSKernel(gk, pr["z"]), pr["z"], pr["x"], 1e-10, verbose=False)
+        samplers.EIGH_HOST_BELOW = 16  # (30 inducing points are "large" now)
+        large = P.basis.OrthonormalBasis(P.pkg.PLSKernel(gk, pr["z"]), pr["z"], pr["x"], 1e-10, verbose=False)
     finally:
-        samplers.DEFAULT_EIGH_DEVICE = prev
-    assert torch.equal(auto.eigenvalues, bases[1].eigenvalues) and torch.equal(auto._A, bases[1]._A)
+        samplers.DEFAULT_EIGH_DEVICE, samplers.EIGH_HOST_BELOW = prev
+    assert torch.equal(small.eigenvalues, bases[0].eigenvalues) and torch.equal(small._A, bases[0]._A)
+    assert torch.equal(large.eigenvalues, bases[1].eigenvalues) and torch.equal(large._A, bases[1]._A)
 
 
 def test_reference_goldens_onb_forward_with_oracle_gauge(P, G):
