@@ -2219,9 +2219,10 @@ size_t pls_onb_step_workspace_bytes(const pls_onb_desc *basis, int64_t j, int64_
 // operand the LDS-DMA can stream (16-byte aligned rows); option 1 takes it while the problem is launch-bound -- few enough
 // particle columns for one workgroup per 16 of them, and a step of at most 8 GFLOP (0.1 ms of matrix pipe): beyond, the
 // slab kernels of small_rank.h share every tile of the operand between four column groups, which is what counts there.
-static bool sr_step_route(const pls_onb_desc *b, int64_t j) {
+static bool sr_step_route(const pls_onb_desc *b, const double *y, int64_t j) {
   const int64_t mode = g_small_rank_step.load();
   if (mode == 0 || !small_rank_ok(b->At, b->ldat, b->mk)) return false;
+  if (reinterpret_cast<uintptr_t>(y) & 15) return false;  // (the targets travel by 16-byte LDS-DMA like the rows)
   if (mode >= 2) return true;
   return j <= 4096 && 4.0 * (double)b->n * (double)b->mk * (double)j <= 8e9;
 }
@@ -2354,7 +2355,7 @@ static int onb_step_impl(const pls_onb_desc *basis, const pls_cost_desc *cost, c
   }
   PLS_REQUIRE(!blocks || (!blocks->energy_partials && !blocks->energy_partials_prev),
               "onb_step: lagged energies (energy_partials) exist on the Gaussian/identity fast path only");
-  if (sr_step_route(basis, j)) {  // launch-bound problems: the whole step, its energies and their chunk sums in ONE launch
+  if (sr_step_route(basis, y, j)) {  // launch-bound problems: the whole step, its energies and their chunk sums in ONE launch
     bool taken = false;
     rc = sr_step_launch(basis, cp, y, U, ldu, j, etap, nz, out, ldo, out_mode, energy_in, blocks, workspace, workspace_bytes, st,
                         &taken);

@@ -5,6 +5,7 @@ column block meeting through the arrival counters, counters left zero, the same 
 sums it delivers, the memset fall-back for callers without counters, column blocks with their own step sizes.
 Reference path: projected_langevin_sampling.py:107-138, basis/orthonormal.py:98-159, experiments/trainers.py:149-158."""
 import ctypes
+import math
 
 import numpy as np
 import pytest
@@ -303,3 +304,63 @@ def test_the_drop_in_loop_takes_a_pre_bound_step_and_nothing_changes(P, route):
     assert torch.equal(v, gb.fused_step(gauss, wide[:, 3:55].contiguous(), 1e-4))
     torch.manual_seed(9)
     assert pls.calculate_particle_update(u0.float(), 1e-4).dtype == torch.float64
+
+
+@pytest.mark.parametrize("n,mk,j", [(1, 1, 1), (17, 1, 16), (64, 128, 3), (65, 127, 33), (700, 5, 600), (2600, 64, 530)])
+def test_edges_of_the_one_launch_step(P, route, n, mk, j):
+    """One data row, one function, one particle; a rank of exactly 128 and an odd one below it; more columns than one
+    256-column chunk with several slabs (the chunk sums' second hand-over across column blocks); a targets vector whose
+    address is not 16-byte aligned (the route steps aside).  Against the slab kernels + update launch at 1e-12 and against a
+    host evaluation of the Gaussian-generic step."""
+    g = torch.Generator().manual_seed(1000 * n + mk + j + FUZZ_SEED)
+    a = torch.randn(mk, n, generator=g) / math.sqrt(max(n, 1))
+    lam = torch.rand(mk, generator=g) + 0.5
+    basis = P.basis.OrthonormalBasis.from_projection(cu(a), cu(lam))
+    y = torch.randn(n, generator=g)
+    u = torch.randn(mk, j, generator=g)
+    xi = torch.randn(mk, j, generator=g)
+    eta = 1e-3
+    spec = P.basis.NoiseSpec(injected=cu(xi))
+    lib = P.pkg._lib.load()
+    for cost in (P.costs.GaussianCost(0.3, y, P.links.IdentityLinkFunction()), P.costs.BernoulliCost((y > 0).double(), P.links.SigmoidLinkFunction())):
+        gauss = isinstance(cost, P.costs.GaussianCost)
+        res = {}
+        for mode in (2, 0):
+            route(mode)
+            e = torch.full((j,), float("nan"), device="cuda")
+            nchunk = (j + 255) // 256
+            s256 = torch.full((nchunk,), float("nan"), device="cuda")
+            s16 = torch.full(((j + 15) // 16,), float("nan"), device="cuda")
+            sync = torch.zeros(int(lib.pls_step_sync_words(j)), dtype=torch.int32, device="cuda")
+            blocks = P.basis.BlockSpec(j, torch.full((1,), eta, device="cuda"), energy_sums=s256.data_ptr(), energy_sums16=s16.data_ptr(),
+                                       step_sync=sync)
+            names = _timeline_names(P, lambda: basis.fused_step(cost, cu(u), 0.0, noise=spec, force_generic=gauss, input_energy=e, blocks=blocks))
+            assert ("small_rank_step" in names) == (mode == 2), names
+            out = basis.fused_step(cost, cu(u), 0.0, noise=spec, force_generic=gauss, input_energy=e, blocks=blocks)
+            assert int(sync.abs().sum()) == 0
+            res[mode] = (out, e.clone(), s256.clone(), s16.clone())
+        assert relerr(res[2][0], res[0][0]) < 1e-12 and relerr(res[2][1], res[0][1]) < 1e-12
+        # the sums: of THIS route's energies, in the library's orders
+        chunk = torch.empty_like(res[2][2])
+        P.pkg._lib.check(lib.pls_chunk_sums(res[2][1].data_ptr(), j, chunk.data_ptr(), P.pkg._lib.stream_ptr()), "pls_chunk_sums")
+        b16 = torch.empty_like(res[2][3])
+        P.pkg._lib.check(lib.pls_sums16(res[2][1].data_ptr(), j, b16.data_ptr(), P.pkg._lib.stream_ptr()), "pls_sums16")
+        assert torch.equal(res[2][2], chunk) and torch.equal(res[2][3], b16)
+        assert torch.equal(res[0][2], torch.stack([res[0][1][256 * c:256 * c + 256].sum() for c in range(nchunk)])) or relerr(res[0][2], chunk) < 1e-12
+        if gauss:
+            f = a.T @ u
+            want = -eta * (a @ ((f - y[:, None]) / 0.3)) - eta * u / lam[:, None] + math.sqrt(2 * eta) * xi
+            assert relerr(res[2][0], want) < 1e-12
+            e_want = ((f - y[:, None]) ** 2).sum(dim=0) / (2 * 0.3) + 0.5 * (u * u / lam[:, None]).sum(dim=0)
+            assert relerr(res[2][1], e_want) < 1e-12
+    # targets at an address that is not a multiple of 16: the one-launch route steps aside, the result does not change
+    cost = P.costs.BernoulliCost((y > 0).double(), P.links.SigmoidLinkFunction())
+    route(2)
+    aligned = basis.fused_step(cost, cu(u), eta, noise=spec)
+    base = torch.empty(n + 1, device="cuda")
+    base[1:] = cost.y_device()
+    cost._y_dev = base[1:]
+    assert cost.y_device().data_ptr() % 16 == 8
+    names = _timeline_names(P, lambda: basis.fused_step(cost, cu(u), eta, noise=spec))
+    assert "small_rank_step" not in names
+    assert relerr(basis.fused_step(cost, cu(u), eta, noise=spec), aligned) < 1e-12
