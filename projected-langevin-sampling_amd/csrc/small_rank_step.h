@@ -93,16 +93,19 @@ constexpr int srs_wave_doubles() { return srs_nbuf<KB>() * srs_tile_doubles<KB>(
 template <int KB>
 constexpr size_t srs_lds_bytes() { return (size_t)(4 * srs_wave_doubles<KB>() + 64 + 256 + 8) * sizeof(double); }
 
-// The plan: slabs per column block.  A wave needs ~0.3 us per tile and 16 functions (half of it matrix pipe, the rest the
-// latencies inside a tile, which nothing overlaps at one wave per SIMD); handing a column block over between workgroups costs
-// three memory round trips past the caches (~6 us).  So: one slab while the whole column block is less than ~6 us of tiles;
-// otherwise as many slabs as put one workgroup on every CU, each at least two rounds of tiles long.
+// The plan: slabs per column block.  A round of tiles (64 rows of a workgroup) takes ~0.28 us per 16 functions when the matrix
+// pipe bounds it and never less than ~1.1 us (narrow ranks: seventeen LDS-DMA instructions per tile and the latencies between the
+// two contractions, which nothing overlaps at one wave per SIMD); handing a column block over between workgroups costs three
+// memory round trips past the caches (~8 us with the finishing loads).  So: ONE slab while the whole column block is at most
+// ~6 us of tiles (the cost function adds up to 1 us per round to them); otherwise as many slabs as put one workgroup on every CU, each at least two rounds long.
+// (profiles/r05_sr_step_probe.txt, r05_ipb_small_probe.txt; tools/sr_step_sweep.py)
 static inline int64_t small_rank_step_splits(int64_t J, int64_t N, int K, int64_t *rows_per_split) {
   const int64_t ncb = (J + 15) / 16;
   const int64_t kb = (K + 15) / 16;
   const int64_t rounds = (N + SRS_WG_ROWS - 1) / SRS_WG_ROWS;
+  const double round_us = 0.28 * (double)kb > 1.1 ? 0.28 * (double)kb : 1.1;
   int64_t s = 1;
-  if (rounds * kb > 20) {
+  if ((double)rounds * round_us > 6.0) {
     s = 256 / ncb;  // (rounded DOWN: 315 workgroups on 256 CUs take two passes, 252 one)
     if (s > rounds / 2) s = rounds / 2;
     if (s > 64) s = 64;
