@@ -143,6 +143,38 @@ class PLSBasis(ABC):
             raise L.PlsHipError(f"workspace of {workspace.numel() * 8} bytes handed in, {nbytes} needed")
         return workspace
 
+    # ---- the one-launch small-rank step (csrc/small_rank_step.h): what both bases keep for it ----------------------
+    def _step_sync(self, j: int, device) -> torch.Tensor:
+        """The zeroed arrival counters of the one-launch small-rank step (pls_block_desc.step_sync) for eager calls: one set per
+        stream (launches on one stream are ordered; two streams must not share counters), grown on demand.  A launch leaves
+        them zero; after a FAILED launch they are dropped (zero_step_sync) -- stale counts would make every later step wrong."""
+        words = int(L.load().pls_step_sync_words(j))
+        key = (str(device), L.stream_ptr())
+        pool = self.__dict__.setdefault("_sync_pool", {})
+        t = pool.get(key)
+        if t is None or t.numel() < words:
+            t = torch.zeros(max(words, 64), dtype=torch.int32, device=device)
+            pool[key] = t
+        return t
+
+    def zero_step_sync(self) -> None:
+        """Forget every counter set (after a failed or aborted launch): the next step allocates zeroed ones."""
+        self.__dict__.pop("_sync_pool", None)
+        self.__dict__.pop("_eager", None)  # (the eager step binds a counter set)
+
+    def _eta_word(self, step_size: float, device) -> torch.Tensor:
+        """``step_size`` as a device word (pls_block_desc.eta), remembered per value: an eager caller steps with the same size
+        thousands of times, and a host -> device copy per call would cost more than the step."""
+        words = self.__dict__.setdefault("_eta_words", {})
+        key = (float(step_size), str(device))
+        t = words.get(key)
+        if t is None:
+            if len(words) >= 64:
+                words.clear()
+            t = torch.full((1,), float(step_size), dtype=torch.float64, device=device)
+            words[key] = t
+        return t
+
     # ---- particles ---------------------------------------------------------------------------------------------
     def _initialise_particles_noise(self, number_of_particles: int, seed: int | None = None, mean: float = 0.0,
                                     stdev: float = 1.0) -> torch.Tensor:

@@ -353,20 +353,32 @@ class InducingPointBasis(PLSBasis):
         ws = self._pick_workspace(workspace, ws_bytes, u.device)
         nd = (noise if noise is not None else self._draw_noise_spec(None)).desc()
         mode = L.OUT_NEW_STATE if new_state else L.OUT_DELTA
-        if blocks is None:
-            L.check(
-                lib.pls_ipb_step(desc, cost.desc(), cost.y_device().data_ptr(), u.data_ptr(), L.ld(u), j, float(step_size), nd,
-                                 out.data_ptr(), L.ld(out), mode, 1 if force_generic else 0, L.ptr(input_energy), ws.data_ptr(),
-                                 ws_bytes, L.stream_ptr()),
-                "pls_ipb_step",
-            )
-        else:
-            L.check(
-                lib.pls_ipb_step_blocks(desc, cost.desc(), cost.y_device().data_ptr(), u.data_ptr(), L.ld(u), j, blocks.desc(), nd,
-                                        out.data_ptr(), L.ld(out), mode, 1 if force_generic else 0, L.ptr(input_energy),
-                                        ws.data_ptr(), ws_bytes, L.stream_ptr()),
-                "pls_ipb_step_blocks",
-            )
+        bd = None if blocks is None else blocks.desc()
+        if not gaussian and 1 <= self.approximation_dimension <= self.SMALL_RANK_MAX:
+            # (the one-launch small-rank step meets through zeroed counters: see OrthonormalBasis.fused_step)
+            if bd is None:
+                bd = L.BlockDesc()
+                bd.block_cols, bd.eta = j, self._eta_word(step_size, u.device).data_ptr()
+            if not bd.step_sync:
+                bd.step_sync = self._step_sync(j, u.device).data_ptr()
+        try:
+            if bd is None:
+                L.check(
+                    lib.pls_ipb_step(desc, cost.desc(), cost.y_device().data_ptr(), u.data_ptr(), L.ld(u), j, float(step_size), nd,
+                                     out.data_ptr(), L.ld(out), mode, 1 if force_generic else 0, L.ptr(input_energy), ws.data_ptr(),
+                                     ws_bytes, L.stream_ptr()),
+                    "pls_ipb_step",
+                )
+            else:
+                L.check(
+                    lib.pls_ipb_step_blocks(desc, cost.desc(), cost.y_device().data_ptr(), u.data_ptr(), L.ld(u), j, bd, nd,
+                                            out.data_ptr(), L.ld(out), mode, 1 if force_generic else 0, L.ptr(input_energy),
+                                            ws.data_ptr(), ws_bytes, L.stream_ptr()),
+                    "pls_ipb_step_blocks",
+                )
+        except L.PlsHipError:
+            self.zero_step_sync()
+            raise
         return out
 
     def step_launcher(self, cost, state: torch.Tensor, step_size: float):
@@ -409,9 +421,52 @@ class InducingPointBasis(PLSBasis):
     def supports_input_energy(self, cost) -> bool:
         return bool(cost.is_native())
 
+    #: inducing-point counts up to which a cost without the Gaussian algebra takes the small-rank kernels
+    SMALL_RANK_MAX = 128
+
     def supports_energy_sums(self, cost) -> bool:
-        """the whitened Gaussian/identity route (see OrthonormalBasis.supports_energy_sums)"""
-        return bool(cost.is_native()) and self.whitened and self._is_gaussian(cost, False)
+        """the whitened Gaussian/identity route, and every other native cost on at most 128 inducing points (the one-launch
+        small-rank step writes the sums itself; see OrthonormalBasis.supports_energy_sums)"""
+        if not cost.is_native():
+            return False
+        return (self.whitened and self._is_gaussian(cost, False)) or self._one_launch_rank(cost)
+
+    def _one_launch_rank(self, cost) -> bool:
+        return (not self._is_gaussian(cost, False)) and 1 <= self.approximation_dimension <= self.SMALL_RANK_MAX
+
+    def uses_sums16(self, cost) -> bool:
+        """(see OrthonormalBasis.uses_sums16)"""
+        return bool(cost.is_native()) and self._one_launch_rank(cost)
+
+    def sums_step_launcher(self, cost, state: torch.Tensor, eta: torch.Tensor):
+        """(see OrthonormalBasis.sums_step_launcher) -- pls_ipb_step_blocks with the energies of the input particles and their
+        16-column sums, pre-bound: V = k(Z,Z)^-1 U and the coloured noise by their own launches, everything else of the step
+        in ONE (csrc/small_rank_step.h) while the problem is launch-bound.  None for the Gaussian fast path."""
+        if not (cost.is_native() and self._one_launch_rank(cost)):
+            return None
+        u = _rows_contiguous(L.require_gpu_tensor(state, "particles"))
+        j = u.shape[1]
+        lib = L.load()
+        desc, cd, y = self._desc(with_gaussian=False), cost.desc(), cost.y_device()
+        ws_bytes = max(lib.pls_ipb_step_workspace_bytes(desc, j, 128), min(lib.pls_ipb_step_workspace_bytes(desc, j, self._n), self.workspace_bytes))
+        ws = torch.empty((ws_bytes + 7) // 8, dtype=torch.float64, device=u.device)
+        sync = torch.zeros(max(int(lib.pls_step_sync_words(j)), 1), dtype=torch.int32, device=u.device)
+        blocks, nd = L.BlockDesc(), L.NoiseDesc()
+        blocks.block_cols, blocks.eta = j, L.require_gpu_tensor(eta, "eta").data_ptr()
+        blocks.step_sync = sync.data_ptr()
+        nd.kind, nd.step, nd.j_offset = L.NOISE_PHILOX, 0, int(self.j_offset)
+        fn = lib.pls_ipb_step_blocks
+        y_ptr, ws_ptr, stream, mode = y.data_ptr(), ws.data_ptr(), L.stream_ptr(), L.OUT_NEW_STATE
+
+        def launch(u_ptr, ldu, out_ptr, ldo, seed, energy_ptr, sums_ptr):
+            nd.seed = seed
+            blocks.energy_sums16 = sums_ptr
+            rc = fn(desc, cd, y_ptr, u_ptr, ldu, j, blocks, nd, out_ptr, ldo, mode, 0, energy_ptr, ws_ptr, ws_bytes, stream)
+            if rc:
+                L.check(rc, "pls_ipb_step_blocks")
+
+        launch.keep_alive = (desc, cd, y, ws, sync, eta, self)
+        return launch
 
     def fused_particle_energy(self, cost, particles: torch.Tensor, force_generic: bool = False) -> torch.Tensor:
         u = _rows_contiguous(L.require_gpu_tensor(particles, "particles", promote=True))

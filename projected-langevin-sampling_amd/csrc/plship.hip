@@ -2219,17 +2219,54 @@ size_t pls_onb_step_workspace_bytes(const pls_onb_desc *basis, int64_t j, int64_
 // operand the LDS-DMA can stream (16-byte aligned rows); option 1 takes it while the problem is launch-bound -- few enough
 // particle columns for one workgroup per 16 of them, and a step of at most 8 GFLOP (0.1 ms of matrix pipe): beyond, the
 // slab kernels of small_rank.h share every tile of the operand between four column groups, which is what counts there.
-static bool sr_step_route(const pls_onb_desc *b, const double *y, int64_t j) {
+static bool sr_step_route_for(const double *Lb, int64_t ldlb, int64_t mk, int64_t n, const double *y, int64_t j) {
   const int64_t mode = g_small_rank_step.load();
-  if (mode == 0 || !small_rank_ok(b->At, b->ldat, b->mk)) return false;
+  if (mode == 0 || !small_rank_ok(Lb, ldlb, mk)) return false;
   if (reinterpret_cast<uintptr_t>(y) & 15) return false;  // (the targets travel by 16-byte LDS-DMA like the rows)
   if (mode >= 2) return true;
-  return j <= 4096 && 4.0 * (double)b->n * (double)b->mk * (double)j <= 8e9;
+  return j <= 4096 && 4.0 * (double)n * (double)mk * (double)j <= 8e9;
+}
+static bool sr_step_route(const pls_onb_desc *b, const double *y, int64_t j) {
+  return sr_step_route_for(b->At, b->ldat, b->mk, b->n, y, j);
 }
 
-static int sr_step_launch(const pls_onb_desc *basis, const CostP &cp, const double *y, const double *U, int64_t ldu, int64_t j,
+// operands of the one-launch step for either basis: Lb (n x mk), the coordinates Vf the forward map contracts (and the prior
+// term weighs: by 1 / lam, or by pconst when lam is NULL), the particles Uadd the update is added to (NULL: Vf)
+struct SrStepOperands {
+  const double *Lb;
+  int64_t ldlb, mk, n;
+  const double *Vf;
+  int64_t ldvf;
+  const double *Uadd;
+  int64_t lduadd;
+  const double *lam;
+  double pconst;
+};
+
+// bytes the one-launch step takes from the workspace for j columns: its slabs, and its counters when the caller brings none
+static size_t sr_step_need_bytes(int64_t mk, int64_t n, int64_t j, const pls_block_desc *blocks, const double *energy_in) {
+  int64_t rows = 0;
+  int64_t ns = small_rank_step_splits(j, n, (int)mk, &rows);
+#ifdef PLS_SRS_PROBE
+  if (const char *f = getenv("PLS_SRS_FORCE_NS")) {
+    ns = atoi(f);
+    rows = (cdiv(n, ns) + 63) / 64 * 64;
+    ns = cdiv(n, rows);
+  }
+#endif
+  const size_t slab_bytes = ns > 1 ? align_up((size_t)cdiv(j, 16) * ns * ((size_t)mk + 1) * 16 * sizeof(double), 256) : 0;
+  const bool need_sync = ns > 1 || (blocks && energy_in && blocks->energy_sums);
+  const bool own_sync = blocks && blocks->step_sync;
+  return slab_bytes + ((need_sync && !own_sync) ? align_up(small_rank_step_sync_words(j) * sizeof(uint32_t), 256) : 0);
+}
+static bool sr_step_fits(int64_t mk, int64_t n, int64_t j, const pls_block_desc *blocks, const double *energy_in, size_t avail) {
+  return sr_step_need_bytes(mk, n, j, blocks, energy_in) <= avail;
+}
+
+static int sr_step_launch(const SrStepOperands &basis_ops, const CostP &cp, const double *y, int64_t j,
                           const EtaP &etap, const NoiseP &nz, double *out, int64_t ldo, int out_mode, double *energy_in,
                           const pls_block_desc *blocks, void *workspace, size_t workspace_bytes, hipStream_t st, bool *taken) {
+  const SrStepOperands *basis = &basis_ops;
   *taken = false;
   int64_t rows = 0;
   int64_t ns = small_rank_step_splits(j, basis->n, (int)basis->mk, &rows);
@@ -2254,12 +2291,15 @@ static int sr_step_launch(const pls_onb_desc *basis, const CostP &cp, const doub
   }
   const int64_t ncb = cdiv(j, 16);
   SrStepP p{};
-  p.Lb = basis->At;
-  p.ldlb = basis->ldat;
-  p.U = U;
-  p.ldu = ldu;
+  p.Lb = basis->Lb;
+  p.ldlb = basis->ldlb;
+  p.U = basis->Vf;
+  p.ldu = basis->ldvf;
+  p.Uadd = basis->Uadd;
+  p.lduadd = basis->lduadd;
   p.y = y;
   p.lam = basis->lam;
+  p.pconst = basis->pconst;
   p.N = basis->n;
   p.J = j;
   p.K = (int)basis->mk;
@@ -2357,8 +2397,8 @@ static int onb_step_impl(const pls_onb_desc *basis, const pls_cost_desc *cost, c
               "onb_step: lagged energies (energy_partials) exist on the Gaussian/identity fast path only");
   if (sr_step_route(basis, y, j)) {  // launch-bound problems: the whole step, its energies and their chunk sums in ONE launch
     bool taken = false;
-    rc = sr_step_launch(basis, cp, y, U, ldu, j, etap, nz, out, ldo, out_mode, energy_in, blocks, workspace, workspace_bytes, st,
-                        &taken);
+    const SrStepOperands ops{basis->At, basis->ldat, basis->mk, basis->n, U, ldu, nullptr, 0, basis->lam, 0.0};
+    rc = sr_step_launch(ops, cp, y, j, etap, nz, out, ldo, out_mode, energy_in, blocks, workspace, workspace_bytes, st, &taken);
     if (rc || taken) return rc;
   }
   // workspace: [D slabs][cost partial rows (energy by-product)][G chunk]; the chunk length follows from what is left
@@ -2531,25 +2571,31 @@ int pls_ipb_forward(const pls_ipb_desc *basis, const double *U, int64_t ldu, int
 }
 
 // shared tail of the IPB update: out = [U +] -eta*D - eta*M*V + sqrt(2 eta) e
+// e = Lc xi for the library's own noise: Philox normals into xi_buf, a triangular product into e_buf; `nz` then names e_buf as
+// injected noise (the inducing-point update adds N(0, k(Z,Z)) samples: inducing_point.py:133-137)
+static int ipb_colour_noise(const pls_ipb_desc *basis, NoiseP &nz, int64_t j, double *xi_buf, double *e_buf, hipStream_t st) {
+  if (nz.kind != PLS_NOISE_PHILOX) return PLS_OK;
+  if (!basis->LcT) return fail(PLS_ERR_INVALID_ARGUMENT, "ipb: Philox noise needs the Cholesky factor LcT");
+  hipLaunchKernelGGL(normal_fill_kernel, dim3((unsigned)cdiv(j, 256), rows_grid(cdiv(basis->m, 8) * 4)), dim3(256), 0, st,
+                     xi_buf, j, basis->m, j, nz.seed, nz.step, nz.j_offset, nz.step_base, nz.block_cols);
+  int rc = check_launch("normal_fill");
+  if (rc) return rc;
+  // e = Lc xi :  L[k][i] = LcT[k][i] = Lc[i][k], zero for k > i: a triangular product (half the contraction)
+  rc = gemm_tn_ex(basis->LcT, basis->ldlct, xi_buf, j, e_buf, j, basis->m, j, basis->m, 1.0, 0.0, 1, st, basis->tri_scratch,
+                  basis->tri_scratch_bytes);
+  if (rc) return rc;
+  nz.kind = PLS_NOISE_INJECTED;
+  nz.xi = e_buf;
+  nz.ldxi = j;
+  return PLS_OK;
+}
+
 static int ipb_finish(const pls_ipb_desc *basis, const double *U, int64_t ldu, const double *D, int nslab,
                       int64_t slab_stride, const double *V, int64_t j, double eta, const pls_noise_desc *noise, double *out, int64_t ldo, int add_u,
                       double *xi_buf, double *e_buf, hipStream_t st, const double *dsub = nullptr, double dsub_scale = 0.0,
                       const pls_block_desc *blocks = nullptr) {
   NoiseP nz = make_noisep(noise, blocks);
-  if (nz.kind == PLS_NOISE_PHILOX) {
-    if (!basis->LcT) return fail(PLS_ERR_INVALID_ARGUMENT, "ipb: Philox noise needs the Cholesky factor LcT");
-    hipLaunchKernelGGL(normal_fill_kernel, dim3((unsigned)cdiv(j, 256), rows_grid(cdiv(basis->m, 8) * 4)), dim3(256), 0, st,
-                       xi_buf, j, basis->m, j, nz.seed, nz.step, nz.j_offset, nz.step_base, nz.block_cols);
-    int rc = check_launch("normal_fill");
-    if (rc) return rc;
-    // e = Lc xi :  L[k][i] = LcT[k][i] = Lc[i][k], zero for k > i: a triangular product (half the contraction)
-    rc = gemm_tn_ex(basis->LcT, basis->ldlct, xi_buf, j, e_buf, j, basis->m, j, basis->m, 1.0, 0.0, 1, st, basis->tri_scratch,
-                    basis->tri_scratch_bytes);
-    if (rc) return rc;
-    nz.kind = PLS_NOISE_INJECTED;
-    nz.xi = e_buf;
-    nz.ldxi = j;
-  }
+  if (int rc = ipb_colour_noise(basis, nz, j, xi_buf, e_buf, st)) return rc;
   hipLaunchKernelGGL(langevin_update_kernel, dim3((unsigned)cdiv(j, 256), rows_grid(cdiv(basis->m, 8) * 4)), dim3(256), 0, st,
                      out, ldo, U, ldu, D, j, nslab, slab_stride, V, j, (const double *)nullptr, (double)basis->m, basis->m, j,
                      make_etap(eta, blocks), add_u, nz, dsub, dsub_scale);
@@ -2604,8 +2650,11 @@ size_t pls_ipb_step_workspace_bytes(const pls_ipb_desc *basis, int64_t j, int64_
   if (!basis || j <= 0) return 0;
   if (n_chunk <= 0 || n_chunk > basis->n) n_chunk = basis->n;
   // V, xi, e (m x j each) + D slabs + cost partial rows of the energy by-product + G chunk
-  return (size_t)(3 + onb_max_slabs(basis->m, j, basis->n)) * align_up((size_t)basis->m * j * sizeof(double), 256) +
-         onb_energy_partial_bytes(n_chunk, j) + (size_t)n_chunk * j * sizeof(double);
+  const size_t mj = align_up((size_t)basis->m * j * sizeof(double), 256);
+  const size_t general = (size_t)(3 + onb_max_slabs(basis->m, j, basis->n)) * mj + onb_energy_partial_bytes(n_chunk, j) +
+                         (size_t)n_chunk * j * sizeof(double);
+  const size_t one_launch = 3 * mj + sr_step_workspace_bytes(basis->m, j, basis->n);  // (V, xi, e, then the step's slabs)
+  return general > one_launch ? general : one_launch;
 }
 
 static int ipb_step_impl(const pls_ipb_desc *basis, const pls_cost_desc *cost, const double *y, double *U, int64_t ldu, int64_t j,
@@ -2688,6 +2737,21 @@ static int ipb_step_impl(const pls_ipb_desc *basis, const pls_cost_desc *cost, c
                     blocks);
     if (rc) return rc;
     return finish_energy_sums(blocks, energy_in, j, st);
+  }
+  if (sr_step_route_for(basis->Kxz, basis->ldkxz, basis->m, basis->n, y, j) &&
+      sr_step_fits(basis->m, basis->n, j, blocks, energy_in, workspace_bytes - 3 * mj)) {
+    // launch-bound problems (the reference's curve experiments build this basis with 10-100 inducing points and 50-100
+    // particles): V and the coloured noise as above, then projection, cost, back-projection, slab sum, prior drift M V, update and
+    // energies in ONE launch (csrc/small_rank_step.h) -- 4-5 launches per step instead of 8
+    NoiseP nz = make_noisep(noise, blocks);
+    rc = ipb_colour_noise(basis, nz, j, xi, e, st);
+    if (rc) return rc;
+    bool taken = false;
+    const SrStepOperands ops{basis->Kxz, basis->ldkxz, basis->m, basis->n, V, j, U, ldu, nullptr, (double)basis->m};
+    rc = sr_step_launch(ops, make_costp(cost), y, j, make_etap(eta, blocks), nz, out, ldo, out_mode, energy_in, blocks, D,
+                        workspace_bytes - 3 * mj, st, &taken);
+    if (rc) return rc;
+    return taken ? PLS_OK : fail(PLS_ERR_WORKSPACE_TOO_SMALL, "ipb_step: the one-launch step refused a workspace it was sized for");
   }
   EnergySink sink;
   if (energy_in) {  // e_j = cost_j(F(U)) + (M/2) ||K^-1 U_j||^2 of the INPUT particles (inducing_point.py:95-115)

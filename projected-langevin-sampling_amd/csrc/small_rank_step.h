@@ -48,10 +48,14 @@ typedef double srs_double4_t __attribute__((ext_vector_type(4)));
 struct SrStepP {
   const double *Lb;  // N x K row-major (At of the orthonormal basis), 16-byte aligned, even leading dimension
   int64_t ldlb;
-  const double *U;  // K x J input particles
+  const double *U;  // K x J: the coordinates the forward map contracts -- the particles of the orthonormal basis, V = k(Z,Z)^-1 U
+                    // of the inducing-point basis -- and the operand of the prior term
   int64_t ldu;
+  const double *Uadd;  // K x J: the particles the update is added to (add_u = 1); NULL: U itself
+  int64_t lduadd;
   const double *y;
-  const double *lam;  // (K) eigenvalues: prior drift U / lambda, prior energy U^2 / (2 lambda)
+  const double *lam;  // (K) eigenvalues: prior drift U / lambda, prior energy U^2 / (2 lambda); NULL: the constant below
+  double pconst;      // lam == NULL: prior drift pconst * U, prior energy pconst * U^2 / 2 (inducing-point basis: M)
   int64_t N, J;
   int K;
   int64_t rows_per_split;  // multiple of 64
@@ -368,7 +372,7 @@ __global__ __launch_bounds__(256, 2) void small_rank_step_kernel(SrStepP p) {
 #endif
   // What the update needs besides the drift -- step size, noise, the particles and 1 / lambda of this thread's rows -- does not
   // depend on the other slabs: with several slabs it is fetched / drawn while the arrival counter's answer travels.
-  double fz[NPT][2], fu[NPT][2], fps[NPT][2];
+  double fz[NPT][2], fu[NPT][2], fps[NPT][2], fb[NPT][2];  // noise, prior operand, prior weight, base of the new state
   double eta = 0.0, sq2eta = 0.0;
   auto prefetch_update_operands = [&]() {
     if (fin_col) {
@@ -397,7 +401,8 @@ __global__ __launch_bounds__(256, 2) void small_rank_step_kernel(SrStepP p) {
         const int i = ib + 4 * h;
         const bool in = on && i < p.K;
         fu[e][h] = in ? p.U[(int64_t)i * p.ldu + fcol] : 0.0;
-        fps[e][h] = in ? 1.0 / p.lam[i] : 0.0;
+        fps[e][h] = in ? (p.lam ? 1.0 / p.lam[i] : p.pconst) : 0.0;
+        if (p.Uadd) fb[e][h] = (in && p.add_u) ? p.Uadd[(int64_t)i * p.lduadd + fcol] : 0.0;
       }
     }
   };
@@ -505,7 +510,7 @@ __global__ __launch_bounds__(256, 2) void small_rank_step_kernel(SrStepP p) {
         if (i < p.K) {
           const double ps = fps[e][h], u = fu[e][h];
           const double dd = srs_langevin_delta(eta, sq2eta, d[e][h], ps, u, fz[e][h]);
-          p.out[(int64_t)i * p.ldo + fcol] = p.add_u ? u + dd : dd;
+          p.out[(int64_t)i * p.ldo + fcol] = p.add_u ? (p.Uadd ? fb[e][h] : u) + dd : dd;
           if constexpr (VALUE) prior += u * u * ps;
         }
       }

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle import pls_oracle as O
 
-from test_gpu_parity import FUZZ_SEED, TOL, build_onb, cu, make_costs, make_problem, relerr, step_tolerance  # noqa: E402
+from test_gpu_parity import FUZZ_SEED, TOL, build_ipb, build_onb, cu, make_costs, make_problem, relerr, step_tolerance  # noqa: E402
 from test_gpu_parity import P, _f64_default  # noqa: F401,E402  (fixtures)
 
 
@@ -364,3 +364,88 @@ def test_edges_of_the_one_launch_step(P, route, n, mk, j):
     names = _timeline_names(P, lambda: basis.fused_step(cost, cu(u), eta, noise=spec))
     assert "small_rank_step" not in names
     assert relerr(basis.fused_step(cost, cu(u), eta, noise=spec), aligned) < 1e-12
+
+
+# ------------------------------------------------------------------------------------------------------------
+# the inducing-point basis (basis/inducing_point.py:60-135): V = k(Z,Z)^-1 U and the coloured noise by their own launches, then
+# projection k(X,Z) V, cost, back-projection, prior drift M V, update and energies in the same one launch
+IPB_SHAPES = [(100, 10, 64, 1), (333, 17, 37, 2), (3000, 30, 40, 2), (1100, 128, 90, 3)]
+
+
+@pytest.mark.parametrize("n,m,j,d", IPB_SHAPES)
+def test_inducing_point_basis_takes_the_one_launch_step(P, route, n, m, j, d):
+    pr = make_problem(n, m, j, d, seed=11 * n + m + FUZZ_SEED)
+    pr["ls"] = pr["ls"] * 0.35
+    ob, gb = build_ipb(P, pr)
+    u = pr["u"]
+    e_noise = torch.randn(m, j, generator=pr["gen"])
+    eta = 1e-3
+    checked = 0
+    for name, oc, gc in make_costs(P, pr["y"], pr["fstar"], pr["gen"]):
+        if name == "gaussian/identity":
+            continue
+        want = O.PLS(ob, oc).calculate_particle_update(u.clone(), eta, noise=e_noise)
+        tol = step_tolerance(ob, oc, u, eta, e_noise, want)
+        if tol >= 1e-8:
+            continue
+        checked += 1
+        spec = P.basis.NoiseSpec(injected=cu(e_noise))
+        e_new = torch.full((j,), float("nan"), device="cuda")
+        route(2)
+        names = _timeline_names(P, lambda: gb.fused_step(gc, cu(u), eta, noise=spec, input_energy=e_new))
+        assert "small_rank_step" in names and not {"small_rank", "small_rank_value", "gemm_cost", "langevin_update"} & set(names), names
+        got = gb.fused_step(gc, cu(u), eta, noise=spec)
+        got_e = gb.fused_step(gc, cu(u), eta, noise=spec, input_energy=e_new)
+        assert torch.equal(got, got_e), "the energy by-product must not move the step"
+        assert relerr(got, want) < tol, name
+        v = torch.cholesky_solve(u, torch.linalg.cholesky(ob.base_gram_induce))
+        e_want = oc.calculate_cost(ob.calculate_untransformed_train_prediction_samples(u)) + 0.5 * m * (v * v).sum(dim=0)
+        assert relerr(e_new, e_want) < 1e-9, name
+        new_state = gb.fused_step(gc, cu(u), eta, noise=spec, new_state=True)
+        assert relerr(new_state, u + want) < max(tol, 1e-12), name
+        route(0)
+        e_old = torch.empty(j, device="cuda")
+        old = gb.fused_step(gc, cu(u), eta, noise=spec, input_energy=e_old)
+        assert relerr(got, old) < 1e-11 and relerr(e_new, e_old) < 1e-11, name
+        # Philox noise: the same draws, coloured by the same factor, whichever kernels finish the step
+        pspec = P.basis.NoiseSpec(seed=77, step=3)
+        old_p = gb.fused_step(gc, cu(u), eta, noise=pspec)
+        route(2)
+        assert relerr(gb.fused_step(gc, cu(u), eta, noise=pspec), old_p) < 1e-11, name
+    assert checked >= 5, checked
+    assert int(gb._step_sync(j, torch.device("cuda")).abs().sum()) == 0, "the arrival counters are left zero"
+
+
+def test_inducing_point_training_loop_polls_the_sums_of_the_one_launch_step(P, route):
+    """train_pls on the inducing-point basis, Bernoulli/sigmoid on a small basis: the pipelined loop (solve + noise + ONE step
+    launch per iteration, 16-column energy sums into the pinned slot) and the plain loop give the same particles, energies, stop
+    index and generator state."""
+    pr = make_problem(500, 16, 48, 1, seed=21 + FUZZ_SEED)
+    pr["ls"] = pr["ls"] * 0.35
+    ob, gb = build_ipb(P, pr)
+    name, oc, gc = make_costs(P, pr["y"], pr["fstar"], pr["gen"])[2]
+    pls = P.pkg.PLS(gb, gc)
+    assert gb.supports_energy_sums(gc) and gb.uses_sums16(gc)
+    u0 = cu(pr["u"])
+    route(1)
+    with P.pkg._lib.Timeline(512) as tl:
+        torch.manual_seed(3)
+        P.pkg.train_pls(pls, u0.clone(), 20, 1e-5, 1e9)
+    summary = tl.summary()
+    assert summary["small_rank_step"]["launches"] >= 20, summary
+    assert not {"small_rank", "gemm_cost", "langevin_update", "block_means"} & set(summary), summary
+    runs = {}
+    for mode in ("pipelined", "plain"):
+        if mode == "plain":
+            gb.supports_input_energy = lambda c: False
+        try:
+            torch.manual_seed(44)
+            out, energies = P.pkg.train_pls(pls, u0.clone(), 40, 1e-5, 1e9)
+            runs[mode] = (out, energies, torch.get_rng_state())
+        finally:
+            if mode == "plain":
+                del gb.supports_input_energy
+    assert len(runs["pipelined"][1]) == len(runs["plain"][1]) == 40
+    assert relerr(runs["pipelined"][0], runs["plain"][0]) < 1e-12
+    assert np.allclose(runs["pipelined"][1], runs["plain"][1], rtol=1e-11)
+    assert torch.equal(runs["pipelined"][2], runs["plain"][2])
