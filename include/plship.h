@@ -313,7 +313,12 @@ typedef enum pls_option {
    * launch (csrc/small_rank_step.h) while the problem is launch-bound (at most 4096 particles and 8 GFLOP per step), the
    * slab kernels of csrc/small_rank.h + update launch beyond; 0 = never; 2 = wherever the kernel applies (A/B runs, tests).
    * Results agree to rounding (another summation order over the data rows), not bit for bit. */
-  PLS_OPT_SMALL_RANK_STEP = 13
+  PLS_OPT_SMALL_RANK_STEP = 13,
+  /* pls_ipb_step on at most 128 inducing points, in front of the one-launch step above: 1 (default) = V = k(Z,Z)^-1 U and the
+   * coloured Philox noise Lc xi in ONE launch (csrc/ipb_prep.h; needs the inverse factor Linv / LinvT in the descriptor and
+   * PLS_OPT_SOLVE_MODE 1), 0 = the two triangular products, the fill and the third product as launches of their own (A/B
+   * runs, tests).  Same draws either way; results agree to rounding. */
+  PLS_OPT_IPB_PREP = 14
 } pls_option;
 /* Diagnostic: out[i] = op(x[i]) with the device exp (op 0) / log (op 1) the per-element kernels use (csrc/fmath.h), or
  * out[i] = x[i] / x[n + i] with their division (op 2: fast_div, IEEE special cases restored; op 3: fast_div_normal), so
@@ -337,7 +342,8 @@ typedef enum {
   PLS_TAG_SMALL_RANK_DRIFT = 8,      /* small_rank_kernel: F, d cost / d f and the back-projection in one pass (rank <= 128) */
   PLS_TAG_SMALL_RANK_VALUE = 9,      /* small_rank_kernel: F and the per-column cost sums in one pass */
   PLS_TAG_TRI_SOLVE = 10,            /* tri_solve_strip_kernel: V = Lc^-T Lc^-1 U, forward + backward substitution in one launch */
-  PLS_TAG_SMALL_RANK_STEP = 11       /* small_rank_step_kernel: the whole step (and its energies) of a small-rank basis in one launch */
+  PLS_TAG_SMALL_RANK_STEP = 11,      /* small_rank_step_kernel: the whole step (and its energies) of a small-rank basis in one launch */
+  PLS_TAG_IPB_PREP = 12              /* ipb_prep_kernel: V = k(Z,Z)^-1 U and the coloured noise Lc xi of a step, <= 128 inducing points */
 } pls_kernel_tag;
 int pls_timeline_begin(int32_t capacity);
 int pls_timeline_end(float *ms, int32_t *tags, int32_t capacity, int32_t *count);
@@ -549,7 +555,10 @@ int pls_ipb_particle_update(const pls_ipb_desc *basis, const double *U, int64_t 
 size_t pls_ipb_step_workspace_bytes(const pls_ipb_desc *basis, int64_t j, int64_t n_chunk);
 /* energy_in (optional, J doubles): receives the energy of the INPUT particles (cost of the same F the drift uses +
  * the prior term) as a by-product, like pls_onb_step.  If basis->B/c are set and the cost is Gaussian/identity the
- * M x M x J fast path is taken unless force_generic != 0. */
+ * M x M x J fast path is taken unless force_generic != 0.  Other costs on at most 128 inducing points take, while the
+ * problem is launch-bound (PLS_OPT_SMALL_RANK_STEP), two launches: V = k(Z,Z)^-1 U with the coloured noise (csrc/ipb_prep.h,
+ * PLS_OPT_IPB_PREP), then projection, cost, back-projection, prior drift, update and energies in one
+ * (csrc/small_rank_step.h; pls_block_desc.step_sync / energy_sums16 apply as for pls_onb_step_blocks). */
 int pls_ipb_step(const pls_ipb_desc *basis, const pls_cost_desc *cost, const double *y, double *U, int64_t ldu,
                  int64_t j, double eta, const pls_noise_desc *noise, double *out, int64_t ldo, int32_t out_mode,
                  int32_t force_generic, double *energy_in, void *workspace, size_t workspace_bytes, void *stream);

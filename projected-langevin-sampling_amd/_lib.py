@@ -230,9 +230,10 @@ OPT_IPB_STEP_OPERATOR = 10
 OPT_ENERGY_FUSED_FINISH = 11
 OPT_KG_NOISE_PREGEN = 12
 OPT_SMALL_RANK_STEP = 13
+OPT_IPB_PREP = 14
 TAG_NAMES = {1: "gemm_store", 2: "gemm_cost_deriv", 3: "gemm_cost_value", 4: "gemm_langevin_gaussian",
              5: "langevin_update", 6: "kernel_gram", 7: "other", 8: "small_rank_drift", 9: "small_rank_value",
-             10: "tri_solve", 11: "small_rank_step"}
+             10: "tri_solve", 11: "small_rank_step", 12: "ipb_prep"}
 
 
 class Timeline:

@@ -25,6 +25,7 @@
 #include "small_rank.h"
 #include "small_rank_launch.h"
 #include "small_rank_step.h"
+#include "ipb_prep.h"
 #include "small_rank_step_launch.h"
 #include "step_params.h"
 
@@ -1492,6 +1493,7 @@ static thread_local RouteOption g_kg_noise_pregen{1};      // pls_set_option(PLS
 static thread_local RouteOption g_energy_fused_finish{1};   // pls_set_option(PLS_OPT_ENERGY_FUSED_FINISH): honour pls_block_desc.energy_sync
 static thread_local RouteOption g_ipb_step_operator{1};     // pls_set_option(PLS_OPT_IPB_STEP_OPERATOR): 1 = Pt route when the descriptor has it
 static thread_local RouteOption g_small_rank_step{1};  // pls_set_option(PLS_OPT_SMALL_RANK_STEP): 0 never, 1 launch-bound problems, 2 wherever it applies
+static thread_local RouteOption g_ipb_prep{1};         // pls_set_option(PLS_OPT_IPB_PREP): solve + coloured noise of a small inducing-point step in one launch
 static thread_local RouteOption g_solve_mode{1};  // pls_set_option(PLS_OPT_SOLVE_MODE): 0 block substitution, 1 inverse-factor products where available
 int64_t solve_mode() { return g_solve_mode.load(); }
 
@@ -1872,6 +1874,10 @@ int pls_set_option(int32_t option, int64_t value) {
       PLS_REQUIRE(value >= 0 && value <= 2, "set_option: small-rank step mode must be 0 (never), 1 (launch-bound) or 2 (always)");
       g_small_rank_step.store(value);
       return PLS_OK;
+    case PLS_OPT_IPB_PREP:
+      PLS_REQUIRE(value == 0 || value == 1, "set_option: ipb prep mode must be 0 or 1");
+      g_ipb_prep.store(value);
+      return PLS_OK;
     default: return fail(PLS_ERR_INVALID_ARGUMENT, "set_option: unknown option %d", (int)option);
   }
 }
@@ -1897,6 +1903,7 @@ int64_t pls_get_option(int32_t option) {
     case PLS_OPT_ENERGY_FUSED_FINISH: return g_energy_fused_finish.load();
     case PLS_OPT_KG_NOISE_PREGEN: return g_kg_noise_pregen.load();
     case PLS_OPT_SMALL_RANK_STEP: return g_small_rank_step.load();
+    case PLS_OPT_IPB_PREP: return g_ipb_prep.load();
     default: return -1;
   }
 }
@@ -2721,7 +2728,25 @@ static int ipb_step_impl(const pls_ipb_desc *basis, const pls_cost_desc *cost, c
     return launch_gemm_any(basis->LcT, basis->ldlct, Wd, j, basis->m, j, basis->m, fin, st, 0, 1,
                            TriScratch{basis->tri_scratch, basis->tri_scratch_bytes});
   }
-  rc = ipb_apply_kinv(basis, U, ldu, j, V, stream, xi);  // (xi is free until the noise is drawn)
+  // launch-bound problems (the reference's curve experiments build this basis with 10-100 inducing points and 50-100
+  // particles): the one-launch small-rank step after the solve and the coloured noise -- and those two in one launch of
+  // their own when the descriptor carries the inverse factor (csrc/ipb_prep.h): 2 launches per step instead of 8
+  const bool fast = ipb_fast_path(basis, cost, force_generic);
+  const bool one_launch = !fast && sr_step_route_for(basis->Kxz, basis->ldkxz, basis->m, basis->n, y, j) &&
+                          sr_step_fits(basis->m, basis->n, j, blocks, energy_in, workspace_bytes - 3 * mj);
+  bool coloured = false;  // the noise of this step already sits in e
+  if (one_launch && g_ipb_prep.load() != 0 && basis->m <= IPB_PREP_MAX_M && basis->Linv && basis->LinvT && solve_mode() != 0 &&
+      !(g_ipb_explicit_inverse.load() != 0 && basis->W)) {
+    const NoiseP nz0 = make_noisep(noise, blocks);
+    const int draw = nz0.kind == PLS_NOISE_PHILOX ? 1 : 0;
+    if (draw && !basis->LcT) return fail(PLS_ERR_INVALID_ARGUMENT, "ipb: Philox noise needs the Cholesky factor LcT");
+    const IpbPrepP pp{basis->LinvT, basis->ldlinvt, basis->Linv, basis->ldlinv, basis->LcT, basis->ldlct, U, ldu, V, j, e, j,
+                      (int)basis->m, j, draw, nz0};
+    rc = launch_ipb_prep(pp, st);
+    coloured = draw != 0;
+  } else {
+    rc = ipb_apply_kinv(basis, U, ldu, j, V, stream, xi);  // (xi is free until the noise is drawn)
+  }
   if (rc) return rc;
   if (ipb_fast_path(basis, cost, force_generic)) {
     const double inv_noise = 1.0 / cost->p[0];
@@ -2738,14 +2763,16 @@ static int ipb_step_impl(const pls_ipb_desc *basis, const pls_cost_desc *cost, c
     if (rc) return rc;
     return finish_energy_sums(blocks, energy_in, j, st);
   }
-  if (sr_step_route_for(basis->Kxz, basis->ldkxz, basis->m, basis->n, y, j) &&
-      sr_step_fits(basis->m, basis->n, j, blocks, energy_in, workspace_bytes - 3 * mj)) {
-    // launch-bound problems (the reference's curve experiments build this basis with 10-100 inducing points and 50-100
-    // particles): V and the coloured noise as above, then projection, cost, back-projection, slab sum, prior drift M V, update and
-    // energies in ONE launch (csrc/small_rank_step.h) -- 4-5 launches per step instead of 8
+  if (one_launch) {
     NoiseP nz = make_noisep(noise, blocks);
-    rc = ipb_colour_noise(basis, nz, j, xi, e, st);
-    if (rc) return rc;
+    if (coloured) {
+      nz.kind = PLS_NOISE_INJECTED;
+      nz.xi = e;
+      nz.ldxi = j;
+    } else {
+      rc = ipb_colour_noise(basis, nz, j, xi, e, st);
+      if (rc) return rc;
+    }
     bool taken = false;
     const SrStepOperands ops{basis->Kxz, basis->ldkxz, basis->m, basis->n, V, j, U, ldu, nullptr, (double)basis->m};
     rc = sr_step_launch(ops, make_costp(cost), y, j, make_etap(eta, blocks), nz, out, ldo, out_mode, energy_in, blocks, D,

@@ -68,6 +68,8 @@ def test_options_validate_without_touching_the_gpu():
     assert lib.pls_set_option(L.OPT_IPB_STEP_OPERATOR, 0) == 0 and lib.pls_set_option(L.OPT_IPB_STEP_OPERATOR, 1) == 0
     assert lib.pls_get_option(L.OPT_SMALL_RANK_STEP) == 1 and lib.pls_set_option(L.OPT_SMALL_RANK_STEP, 3) != 0
     assert lib.pls_set_option(L.OPT_SMALL_RANK_STEP, 2) == 0 and lib.pls_set_option(L.OPT_SMALL_RANK_STEP, 1) == 0
+    assert lib.pls_get_option(L.OPT_IPB_PREP) == 1 and lib.pls_set_option(L.OPT_IPB_PREP, 2) != 0
+    assert lib.pls_set_option(L.OPT_IPB_PREP, 0) == 0 and lib.pls_set_option(L.OPT_IPB_PREP, 1) == 0
     assert lib.pls_step_sync_words(512) == 32 + 2 and lib.pls_step_sync_words(17) == 2 + 1 and lib.pls_step_sync_words(0) == 0
     assert lib.pls_tri_scratch_bytes(1024, 1024) == 16384 + 8 * 16 * 2 * 4096 * 8 and lib.pls_tri_scratch_bytes(0, 5) == 0
 

@@ -369,7 +369,12 @@ def test_edges_of_the_one_launch_step(P, route, n, mk, j):
 # ------------------------------------------------------------------------------------------------------------
 # the inducing-point basis (basis/inducing_point.py:60-135): V = k(Z,Z)^-1 U and the coloured noise by their own launches, then
 # projection k(X,Z) V, cost, back-projection, prior drift M V, update and energies in the same one launch
-IPB_SHAPES = [(100, 10, 64, 1), (333, 17, 37, 2), (3000, 30, 40, 2), (1100, 128, 90, 3)]
+IPB_SHAPES = [(100, 10, 64, 1), (333, 17, 37, 2), (3000, 30, 40, 2), (1100, 128, 90, 3), (640, 100, 130, 2), (500, 65, 16, 2)]
+
+
+def _ipb_prep(P, mode):
+    L = P.pkg._lib
+    L.check(L.load().pls_set_option(L.OPT_IPB_PREP, mode), "pls_set_option")
 
 
 @pytest.mark.parametrize("n,m,j,d", IPB_SHAPES)
@@ -393,8 +398,15 @@ def test_inducing_point_basis_takes_the_one_launch_step(P, route, n, m, j, d):
         e_new = torch.full((j,), float("nan"), device="cuda")
         route(2)
         names = _timeline_names(P, lambda: gb.fused_step(gc, cu(u), eta, noise=spec, input_energy=e_new))
-        assert "small_rank_step" in names and not {"small_rank", "small_rank_value", "gemm_cost", "langevin_update"} & set(names), names
+        assert names == ["ipb_prep", "small_rank_step"], names  # (solve [+ coloured noise], then everything else of the step)
         got = gb.fused_step(gc, cu(u), eta, noise=spec)
+        _ipb_prep(P, 0)
+        try:  # the solve as two triangular products of their own: the same V to rounding
+            names = _timeline_names(P, lambda: gb.fused_step(gc, cu(u), eta, noise=spec))
+            assert names == ["gemm_store", "small_rank_step"], names
+            assert relerr(gb.fused_step(gc, cu(u), eta, noise=spec), got) < 1e-11, name
+        finally:
+            _ipb_prep(P, 1)
         got_e = gb.fused_step(gc, cu(u), eta, noise=spec, input_energy=e_new)
         assert torch.equal(got, got_e), "the energy by-product must not move the step"
         assert relerr(got, want) < tol, name
@@ -411,7 +423,14 @@ def test_inducing_point_basis_takes_the_one_launch_step(P, route, n, m, j, d):
         pspec = P.basis.NoiseSpec(seed=77, step=3)
         old_p = gb.fused_step(gc, cu(u), eta, noise=pspec)
         route(2)
-        assert relerr(gb.fused_step(gc, cu(u), eta, noise=pspec), old_p) < 1e-11, name
+        new_p = gb.fused_step(gc, cu(u), eta, noise=pspec)
+        assert relerr(new_p, old_p) < 1e-11, name
+        assert _timeline_names(P, lambda: gb.fused_step(gc, cu(u), eta, noise=pspec)) == ["ipb_prep", "small_rank_step"]
+        _ipb_prep(P, 0)
+        try:
+            assert relerr(gb.fused_step(gc, cu(u), eta, noise=pspec), new_p) < 1e-11, name
+        finally:
+            _ipb_prep(P, 1)
     assert checked >= 5, checked
     assert int(gb._step_sync(j, torch.device("cuda")).abs().sum()) == 0, "the arrival counters are left zero"
 
@@ -433,7 +452,8 @@ def test_inducing_point_training_loop_polls_the_sums_of_the_one_launch_step(P, r
         P.pkg.train_pls(pls, u0.clone(), 20, 1e-5, 1e9)
     summary = tl.summary()
     assert summary["small_rank_step"]["launches"] >= 20, summary
-    assert not {"small_rank", "gemm_cost", "langevin_update", "block_means"} & set(summary), summary
+    assert not {"small_rank", "gemm_cost", "langevin_update", "block_means", "gemm_store"} & set(summary), summary
+    assert summary["ipb_prep"]["launches"] == summary["small_rank_step"]["launches"], summary
     runs = {}
     for mode in ("pipelined", "plain"):
         if mode == "plain":

@@ -22,9 +22,12 @@ for (n, m, j, d) in ((100, 10, 64, 1), (1000, 32, 100, 1), (4096, 128, 512, 4)):
             u = (1.0 + 0.1 * torch.randn(basis.approximation_dimension, j, generator=g)).cuda()
             eta = 1e-9
             train_pls(pls, u.clone(), 30, eta, 1e9)
-            torch.cuda.synchronize(); t0 = time.perf_counter()
-            _, e = train_pls(pls, u.clone(), 2000, eta, 1e9)
-            torch.cuda.synchronize(); w = time.perf_counter() - t0
+            ws = []
+            for _ in range(3):  # (median of three runs: one run in a few dozen is 1.5-2x slow as a whole, tools/sr_step_jitter.py)
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                _, e = train_pls(pls, u.clone(), 2000, eta, 1e9)
+                torch.cuda.synchronize(); ws.append(time.perf_counter() - t0)
+            w = sorted(ws)[1]
             out = torch.empty_like(u); en = torch.empty(j, device="cuda")
             with L.Timeline(64) as tl:
                 basis.fused_step(cost, u, eta, out=out, new_state=True, noise=NoiseSpec(seed=1, step=0), input_energy=en)
