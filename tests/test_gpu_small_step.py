@@ -469,3 +469,29 @@ def test_inducing_point_training_loop_polls_the_sums_of_the_one_launch_step(P, r
     assert relerr(runs["pipelined"][0], runs["plain"][0]) < 1e-12
     assert np.allclose(runs["pipelined"][1], runs["plain"][1], rtol=1e-11)
     assert torch.equal(runs["pipelined"][2], runs["plain"][2])
+
+
+@pytest.mark.parametrize("m", [1, 2, 15, 16, 17, 31, 33, 48, 49, 63, 64, 65, 80, 81, 97, 112, 113, 127])
+def test_solve_and_coloured_noise_in_one_launch_at_every_rank(P, route, m):
+    """csrc/ipb_prep.h against the launches it replaces (two triangular products, fill, third product) for ranks on both sides
+    of every 16-row tile edge and ragged column counts: same V, same draws, to rounding."""
+    n = 200 + m
+    for j in (1, 16, 17, 50):
+        pr = make_problem(n, m, j, 2, seed=13 * m + j + FUZZ_SEED)
+        pr["ls"] = pr["ls"] * 0.3
+        ob, gb = build_ipb(P, pr)
+        name, oc, gc = make_costs(P, pr["y"], pr["fstar"], pr["gen"])[2]
+        u = cu(pr["u"])
+        route(2)
+        spec = P.basis.NoiseSpec(seed=5, step=7)
+        e1 = torch.empty(j, device="cuda")
+        got = gb.fused_step(gc, u, 1e-3, noise=spec, input_energy=e1)
+        assert _timeline_names(P, lambda: gb.fused_step(gc, u, 1e-3, noise=spec)) == ["ipb_prep", "small_rank_step"]
+        _ipb_prep(P, 0)
+        try:
+            e0 = torch.empty(j, device="cuda")
+            want = gb.fused_step(gc, u, 1e-3, noise=spec, input_energy=e0)
+        finally:
+            _ipb_prep(P, 1)
+        assert torch.isfinite(got).all()
+        assert relerr(got, want) < 1e-11 and relerr(e1, e0) < 1e-11, (m, j)
