@@ -21,6 +21,7 @@ import math
 import os
 import sys
 import time
+import warnings
 
 import torch
 
@@ -312,6 +313,49 @@ def profiler_grid_line(args):
     print(json.dumps(line), flush=True)
 
 
+def reference_scale_block(pkg, iterations: int):
+    """`train_pls` (experiments/trainers.py:139-162) at the sizes the reference's own experiments and profiler run at
+    (experiments/curves/*/config.yaml, experiments/profiler/config.yaml): microseconds per iteration for both bases and a cost
+    with / without the Gaussian algebra -- the launch-bound regime of csrc/small_rank_step.h and csrc/ipb_prep.h.  Median of
+    three runs of `iterations` iterations each; extra to BASELINE.json's metric."""
+    import statistics
+
+    from projected_langevin_sampling_amd.basis import InducingPointBasis, OrthonormalBasis
+    from projected_langevin_sampling_amd.costs import BernoulliCost, GaussianCost
+    from projected_langevin_sampling_amd.link_functions import IdentityLinkFunction, SigmoidLinkFunction
+    from projected_langevin_sampling_amd.trainers import train_pls
+
+    rows = []
+    for (n, m, j, d) in ((100, 10, 64, 1), (1000, 32, 100, 1), (4096, 128, 512, 4)):
+        g = torch.Generator().manual_seed(0)
+        x = torch.rand(n, d, generator=g, dtype=torch.float64) * 2 - 1
+        z = x[torch.randperm(n, generator=g)[:m]].clone()
+        y = torch.sin(2.0 * x.sum(dim=1)) + 0.1 * torch.randn(n, generator=g, dtype=torch.float64)
+        kern = pkg.PLSKernel(pkg.ARDKernel(torch.full((d,), 0.5, dtype=torch.float64), 1.0), z)
+        row = {"n": n, "m": m, "j": j}
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")  # (the Cholesky jitter note of a random Z)
+            bases = (("orthonormal", OrthonormalBasis(kern, z, x, 1e-8, verbose=False)), ("inducing_point", InducingPointBasis(kern, z, y[:m], x)))
+        for bname, basis in bases:
+            for cname, cost in (("gaussian_identity", GaussianCost(0.1, y, IdentityLinkFunction())),
+                                ("bernoulli_sigmoid", BernoulliCost((y > 0).double(), SigmoidLinkFunction()))):
+                pls = pkg.PLS(basis, cost)
+                u = (1.0 + 0.1 * torch.randn(basis.approximation_dimension, j, generator=g, dtype=torch.float64)).cuda()
+                train_pls(pls, u.clone(), 30, 1e-9, 1e9)
+                runs = []
+                for _ in range(3):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    _, e = train_pls(pls, u.clone(), iterations, 1e-9, 1e9)
+                    torch.cuda.synchronize()
+                    runs.append((time.perf_counter() - t0) / max(len(e), 1) * 1e6)
+                row[f"{bname}/{cname}"] = round(statistics.median(runs), 2)
+        rows.append(row)
+    return {"unit": "us per train_pls iteration (step + energy + early-stop test)", "iterations": iterations, "rows": rows,
+            "protocol": "experiments/trainers.py:139-162 through the drop-in train_pls; sizes of experiments/curves/*/config.yaml and "
+                        "experiments/profiler/config.yaml; median of 3 runs"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -334,6 +378,8 @@ def main():
                     help="like-for-like steps of the `sustained` block (>= 10 s at configs[1]; 0 = skip)")
     ap.add_argument("--profiler-steps", type=int, default=100,
                     help="T of the reference's profiler protocol: construction + T steps timed as one block (0 = skip)")
+    ap.add_argument("--reference-scale-iterations", type=int, default=1000,
+                    help="iterations per run of the `reference_scale` block: train_pls at the reference's experiment sizes (0 = skip)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="development aid: run rank 0's particle shard of an N-GPU job on ONE GPU (no collectives); "
                          "the JSON line is marked emulated and is not a scaling result")
@@ -1026,6 +1072,10 @@ def main():
                         "drop-in API",
         }
         log(f"profiler protocol: construction {t_construct:.2f} s + {args.profiler_steps} steps = {t_block:.2f} s")
+    if rank == 0 and world == 1 and shard_world == 1 and args.reference_scale_iterations > 0:
+        out["reference_scale"] = reference_scale_block(pkg, args.reference_scale_iterations)
+        log("reference scale: " + "; ".join(f"N={r['n']} M={r['m']} J={r['j']}: onb {r['orthonormal/gaussian_identity']} / {r['orthonormal/bernoulli_sigmoid']}, "
+                                            f"ipb {r['inducing_point/gaussian_identity']} / {r['inducing_point/bernoulli_sigmoid']} us" for r in out["reference_scale"]["rows"]))
     # ---- CPU baseline (rank 0, N=1 only) ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         lam_all, vec_all = basis.eigenvalues.cpu(), basis.eigenvectors.cpu()
