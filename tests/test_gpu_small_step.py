@@ -471,7 +471,7 @@ def test_inducing_point_training_loop_polls_the_sums_of_the_one_launch_step(P, r
     assert torch.equal(runs["pipelined"][2], runs["plain"][2])
 
 
-@pytest.mark.parametrize("m", [1, 2, 15, 16, 17, 31, 33, 48, 49, 63, 64, 65, 80, 81, 97, 112, 113, 127])
+@pytest.mark.parametrize("m", [1, 2, 3, 5, 15, 16, 17, 18, 31, 32, 33, 48, 49, 63, 64, 65, 80, 81, 97, 112, 113, 127])
 def test_solve_and_coloured_noise_in_one_launch_at_every_rank(P, route, m):
     """csrc/ipb_prep.h against the launches it replaces (two triangular products, fill, third product) for ranks on both sides
     of every 16-row tile edge and ragged column counts: same V, same draws, to rounding."""
