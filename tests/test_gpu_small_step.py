@@ -404,7 +404,8 @@ def test_inducing_point_basis_takes_the_one_launch_step(P, route, n, m, j, d):
         try:  # the solve as two triangular products of their own: the same V to rounding
             names = _timeline_names(P, lambda: gb.fused_step(gc, cu(u), eta, noise=spec))
             assert names == ["gemm_store", "small_rank_step"], names
-            assert relerr(gb.fused_step(gc, cu(u), eta, noise=spec), got) < 1e-11, name
+            # (a tenth of the oracle tolerance: for a cost with a pole the two solves' rounding is amplified like anything else)
+            assert relerr(gb.fused_step(gc, cu(u), eta, noise=spec), got) < max(1e-11, 0.1 * tol), name
         finally:
             _ipb_prep(P, 1)
         got_e = gb.fused_step(gc, cu(u), eta, noise=spec, input_energy=e_new)
@@ -418,17 +419,17 @@ def test_inducing_point_basis_takes_the_one_launch_step(P, route, n, m, j, d):
         route(0)
         e_old = torch.empty(j, device="cuda")
         old = gb.fused_step(gc, cu(u), eta, noise=spec, input_energy=e_old)
-        assert relerr(got, old) < 1e-11 and relerr(e_new, e_old) < 1e-11, name
+        assert relerr(got, old) < max(1e-11, 0.1 * tol) and relerr(e_new, e_old) < 1e-11, name
         # Philox noise: the same draws, coloured by the same factor, whichever kernels finish the step
         pspec = P.basis.NoiseSpec(seed=77, step=3)
         old_p = gb.fused_step(gc, cu(u), eta, noise=pspec)
         route(2)
         new_p = gb.fused_step(gc, cu(u), eta, noise=pspec)
-        assert relerr(new_p, old_p) < 1e-11, name
+        assert relerr(new_p, old_p) < max(1e-11, 0.1 * tol), name
         assert _timeline_names(P, lambda: gb.fused_step(gc, cu(u), eta, noise=pspec)) == ["ipb_prep", "small_rank_step"]
         _ipb_prep(P, 0)
         try:
-            assert relerr(gb.fused_step(gc, cu(u), eta, noise=pspec), new_p) < 1e-11, name
+            assert relerr(gb.fused_step(gc, cu(u), eta, noise=pspec), new_p) < max(1e-11, 0.1 * tol), name
         finally:
             _ipb_prep(P, 1)
     assert checked >= 5, checked
@@ -446,10 +447,12 @@ def test_inducing_point_training_loop_polls_the_sums_of_the_one_launch_step(P, r
     pls = P.pkg.PLS(gb, gc)
     assert gb.supports_energy_sums(gc) and gb.uses_sums16(gc)
     u0 = cu(pr["u"])
+    # a step size inside the stability bound of the stiffest mode of the prior drift M k(Z,Z)^-1 (eta M / lambda_min < 2)
+    eta = 0.25 * float(torch.linalg.eigvalsh(ob.base_gram_induce).min()) / 16
     route(1)
     with P.pkg._lib.Timeline(512) as tl:
         torch.manual_seed(3)
-        P.pkg.train_pls(pls, u0.clone(), 20, 1e-5, 1e9)
+        P.pkg.train_pls(pls, u0.clone(), 20, eta, 1e9)
     summary = tl.summary()
     assert summary["small_rank_step"]["launches"] >= 20, summary
     assert not {"small_rank", "gemm_cost", "langevin_update", "block_means", "gemm_store"} & set(summary), summary
@@ -460,12 +463,12 @@ def test_inducing_point_training_loop_polls_the_sums_of_the_one_launch_step(P, r
             gb.supports_input_energy = lambda c: False
         try:
             torch.manual_seed(44)
-            out, energies = P.pkg.train_pls(pls, u0.clone(), 40, 1e-5, 1e9)
+            out, energies = P.pkg.train_pls(pls, u0.clone(), 40, eta, 1e9)
             runs[mode] = (out, energies, torch.get_rng_state())
         finally:
             if mode == "plain":
                 del gb.supports_input_energy
-    assert len(runs["pipelined"][1]) == len(runs["plain"][1]) == 40
+    assert len(runs["pipelined"][1]) == len(runs["plain"][1]) == 40 and np.isfinite(runs["plain"][1]).all()
     assert relerr(runs["pipelined"][0], runs["plain"][0]) < 1e-12
     assert np.allclose(runs["pipelined"][1], runs["plain"][1], rtol=1e-11)
     assert torch.equal(runs["pipelined"][2], runs["plain"][2])
