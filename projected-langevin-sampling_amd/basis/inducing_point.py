@@ -207,8 +207,9 @@ class InducingPointBasis(PLSBasis):
         return out
 
     def supports_lagged_energies(self, cost) -> bool:
-        """(see OrthonormalBasis.supports_lagged_energies) -- for loops that stay in whitened coordinates"""
-        return self.supports_energy_sums(cost)
+        """(see OrthonormalBasis.supports_lagged_energies) -- for loops that stay in whitened coordinates: the Gaussian/identity
+        route only (the one-launch small-rank step finishes its energies itself)"""
+        return bool(cost.is_native()) and self.whitened and self._is_gaussian(cost, False)
 
     def energy_partial_rows_bytes(self, j: int) -> int:
         return int(L.load().pls_energy_partials_bytes(self.approximation_dimension, j))

@@ -446,6 +446,7 @@ def test_inducing_point_training_loop_polls_the_sums_of_the_one_launch_step(P, r
     name, oc, gc = make_costs(P, pr["y"], pr["fstar"], pr["gen"])[2]
     pls = P.pkg.PLS(gb, gc)
     assert gb.supports_energy_sums(gc) and gb.uses_sums16(gc)
+    assert not gb.supports_lagged_energies(gc), "lagged energies belong to the Gaussian/identity routes"
     u0 = cu(pr["u"])
     # a step size inside the stability bound of the stiffest mode of the prior drift M k(Z,Z)^-1 (eta M / lambda_min < 2)
     eta = 0.25 * float(torch.linalg.eigvalsh(ob.base_gram_induce).min()) / 16
