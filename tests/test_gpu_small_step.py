@@ -499,3 +499,29 @@ def test_solve_and_coloured_noise_in_one_launch_at_every_rank(P, route, m):
             _ipb_prep(P, 1)
         assert torch.isfinite(got).all()
         assert relerr(got, want) < 1e-11 and relerr(e1, e0) < 1e-11, (m, j)
+
+
+@pytest.mark.parametrize("j,k", [(40, 4), (300, 8)])
+def test_inducing_point_captured_training_equals_the_plain_loop(P, route, j, k):
+    """train_pls_captured (K steps + energies per hipGraph replay: the capture owns the counters of the one-launch step and asks
+    for the 256-column chunk sums, the kernel's second hand-over) on the inducing-point basis with a cost without the Gaussian
+    algebra, against the plain loop over the same counter-based noise stream."""
+    pr = make_problem(400, 12, j, 2, seed=19 + FUZZ_SEED)
+    pr["ls"] = pr["ls"] * 0.35
+    ob, gb = build_ipb(P, pr)
+    name, oc, gc = make_costs(P, pr["y"], pr["fstar"], pr["gen"])[2]
+    pls = P.pkg.PLS(gb, gc)
+    eta = 0.25 * float(torch.linalg.eigvalsh(ob.base_gram_induce).min()) / 12
+    seed, epochs = 4242, 21
+    route(1)
+    u = cu(pr["u"])
+    nxt = torch.empty_like(u)
+    want_e = []
+    for t in range(epochs):
+        gb.fused_step(gc, u, eta, out=nxt, new_state=True, noise=P.basis.NoiseSpec(seed=seed, step=t))
+        u, nxt = nxt, u
+        want_e.append(pls.particle_energy_potential(u).mean().item())
+    got_u, got_e = P.pkg.train_pls_captured(pls, cu(pr["u"]), epochs, eta, 1e9, steps_per_replay=k, seed=seed)
+    assert len(got_e) == epochs and np.isfinite(got_e).all()
+    assert torch.equal(got_u, u)
+    assert np.allclose(got_e, want_e, rtol=1e-11)
