@@ -207,6 +207,13 @@ typedef struct {
    * Q (q_inv_noise).  A call that asks for energy_in keeps the three-launch route (the energy is a quadratic form in S). */
   const double *Pt;
   int64_t ldpt;
+  /* Optional (ABI 5): Awa ((n + m) x m, k-major like Kxz, 16-byte aligned rows, even ldawa; pls_ipb_build_whitened_operand),
+   * the forward operand of WHITENED particles with the prior as rows: rows [0, n) = k(X,Z) Lc^-T (F = Awa S for S = Lc^-1 U),
+   * rows [n, n + m) = sqrt(m) Lc^-T, whose "cost" is f^2 / 2 -- their back-projection is the prior drift m (Lc^T Lc)^-1 S and
+   * their cost the prior energy (m / 2) |k(Z,Z)^-1 U|^2.  With it the step of a cost without the Gaussian algebra in whitened
+   * coordinates is the one-launch small-rank step and nothing else (pls_ipb_whitened_generic_step). */
+  const double *Awa;
+  int64_t ldawa;
 } pls_ipb_desc;
 
 /* Step-size search (experiments/runners.py:331-446): the S candidate step sizes run as S column blocks of ONE particle
@@ -603,6 +610,18 @@ size_t pls_ipb_whitened_workspace_bytes(const pls_ipb_desc *basis, int64_t j);
 int pls_ipb_whitened_step(const pls_ipb_desc *basis, const pls_cost_desc *cost, const double *S, int64_t lds, int64_t j,
                           double eta, const pls_noise_desc *noise, double *out, int64_t ldo, int32_t out_mode, double *energy_in,
                           void *workspace, size_t workspace_bytes, void *stream);
+/* The same for ANY cost, on at most 128 inducing points, in ONE launch (csrc/small_rank_step.h over pls_ipb_desc.Awa): dS =
+ * -eta Awa^T g + sqrt(2 eta) xi with g = d cost / d f on the data rows and f on the prior rows -- inducing_point.py:117-150 in
+ * whitened coordinates, no solve and no coloured noise per step (a training loop whitens once, unwhitens once).  y: the n targets.
+ * blocks: step sizes, and step_sync / energy_sums / energy_sums16 as for pls_onb_step_blocks.  _applies: 1 if the descriptor,
+ * the targets' alignment and the sizes allow it (else the caller stays in the original coordinates: pls_ipb_step). */
+int pls_ipb_build_whitened_operand(const pls_ipb_desc *basis, double *Awa, int64_t ldawa, void *stream);
+int pls_ipb_whitened_generic_applies(const pls_ipb_desc *basis, const double *y, int64_t j);
+size_t pls_ipb_whitened_generic_workspace_bytes(const pls_ipb_desc *basis, int64_t j);
+int pls_ipb_whitened_generic_step(const pls_ipb_desc *basis, const pls_cost_desc *cost, const double *y, const double *S,
+                                  int64_t lds, int64_t j, double eta, const pls_block_desc *blocks, const pls_noise_desc *noise,
+                                  double *out, int64_t ldo, int32_t out_mode, double *energy_in, void *workspace,
+                                  size_t workspace_bytes, void *stream);
 int pls_ipb_whitened_step_blocks(const pls_ipb_desc *basis, const pls_cost_desc *cost, const double *S, int64_t lds, int64_t j,
                                  const pls_block_desc *blocks, const pls_noise_desc *noise, double *out, int64_t ldo,
                                  int32_t out_mode, double *energy_in, void *workspace, size_t workspace_bytes, void *stream);

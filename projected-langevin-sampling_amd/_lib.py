@@ -94,6 +94,8 @@ class IpbDesc(C.Structure):
         ("tri_scratch_bytes", C.c_size_t),
         ("Pt", C.c_void_p),
         ("ldpt", C.c_int64),
+        ("Awa", C.c_void_p),
+        ("ldawa", C.c_int64),
     ]
 
 
@@ -189,6 +191,10 @@ SIGNATURES = {
     "pls_ipb_whitened_step": (C.c_int, [_ID, _CD, _P, _I64, _I64, _D, _ND, _P, _I64, _I32, _P, _P, _SZ, _P]),
     "pls_ipb_whitened_step_blocks": (C.c_int, [_ID, _CD, _P, _I64, _I64, _BD, _ND, _P, _I64, _I32, _P, _P, _SZ, _P]),
     "pls_ipb_whitened_energy": (C.c_int, [_ID, _CD, _P, _I64, _I64, _P, _P, _SZ, _P]),
+    "pls_ipb_build_whitened_operand": (C.c_int, [_ID, _P, _I64, _P]),
+    "pls_ipb_whitened_generic_applies": (C.c_int, [_ID, _P, _I64]),
+    "pls_ipb_whitened_generic_workspace_bytes": (_SZ, [_ID, _I64]),
+    "pls_ipb_whitened_generic_step": (C.c_int, [_ID, _CD, _P, _P, _I64, _I64, _D, _BD, _ND, _P, _I64, _I32, _P, _P, _SZ, _P]),
     "pls_onb_step_blocks": (C.c_int, [_OD, _CD, _P, _P, _I64, _I64, _BD, _ND, _P, _I64, _I32, _I32, _P, _P, _SZ, _P]),
     "pls_ipb_step_blocks": (C.c_int, [_ID, _CD, _P, _P, _I64, _I64, _BD, _ND, _P, _I64, _I32, _I32, _P, _P, _SZ, _P]),
 }

@@ -67,6 +67,7 @@ class InducingPointBasis(PLSBasis):
         self._ct = None
         self._q_inv_noise = 0.0
         self._white_key = None
+        self._Awa = None  # k(X,Z) Lc^-T over sqrt(M) Lc^-T: the forward operand of whitened particles with the prior as rows
 
     @property
     def approximation_dimension(self) -> int:
@@ -89,6 +90,8 @@ class InducingPointBasis(PLSBasis):
         sc = f.tri_scratch()  # balanced triangular products on narrow particle shards (pls_ipb_desc.tri_scratch)
         if sc is not None:
             d.tri_scratch, d.tri_scratch_bytes = sc.data_ptr(), sc.numel() * 8
+        if self._Awa is not None:
+            d.Awa, d.ldawa = self._Awa.data_ptr(), L.ld(self._Awa)
         if with_gaussian and self._B is not None:
             d.B, d.ldb, d.c = self._B.data_ptr(), L.ld(self._B), self._c.data_ptr()
             if self._Q is not None and self.whitened:
@@ -175,7 +178,6 @@ class InducingPointBasis(PLSBasis):
         """One Langevin step of whitened particles (pls_ipb_whitened_step): ONE M x M x J contraction with the update,
         the noise and -- optionally -- the energy of the input particles in its epilogue.  ``noise`` injected = xi itself
         (standard normal, not coloured); Philox noise draws the xi of fused_step's e = Lc xi."""
-        assert self._is_gaussian(cost, False), "whitened steps exist for the Gaussian cost with the identity link"
         s = _rows_contiguous(L.require_gpu_tensor(whitened, "whitened particles"))
         j = s.shape[1]
         if out is None:
@@ -187,6 +189,8 @@ class InducingPointBasis(PLSBasis):
             return out
         assert out.data_ptr() != s.data_ptr(), "whitened_step: out must not alias its input"
         assert self.whitened, "whitened coordinates are switched off on this basis"
+        if not self._is_gaussian(cost, False):  # any other cost: the one-launch small-rank step over Awa (at most 128 points)
+            return self._whitened_generic_step(cost, s, step_size, out, new_state, noise, input_energy, blocks, workspace)
         self._prepare_for(cost)
         lib = L.load()
         desc = self._desc(with_gaussian=True)
@@ -204,6 +208,77 @@ class InducingPointBasis(PLSBasis):
             L.check(lib.pls_ipb_whitened_step_blocks(desc, cost.desc(), s.data_ptr(), L.ld(s), j, blocks.desc(), nd,
                                                      out.data_ptr(), L.ld(out), mode, L.ptr(input_energy), L.ptr(ws), ws_bytes,
                                                      L.stream_ptr()), "pls_ipb_whitened_step_blocks")
+        return out
+
+    # ---- whitened coordinates for the costs WITHOUT the Gaussian algebra (at most 128 inducing points, launch-bound sizes) ----
+    def whitened_generic_applies(self, cost, j: int) -> bool:
+        """True if a loop over `j` particle columns may keep this cost's particles whitened: every step is then ONE launch
+        (pls_ipb_whitened_generic_step: the one-launch small-rank step over k(X,Z) Lc^-T with the prior as rows) instead of the
+        solve, the coloured noise and the step.  The operand is built on first use."""
+        if not (self.whitened and cost.is_native()) or self._is_gaussian(cost, False):
+            return False
+        if not (1 <= self.approximation_dimension <= self.SMALL_RANK_MAX) or self._chol.Linv is None or j <= 0:
+            return False
+        if self._Awa is None:
+            m, n = self.approximation_dimension, self._n
+            awa = alloc_matrix(n + m, m, self._Kxz.device)
+            L.check(L.load().pls_ipb_build_whitened_operand(self._desc(), awa.data_ptr(), L.ld(awa), L.stream_ptr()),
+                    "pls_ipb_build_whitened_operand")
+            self._Awa = awa
+        return bool(L.load().pls_ipb_whitened_generic_applies(self._desc(), cost.y_device().data_ptr(), int(j)))
+
+    def _whitened_generic_call(self, cost, j: int, device):
+        lib = L.load()
+        desc = self._desc()
+        ws_bytes = int(lib.pls_ipb_whitened_generic_workspace_bytes(desc, j))
+        return lib, desc, ws_bytes
+
+    def whitened_generic_sums_step_launcher(self, cost, state: torch.Tensor, eta: torch.Tensor):
+        """(see OrthonormalBasis.sums_step_launcher) -- pls_ipb_whitened_generic_step on WHITENED particles, pre-bound"""
+        s = _rows_contiguous(L.require_gpu_tensor(state, "whitened particles"))
+        j = s.shape[1]
+        assert self.whitened_generic_applies(cost, j)
+        lib, desc, ws_bytes = self._whitened_generic_call(cost, j, s.device)
+        cd, y = cost.desc(), cost.y_device()
+        ws = torch.empty((ws_bytes + 7) // 8 + 1, dtype=torch.float64, device=s.device)
+        sync = torch.zeros(max(int(lib.pls_step_sync_words(j)), 1), dtype=torch.int32, device=s.device)
+        blocks, nd = L.BlockDesc(), L.NoiseDesc()
+        blocks.block_cols, blocks.eta = j, L.require_gpu_tensor(eta, "eta").data_ptr()
+        blocks.step_sync = sync.data_ptr()
+        nd.kind, nd.step, nd.j_offset = L.NOISE_PHILOX, 0, int(self.j_offset)
+        fn = lib.pls_ipb_whitened_generic_step
+        y_ptr, ws_ptr, stream, mode = y.data_ptr(), ws.data_ptr(), L.stream_ptr(), L.OUT_NEW_STATE
+
+        def launch(s_ptr, lds, out_ptr, ldo, seed, energy_ptr, sums_ptr):
+            nd.seed = seed
+            blocks.energy_sums16 = sums_ptr
+            rc = fn(desc, cd, y_ptr, s_ptr, lds, j, 0.0, blocks, nd, out_ptr, ldo, mode, energy_ptr, ws_ptr, ws_bytes, stream)
+            if rc:
+                L.check(rc, "pls_ipb_whitened_generic_step")
+
+        launch.keep_alive = (desc, cd, y, ws, sync, eta, self)
+        return launch
+
+    def _whitened_generic_step(self, cost, s, step_size, out, new_state, noise, input_energy, blocks, workspace):
+        j = s.shape[1]
+        assert self.whitened_generic_applies(cost, j), "this cost / size has no whitened step: stay in the original coordinates"
+        lib, desc, ws_bytes = self._whitened_generic_call(cost, j, s.device)
+        ws = self._pick_workspace(workspace, ws_bytes, s.device)
+        nd = (noise if noise is not None else self._draw_noise_spec(None)).desc()
+        bd = None if blocks is None else blocks.desc()
+        if bd is None:
+            bd = L.BlockDesc()
+            bd.block_cols, bd.eta = j, self._eta_word(step_size, s.device).data_ptr()
+        if not bd.step_sync:
+            bd.step_sync = self._step_sync(j, s.device).data_ptr()
+        try:
+            L.check(lib.pls_ipb_whitened_generic_step(desc, cost.desc(), cost.y_device().data_ptr(), s.data_ptr(), L.ld(s), j, 0.0, bd,
+                                                      nd, out.data_ptr(), L.ld(out), L.OUT_NEW_STATE if new_state else L.OUT_DELTA,
+                                                      L.ptr(input_energy), ws.data_ptr(), ws_bytes, L.stream_ptr()),
+                    "pls_ipb_whitened_generic_step")
+        except L.PlsHipError:
+            self.zero_step_sync()
+            raise
         return out
 
     def supports_lagged_energies(self, cost) -> bool:
@@ -253,6 +328,13 @@ class InducingPointBasis(PLSBasis):
         """e_j of whitened particles: S^T Q S / 2 - c~^T S + y^T y / (2 sigma2) (pls_ipb_whitened_energy)."""
         s = _rows_contiguous(L.require_gpu_tensor(whitened, "whitened particles"))
         j = s.shape[1]
+        if not self._is_gaussian(cost, False):
+            # (plain loops and final values only: a step with step size zero and no noise, for its energy by-product)
+            e = torch.empty(j, dtype=torch.float64, device=s.device)
+            if j:
+                scratch = torch.empty_like(s, memory_format=torch.contiguous_format)
+                self._whitened_generic_step(cost, s, 0.0, scratch, False, NoiseSpec(none=True), e, None, None)
+            return e
         self._prepare_for(cost)
         lib = L.load()
         desc = self._desc(with_gaussian=True)

@@ -1277,6 +1277,12 @@ __global__ __launch_bounds__(256) void scale_copy_kernel(const double *__restric
   if (i < n) out[i] = alpha * in[i];
 }
 
+__global__ __launch_bounds__(256) void scale_copy_2d_kernel(const double *__restrict__ in, int64_t ldin, double *__restrict__ out,
+                                                             int64_t ldout, int64_t rows, int64_t cols, double alpha) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < rows * cols) out[(i / cols) * ldout + i % cols] = alpha * in[(i / cols) * ldin + i % cols];
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // greedy conditional-variance inducing-point selection (reference: src/inducing_point_selectors/conditional_variance.py)
 // ---------------------------------------------------------------------------------------------------------------
@@ -2248,6 +2254,7 @@ struct SrStepOperands {
   int64_t lduadd;
   const double *lam;
   double pconst;
+  int64_t n_data = -1;  // rows of Lb that are data rows (the rest: prior rows, small_rank_step.h); -1: all n
 };
 
 // bytes the one-launch step takes from the workspace for j columns: its slabs, and its counters when the caller brings none
@@ -2308,6 +2315,7 @@ static int sr_step_launch(const SrStepOperands &basis_ops, const CostP &cp, cons
   p.lam = basis->lam;
   p.pconst = basis->pconst;
   p.N = basis->n;
+  p.Ndata = basis->n_data >= 0 ? basis->n_data : basis->n;
   p.J = j;
   p.K = (int)basis->mk;
   p.rows_per_split = rows;
@@ -2329,6 +2337,7 @@ static int sr_step_launch(const SrStepOperands &basis_ops, const CostP &cp, cons
   p.debug_stop = getenv("PLS_SRS_STOP") ? atoi(getenv("PLS_SRS_STOP")) : 0;
 #endif
   *taken = true;
+  if (p.Ndata < p.N) return energy_in ? launch_small_rank_step_prior_value(p, st) : launch_small_rank_step_prior(p, st);
   return energy_in ? launch_small_rank_step_value(p, st) : launch_small_rank_step(p, st);
 }
 
@@ -3004,6 +3013,70 @@ int pls_ipb_whitened_step_blocks(const pls_ipb_desc *basis, const pls_cost_desc 
   PLS_REQUIRE(blocks != nullptr, "ipb_whitened_step_blocks: block descriptor is NULL");
   return ipb_whitened_step_impl(basis, cost, Sw, lds, j, 0.0, blocks, noise, out, ldo, out_mode, energy_in, workspace,
                                 workspace_bytes, stream);
+}
+
+// ---- whitened coordinates for every cost: the prior as rows of the forward operand (pls_ipb_desc.Awa) ------------------------
+int pls_ipb_build_whitened_operand(const pls_ipb_desc *basis, double *Awa, int64_t ldawa, void *stream) {
+  int rc = validate_ipb(basis);
+  if (rc) return rc;
+  PLS_REQUIRE(basis->LinvT && basis->ldlinvt >= basis->m, "ipb_build_whitened_operand: the descriptor needs the inverse factor LinvT");
+  PLS_REQUIRE(Awa && ldawa >= basis->m && (ldawa & 1) == 0 && (reinterpret_cast<uintptr_t>(Awa) & 15) == 0,
+              "ipb_build_whitened_operand: Awa must be 16-byte aligned with an even leading dimension >= m");
+  // rows [0, n): (k(X,Z) Lc^-T)[x][i] = sum_k Kzx[k][x] LinvT[k][i]
+  rc = pls_gemm_tn(basis->Kzx, basis->ldkzx, basis->LinvT, basis->ldlinvt, Awa, ldawa, basis->n, basis->m, basis->m, 1.0, 0.0, stream);
+  if (rc) return rc;
+  // rows [n, n + m): sqrt(m) Lc^-T = sqrt(m) LinvT
+  hipLaunchKernelGGL(scale_copy_2d_kernel, dim3((unsigned)cdiv(basis->m * basis->m, 256)), dim3(256), 0, S(stream), basis->LinvT,
+                     basis->ldlinvt, Awa + basis->n * ldawa, ldawa, basis->m, basis->m, sqrt((double)basis->m));
+  return check_launch("scale_copy_2d");
+}
+
+static bool ipb_whitened_generic_ok(const pls_ipb_desc *b, const double *y, int64_t j) {
+  if (!b->Awa || b->ldawa < b->m || g_small_rank_step.load() == 0) return false;
+  if (!small_rank_ok(b->Awa, b->ldawa, b->m) || (reinterpret_cast<uintptr_t>(y) & 15)) return false;
+  return j <= 4096 && 4.0 * (double)(b->n + b->m) * (double)b->m * (double)j <= 8e9;  // (sr_step_route_for's launch-bound window)
+}
+
+int pls_ipb_whitened_generic_applies(const pls_ipb_desc *basis, const double *y, int64_t j) {
+  if (!basis || validate_ipb(basis) != PLS_OK || !y || j <= 0) return 0;
+  return ipb_whitened_generic_ok(basis, y, j) ? 1 : 0;
+}
+
+size_t pls_ipb_whitened_generic_workspace_bytes(const pls_ipb_desc *basis, int64_t j) {
+  if (!basis || j <= 0) return 0;
+  return sr_step_workspace_bytes(basis->m, j, basis->n + basis->m);
+}
+
+int pls_ipb_whitened_generic_step(const pls_ipb_desc *basis, const pls_cost_desc *cost, const double *y, const double *Sw,
+                                  int64_t lds, int64_t j, double eta, const pls_block_desc *blocks, const pls_noise_desc *noise,
+                                  double *out, int64_t ldo, int32_t out_mode, double *energy_in, void *workspace,
+                                  size_t workspace_bytes, void *stream) {
+  int rc = validate_ipb(basis);
+  if (rc) return rc;
+  rc = validate_cost(cost);
+  if (rc) return rc;
+  rc = validate_noise(noise, basis->m, j);
+  if (rc) return rc;
+  rc = validate_blocks(blocks, j);
+  if (rc) return rc;
+  PLS_REQUIRE(!blocks || (!blocks->energy_partials && !blocks->energy_partials_prev && !blocks->energy_flush),
+              "ipb_whitened_generic_step: lagged energies exist on the Gaussian/identity routes only");
+  PLS_REQUIRE(y && Sw && out && out != Sw && j >= 0 && lds >= j && ldo >= j && eta >= 0.0, "ipb_whitened_generic_step: bad arguments");
+  PLS_REQUIRE(out_mode == 0 || out_mode == 1, "ipb_whitened_generic_step: out_mode must be 0 or 1");
+  if (j == 0) return PLS_OK;
+  if (!ipb_whitened_generic_ok(basis, y, j))
+    return fail(PLS_ERR_INVALID_ARGUMENT, "ipb_whitened_generic_step: needs pls_ipb_desc.Awa (pls_ipb_build_whitened_operand), at most 128 "
+                "inducing points, 16-byte aligned targets and a launch-bound problem (pls_ipb_whitened_generic_applies)");
+  if (!sr_step_fits(basis->m, basis->n + basis->m, j, blocks, energy_in, workspace ? workspace_bytes : 0))
+    return fail(PLS_ERR_WORKSPACE_TOO_SMALL, "ipb_whitened_generic_step: workspace %zu bytes, need %zu", workspace_bytes,
+                pls_ipb_whitened_generic_workspace_bytes(basis, j));
+  SrStepOperands ops{basis->Awa, basis->ldawa, basis->m, basis->n + basis->m, Sw, lds, nullptr, 0, nullptr, 0.0};
+  ops.n_data = basis->n;
+  bool taken = false;
+  rc = sr_step_launch(ops, make_costp(cost), y, j, make_etap(eta, blocks), make_noisep(noise, blocks), out, ldo, out_mode, energy_in,
+                      blocks, workspace, workspace ? workspace_bytes : 0, S(stream), &taken);
+  if (rc) return rc;
+  return taken ? PLS_OK : fail(PLS_ERR_WORKSPACE_TOO_SMALL, "ipb_whitened_generic_step: the one-launch step refused a workspace it was sized for");
 }
 
 int pls_ipb_whitened_energy(const pls_ipb_desc *basis, const pls_cost_desc *cost, const double *Sw, int64_t lds, int64_t j,

@@ -75,6 +75,10 @@ struct SrStepP {
 #ifdef PLS_SRS_PROBE
   int debug_stop;        // probe builds: 1 = return after the main loop, 2 = after the in-workgroup sum, 3 = after the arrival, 4 = after the slab loads
 #endif
+  int64_t Ndata;         // rows [0, Ndata) of Lb are data rows (cost cp against y); rows [Ndata, N) are PRIOR rows: their "cost"
+                         // is f^2 / 2 with derivative f -- a prior drift R^T R u and a prior energy |R u|^2 / 2 for the block R of
+                         // Lb they hold (the inducing-point basis in whitened coordinates: R^T R = M (Lc^T Lc)^-1).  Ndata = N: none.
+                         // y holds N entries either way (whatever stands behind the data rows is never used)
   double *sums16;        // [cdiv(J, 16)] sums of e over the 16 columns of each column block (ascending), may be pinned host
                          // memory; NULL: not wanted.  Costs nothing (the finishing workgroup of a column block holds them); the
                          // chunk sums cost a second hand-over between workgroups
@@ -117,6 +121,16 @@ static inline int64_t small_rank_step_splits(int64_t J, int64_t N, int K, int64_
   }
   int64_t rows = ((N + s - 1) / s + SRS_WG_ROWS - 1) / SRS_WG_ROWS * SRS_WG_ROWS;
   if (rows < SRS_WG_ROWS) rows = SRS_WG_ROWS;
+  if (s > 1) {
+    // a few rows past a multiple of the round (N = 1000 data rows + 32 prior rows: 129 rows per slab) must not cost every slab a
+    // whole round: rather one short slab more, while the finishing workgroup still fetches all slabs in one batch of loads and
+    // the grid stays within one workgroup per CU
+    int64_t down = (N / s) / SRS_WG_ROWS * SRS_WG_ROWS;
+    if (down < 2 * SRS_WG_ROWS) down = 2 * SRS_WG_ROWS;
+    const int64_t sd = (N + down - 1) / down;
+    const int64_t batch = kb <= 2 ? 16 : kb <= 4 ? 12 : 8;  // (slabs per batch of finishing loads, SB in the kernel)
+    if (down < rows && sd <= batch && ncb * sd <= 256) rows = down;
+  }
   s = (N + rows - 1) / rows;
   if (s < 1) s = 1;
   *rows_per_split = rows;
@@ -138,7 +152,9 @@ __device__ __forceinline__ double srs_langevin_delta(double eta, double sq2eta, 
   return -eta * drift - eta * ps * u + sq2eta * z;
 }
 
-template <int KB, int COST, int LINK, bool VALUE>
+template <int KB, int COST, int LINK, bool VALUE, bool PRIOR = false>
+// (PRIOR: the last rows of Lb may be prior rows, SrStepP.Ndata -- instantiations of their own, so that the kernels without them
+// stay the instruction sequence they were tuned as: a select per element in the cost loop cost the Poisson step 1.2 us)
 // (launch bounds of TWO workgroups per CU although the LDS image admits one: the bound caps the kernel at 256 registers, all of
 // them vector registers.  Allowed 512, the register allocator keeps the loop-carried drift accumulators of the wide ranks in
 // vector registers and copies all of them to accumulation registers and back around every tile: ~120 copies per 64 MFMAs.)
@@ -282,15 +298,31 @@ __global__ __launch_bounds__(256, 2) void small_rank_step_kernel(SrStepP p) {
       for (int ta = 0; ta < KB; ++ta) an[0][ta] = ap[16 * ta];
     }
     // per-element cost on the accumulator registers: register r <-> tile row q + 4 r
+    bool data_tile = true;
+    if constexpr (PRIOR) data_tile = n0w + SRS_TILE <= p.Ndata;  // (wave-uniform)
+    if (data_tile) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const bool valid = n0w + q + 4 * r < nend;
-      if constexpr (VALUE) {
-        const double cval = cost_value(cp, yv[r], f[r]);
-        vsum += valid ? cval : 0.0;
+      for (int r = 0; r < 4; ++r) {
+        const bool valid = n0w + q + 4 * r < nend;
+        if constexpr (VALUE) {
+          const double cval = cost_value(cp, yv[r], f[r]);
+          vsum += valid ? cval : 0.0;
+        }
+        const double gval = cost_deriv(cp, yv[r], f[r]);
+        f[r] = valid ? gval : 0.0;
       }
-      const double gval = cost_deriv(cp, yv[r], f[r]);
-      f[r] = valid ? gval : 0.0;
+    } else {  // a tile with prior rows (at most cdiv(K, 16) + 1 tiles of the last slab): f^2 / 2 and f for those
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool valid = n0w + q + 4 * r < nend;
+        const bool prow = n0w + q + 4 * r >= p.Ndata;
+        if constexpr (VALUE) {
+          const double cval = prow ? 0.5 * (f[r] * f[r]) : cost_value(cp, yv[r], f[r]);
+          vsum += valid ? cval : 0.0;
+        }
+        const double gval = prow ? f[r] : cost_deriv(cp, yv[r], f[r]);
+        f[r] = valid ? gval : 0.0;
+      }
     }
     // second contraction: D[16 ta + c][jcol] += sum_rows Lb[row][16 ta + c] * G[row][jcol]
 #pragma unroll

@@ -2,5 +2,5 @@
 #include "small_rank_step_launch.inc"
 
 namespace plship {
-int launch_small_rank_step(const SrStepP &p, hipStream_t st) { return launch_small_rank_step_any<false>(p, st); }
+int launch_small_rank_step(const SrStepP &p, hipStream_t st) { return launch_small_rank_step_any<false, false>(p, st); }
 }  // namespace plship

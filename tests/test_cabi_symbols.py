@@ -82,7 +82,7 @@ def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(L.CostDesc) == 4 * 4 + 4 * 8 + 8
     assert ctypes.sizeof(L.NoiseDesc) == 8 + 8 + 8 + 8 + 8 + 8 + 8
     assert ctypes.sizeof(L.OnbDesc) == 10 * 8
-    assert ctypes.sizeof(L.IpbDesc) == 29 * 8  # (ABI 4: + tri_scratch, tri_scratch_bytes, Pt, ldpt)
+    assert ctypes.sizeof(L.IpbDesc) == 31 * 8  # (ABI 4: + tri_scratch, tri_scratch_bytes, Pt, ldpt; ABI 5: + Awa, ldawa)
     assert ctypes.sizeof(L.CholDesc) == 15 * 8
     assert ctypes.sizeof(L.BlockDesc) == 11 * 8  # (ABI 5: + step_sync, energy_sums16)
     assert L.CostDesc.p.offset == 16 and L.CostDesc.jitter.offset == 48

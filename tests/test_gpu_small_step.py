@@ -451,13 +451,15 @@ def test_inducing_point_training_loop_polls_the_sums_of_the_one_launch_step(P, r
     # a step size inside the stability bound of the stiffest mode of the prior drift M k(Z,Z)^-1 (eta M / lambda_min < 2)
     eta = 0.25 * float(torch.linalg.eigvalsh(ob.base_gram_induce).min()) / 16
     route(1)
+    assert gb.whitened_generic_applies(gc, 48)  # (builds the whitened operand: one product, once per basis)
     with P.pkg._lib.Timeline(512) as tl:
         torch.manual_seed(3)
         P.pkg.train_pls(pls, u0.clone(), 20, eta, 1e9)
     summary = tl.summary()
     assert summary["small_rank_step"]["launches"] >= 20, summary
-    assert not {"small_rank", "gemm_cost", "langevin_update", "block_means", "gemm_store"} & set(summary), summary
-    assert summary["ipb_prep"]["launches"] == summary["small_rank_step"]["launches"], summary
+    # (whitened coordinates: S = Lc^-1 U once, ONE launch per iteration, U = Lc S once)
+    assert not {"small_rank", "gemm_cost", "langevin_update", "block_means", "ipb_prep", "normal_fill"} & set(summary), summary
+    assert summary.get("gemm_store", {"launches": 0})["launches"] <= 2, summary
     runs = {}
     for mode in ("pipelined", "plain"):
         if mode == "plain":
@@ -470,6 +472,16 @@ def test_inducing_point_training_loop_polls_the_sums_of_the_one_launch_step(P, r
             if mode == "plain":
                 del gb.supports_input_energy
     assert len(runs["pipelined"][1]) == len(runs["plain"][1]) == 40 and np.isfinite(runs["plain"][1]).all()
+    # ... and the chain in the ORIGINAL coordinates -- solve + coloured noise + step per call, the keys train_pls draws --: the
+    # same draws (Lc^-1 Lc xi = xi), the same particles and energies to the conditioning of two routes through k(Z,Z)
+    torch.manual_seed(44)
+    keys = torch.randint(0, 2**62, (256,), dtype=torch.int64).tolist()
+    u, es = u0.clone(), []
+    for t in range(40):
+        u = gb.fused_step(gc, u, eta, new_state=True, noise=P.basis.NoiseSpec(seed=keys[t], step=0))
+        es.append(pls.particle_energy_potential(u).mean().item())
+    assert relerr(runs["pipelined"][0], u) < 1e-9
+    assert np.allclose(runs["pipelined"][1], es, rtol=1e-9)
     assert relerr(runs["pipelined"][0], runs["plain"][0]) < 1e-12
     assert np.allclose(runs["pipelined"][1], runs["plain"][1], rtol=1e-11)
     assert torch.equal(runs["pipelined"][2], runs["plain"][2])

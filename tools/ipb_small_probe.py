@@ -20,7 +20,7 @@ for (n, m, j, d) in ((100, 10, 64, 1), (1000, 32, 100, 1), (4096, 128, 512, 4)):
                             ("poisson", PoissonCost(torch.poisson(y * y + 0.5, generator=g), SquareLinkFunction()))):
             pls = P.PLS(basis, cost)
             u = (1.0 + 0.1 * torch.randn(basis.approximation_dimension, j, generator=g)).cuda()
-            eta = 1e-9
+            eta = 1e-13  # (timing only; small enough that the stiffest mode of a random Z's prior drift stays stable for 2000 steps)
             train_pls(pls, u.clone(), 30, eta, 1e9)
             ws = []
             for _ in range(3):  # (median of three runs: one run in a few dozen is 1.5-2x slow as a whole, tools/sr_step_jitter.py)
@@ -28,6 +28,7 @@ for (n, m, j, d) in ((100, 10, 64, 1), (1000, 32, 100, 1), (4096, 128, 512, 4)):
                 _, e = train_pls(pls, u.clone(), 2000, eta, 1e9)
                 torch.cuda.synchronize(); ws.append(time.perf_counter() - t0)
             w = sorted(ws)[1]
+            assert len(e) == 2000, f"the run stopped after {len(e)} iterations"
             out = torch.empty_like(u); en = torch.empty(j, device="cuda")
             with L.Timeline(64) as tl:
                 basis.fused_step(cost, u, eta, out=out, new_state=True, noise=NoiseSpec(seed=1, step=0), input_energy=en)
