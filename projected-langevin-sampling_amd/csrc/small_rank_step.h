@@ -78,7 +78,7 @@ struct SrStepP {
   int64_t Ndata;         // rows [0, Ndata) of Lb are data rows (cost cp against y); rows [Ndata, N) are PRIOR rows: their "cost"
                          // is f^2 / 2 with derivative f -- a prior drift R^T R u and a prior energy |R u|^2 / 2 for the block R of
                          // Lb they hold (the inducing-point basis in whitened coordinates: R^T R = M (Lc^T Lc)^-1).  Ndata = N: none.
-                         // y holds N entries either way (whatever stands behind the data rows is never used)
+                         // y holds Ndata entries
   double *sums16;        // [cdiv(J, 16)] sums of e over the 16 columns of each column block (ascending), may be pinned host
                          // memory; NULL: not wanted.  Costs nothing (the finishing workgroup of a column block holds them); the
                          // chunk sums cost a second hand-over between workgroups
@@ -245,7 +245,13 @@ __global__ __launch_bounds__(256, 2) void small_rank_step_kernel(SrStepP p) {
     const uint64_t ybase = reinterpret_cast<uint64_t>(p.y + n0w);
     const uint64_t uy = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(ybase >> 32)) << 32) |
                         (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ybase);
-    const int ybytes = __builtin_amdgcn_readfirstlane((int)(rows_mem * 8 < 0x7FFFFFF0 ? rows_mem * 8 : 0x7FFFFFF0));
+    int ybytes;
+    if constexpr (PRIOR) {  // the targets end with the DATA rows: a tile of prior rows must not read behind y (<= 0 rows: nothing)
+      const int64_t rows_y = p.Ndata - n0w;
+      ybytes = __builtin_amdgcn_readfirstlane((int)(rows_y <= 0 ? 0 : rows_y * 8 < 0x7FFFFFF0 ? rows_y * 8 : 0x7FFFFFF0));
+    } else {
+      ybytes = __builtin_amdgcn_readfirstlane((int)(rows_mem * 8 < 0x7FFFFFF0 ? rows_mem * 8 : 0x7FFFFFF0));
+    }
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(uy), 0, ybytes, 0x00020000);
     if (lane < 8) __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (lds_ptr_t)(T + SRS_TILE * STR), 16, voff, 0, 0, 0);
   };

@@ -537,3 +537,64 @@ def test_inducing_point_captured_training_equals_the_plain_loop(P, route, j, k):
     assert len(got_e) == epochs and np.isfinite(got_e).all()
     assert torch.equal(got_u, u)
     assert np.allclose(got_e, want_e, rtol=1e-11)
+
+
+@pytest.mark.parametrize("n,m,j,d", [(100, 10, 64, 1), (333, 17, 37, 2), (1000, 32, 100, 2), (1100, 128, 90, 3), (520, 65, 16, 2)])
+def test_whitened_step_of_every_cost_against_the_oracle(P, route, n, m, j, d):
+    """pls_ipb_whitened_generic_step (inducing_point.py:117-150 in the coordinates S = Lc^-1 U: ONE launch, the prior as M rows of
+    the forward operand, white noise) against the oracle's update in the ORIGINAL coordinates with the coloured noise e = Lc xi
+    injected: U + dU = Lc (S + dS), the energies of the input particles, delta and new-state forms, column blocks with their own
+    step sizes; and against the library's own step in the original coordinates over the same Philox draws."""
+    pr = make_problem(n, m, j, d, seed=17 * n + m + FUZZ_SEED)
+    pr["ls"] = pr["ls"] * 0.35
+    ob, gb = build_ipb(P, pr)
+    lc = torch.linalg.cholesky(ob.base_gram_induce)
+    cond = torch.linalg.cond(ob.base_gram_induce).item()
+    u = pr["u"]
+    xi = torch.randn(m, j, generator=pr["gen"])
+    e_noise = lc @ xi
+    eta = 1e-3
+    s_dev = gb.whiten(cu(u))
+    assert relerr(s_dev, torch.linalg.solve_triangular(lc, u, upper=False)) < 1e-11 * max(1.0, cond / 1e5)
+    checked = 0
+    route(1)
+    for name, oc, gc in make_costs(P, pr["y"], pr["fstar"], pr["gen"]):
+        if name == "gaussian/identity":
+            continue  # (its whitened route is the M x M x J contraction of test_gpu_whitened.py)
+        assert gb.whitened_generic_applies(gc, j), name
+        want = O.PLS(ob, oc).calculate_particle_update(u.clone(), eta, noise=e_noise)
+        tol = step_tolerance(ob, oc, u, eta, e_noise, want)
+        if tol >= 1e-8:
+            continue
+        tol = tol * max(1.0, cond / 1e5)
+        checked += 1
+        e_in = torch.full((j,), float("nan"), device="cuda")
+        spec = P.basis.NoiseSpec(injected=cu(xi))  # (white: the xi of e = Lc xi)
+        names = _timeline_names(P, lambda: gb.whitened_step(gc, s_dev, eta, noise=spec, input_energy=e_in))
+        assert names == ["small_rank_step"], names
+        ds = gb.whitened_step(gc, s_dev, eta, noise=spec)
+        s_new = gb.whitened_step(gc, s_dev, eta, noise=spec, new_state=True, input_energy=e_in)
+        assert relerr(s_new, s_dev + ds) < 1e-14
+        assert relerr(gb.unwhiten(ds), want) < tol, name
+        assert relerr(gb.unwhiten(s_new), u + want) < max(tol, 1e-12), name
+        v = torch.cholesky_solve(u, lc)
+        e_want = oc.calculate_cost(ob.calculate_untransformed_train_prediction_samples(u)) + 0.5 * m * (v * v).sum(dim=0)
+        assert relerr(e_in, e_want) < 1e-9 * max(1.0, cond / 1e5), name
+        assert relerr(gb.whitened_particle_energy(gc, s_dev), e_in) < 1e-12, name
+        # the library's step in the original coordinates, Philox noise: the same draws
+        pspec = P.basis.NoiseSpec(seed=31, step=2)
+        du = gb.fused_step(gc, cu(u), eta, noise=pspec)
+        assert relerr(gb.unwhiten(gb.whitened_step(gc, s_dev, eta, noise=pspec)), du) < tol, name
+        # two column blocks with their own step sizes
+        if j >= 4:
+            half = j // 2
+            etas = torch.tensor([eta, 3.0 * eta], device="cuda")
+            blocks = P.basis.BlockSpec(half, etas)
+            jj = 2 * half
+            sb = s_dev[:, :jj].contiguous()
+            got_b = gb.whitened_step(gc, sb, 0.0, noise=P.basis.NoiseSpec(none=True), blocks=blocks)
+            a = gb.whitened_step(gc, sb[:, :half].contiguous(), eta, noise=P.basis.NoiseSpec(none=True))
+            b = gb.whitened_step(gc, sb[:, half:].contiguous(), 3.0 * eta, noise=P.basis.NoiseSpec(none=True))
+            assert relerr(got_b, torch.cat([a, b], dim=1)) < 1e-12, name
+    assert checked >= 5, checked
+    assert int(gb._step_sync(j, torch.device("cuda")).abs().sum()) == 0
