@@ -219,8 +219,10 @@ class InducingPointBasis(PLSBasis):
             return False
         if not (1 <= self.approximation_dimension <= self.SMALL_RANK_MAX) or self._chol.Linv is None or j <= 0:
             return False
+        m, n = self.approximation_dimension, self._n
+        if j > 4096 or 4.0 * (n + m) * m * j > 8e9:  # (the launch-bound window of the C side: do not build the operand for nothing)
+            return False
         if self._Awa is None:
-            m, n = self.approximation_dimension, self._n
             awa = alloc_matrix(n + m, m, self._Kxz.device)
             L.check(L.load().pls_ipb_build_whitened_operand(self._desc(), awa.data_ptr(), L.ld(awa), L.stream_ptr()),
                     "pls_ipb_build_whitened_operand")
