@@ -598,3 +598,29 @@ def test_whitened_step_of_every_cost_against_the_oracle(P, route, n, m, j, d):
             assert relerr(got_b, torch.cat([a, b], dim=1)) < 1e-12, name
     assert checked >= 5, checked
     assert int(gb._step_sync(j, torch.device("cuda")).abs().sum()) == 0
+
+
+def test_inducing_point_routes_are_invariant_under_particle_sharding(P, route):
+    """a rank of a J-sharded run holds a block of particle columns and draws the noise of its GLOBAL columns.  The
+    inducing-point basis' small routes -- a single call (solve + coloured noise in one launch, then the step) and the whitened
+    step of a loop -- give, shard by shard, the columns of the unsharded call."""
+    pr = make_problem(400, 20, 96, 2, seed=29 + FUZZ_SEED)
+    pr["ls"] = pr["ls"] * 0.35
+    ob, gb = build_ipb(P, pr)
+    name, oc, gc = make_costs(P, pr["y"], pr["fstar"], pr["gen"])[2]
+    u = cu(pr["u"])
+    s = gb.whiten(u)
+    route(1)
+    assert gb.whitened_generic_applies(gc, 96)
+    full = gb.fused_step(gc, u, 1e-3, noise=P.basis.NoiseSpec(seed=5, step=7, j_offset=0))
+    full_w = gb.whitened_step(gc, s, 1e-3, noise=P.basis.NoiseSpec(seed=5, step=7, j_offset=0))
+    assert relerr(gb.unwhiten(full_w), full) < 1e-10
+    for world in (2, 3):
+        parts, parts_w = [], []
+        for r in range(world):
+            j0, j1 = P.dist.shard_bounds(96, r, world)
+            spec = P.basis.NoiseSpec(seed=5, step=7, j_offset=j0)
+            parts.append(gb.fused_step(gc, u[:, j0:j1].contiguous(), 1e-3, noise=spec))
+            parts_w.append(gb.whitened_step(gc, s[:, j0:j1].contiguous(), 1e-3, noise=spec))
+        assert relerr(torch.cat(parts, dim=1), full) < 1e-13
+        assert relerr(torch.cat(parts_w, dim=1), full_w) < 1e-13
