@@ -52,6 +52,23 @@ def _build(eigh_device, group=None):
     return pkg, basis, cost, xs, j
 
 
+def _build_small_ipb():
+    """the inducing-point basis at the reference's curve-experiment scale with a cost without the Gaussian algebra: the loop that
+    keeps its particles whitened (one launch per iteration, csrc/small_rank_step.h over pls_ipb_desc.Awa)"""
+    import projected_langevin_sampling_amd as pkg
+    from projected_langevin_sampling_amd.basis import InducingPointBasis
+    from projected_langevin_sampling_amd.costs import BernoulliCost
+    from projected_langevin_sampling_amd.link_functions import SigmoidLinkFunction
+
+    x, z, y, ls, xs, j = _problem()
+    x, y, z = x[:700].contiguous(), y[:700].contiguous(), z[:24].contiguous()
+    basis = InducingPointBasis(pkg.PLSKernel(pkg.ARDKernel(ls, 1.2), z), z, y[:24], x)
+    cost = BernoulliCost((y > 0).double(), SigmoidLinkFunction())
+    eta = 0.25 * float(torch.linalg.eigvalsh(basis.base_gram_induce.cpu()).min()) / 24
+    u0 = torch.randn(24, j, generator=torch.Generator().manual_seed(6), dtype=torch.float64)
+    return pkg, basis, cost, u0, eta, j
+
+
 def _steps(basis, cost, u, first, count, seed=4242):
     from projected_langevin_sampling_amd.basis import NoiseSpec
 
@@ -131,6 +148,20 @@ def _worker(rank, world, port, out_dir):
     pb = train_pls(ppls, pstart.clone(), 12, 0.2 * eta, 1e9, energy_reduce=blocking)
     assert torch.equal(pa[0], pb[0]) and len(pa[1]) == len(pb[1]) == 12
     assert max(abs(x - y) / abs(y) for x, y in zip(pa[1], pb[1])) < 1e-12
+    # ... and the inducing-point basis' whitened loop for a cost without the Gaussian algebra (16-column energy sums, one launch
+    # per iteration): the same exchange, the same particles whichever way the mean travels
+    ipkg, ibasis, icost, iu0, ieta, _ = _build_small_ipb()
+    D.attach_shard(ibasis, j, rank, world)
+    ipls = ipkg.PLS(ibasis, icost)
+    assert ibasis.whitened_generic_applies(icost, j1 - j0)
+    istart = iu0[:, j0:j1].contiguous().cuda()
+    torch.manual_seed(23)
+    ia = train_pls(ipls, istart.clone(), 15, ieta, 1e9, energy_reduce=em)
+    torch.manual_seed(23)
+    ib = train_pls(ipls, istart.clone(), 15, ieta, 1e9, energy_reduce=blocking)
+    assert torch.equal(ia[0], ib[0]) and len(ia[1]) == len(ib[1]) == 15
+    assert max(abs(x - y) / abs(y) for x, y in zip(ia[1], ib[1])) < 1e-12
+    train["ipb_whitened"] = (ia[0].cpu(), ia[1])
     torch.save({"particles": mine.cpu(), "energy": energy, "mean": mean.cpu(), "var": var.cpu(), "samples": samples.cpu(),
                 "lam": basis.eigenvalues.cpu(), "vec": basis.eigenvectors.cpu(), "j0": j0, "j1": j1, "train": train},
                os.path.join(out_dir, f"out{rank}.pt"))
@@ -174,6 +205,14 @@ def test_two_ranks_on_one_gpu_equal_the_unsharded_run(tmp_path):
             assert len(e_s) == len(e_w) and max(abs(x - y) / abs(y) for x, y in zip(e_s, e_w)) < 1e-10, name
             assert _relerr(torch.cat([o["train"][name][0] for o in outs], dim=1), u_w.cpu()) < 1e-10, name
         assert len(outs[0]["train"]["board_stop"][1]) < 40, "test construction: the patience never stopped the run"
+        # the inducing-point basis' whitened loop, sharded against unsharded
+        ipkg, ibasis, icost, iu0, ieta, _ = _build_small_ipb()
+        torch.manual_seed(23)
+        iu_w, ie_w = train_pls(ipkg.PLS(ibasis, icost), iu0.cuda(), 15, ieta, 1e9)
+        assert outs[0]["train"]["ipb_whitened"][1] == outs[1]["train"]["ipb_whitened"][1]
+        ie_s = outs[0]["train"]["ipb_whitened"][1]
+        assert len(ie_s) == len(ie_w) == 15 and max(abs(x - y) / abs(y) for x, y in zip(ie_s, ie_w)) < 1e-10
+        assert _relerr(torch.cat([o["train"]["ipb_whitened"][0] for o in outs], dim=1), iu_w.cpu()) < 1e-10
         prev_stream = samplers.DEFAULT_NORMAL_STREAM
         samplers.DEFAULT_NORMAL_STREAM = "device"
         try:
