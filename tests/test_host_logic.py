@@ -502,3 +502,54 @@ def test_the_partial_sum_exchange_of_the_balanced_products_is_tested_across_xcds
     crossing = {k: v for k, v in split.items() if v > 0}
     assert len(crossing) >= 3, f"shapes whose pairs cross XCD groups: {crossing}"
     assert all(split[k] > 0 for k in ((192, 192), (200, 130), (1088, 320))), split  # (the ones the round-4 review replayed)
+
+
+def test_slab_plan_of_the_one_launch_step(tmp_path):
+    """csrc/small_rank_step.h, small_rank_step_splits: the host-side plan of the one-launch small-rank step (slabs per column block,
+    rows per slab), compiled from the header itself and checked over a grid of sizes -- rows in whole rounds of 64, every row
+    covered, no empty slab, several slabs only where they fit one workgroup per CU and are at least two rounds long; and the cases
+    the plan was tuned on (a few prior rows past a round must not cost every slab a round)."""
+    import os
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not found")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "plan.cpp"
+    src.write_text('''#include <cstdio>
+#include <cstdint>
+#include <hip/hip_runtime.h>
+#include "small_rank_step.h"
+int main() {
+  const int64_t js[] = {1, 16, 48, 64, 100, 330, 512, 1000, 4096};
+  const int64_t ns[] = {1, 40, 100, 110, 600, 1000, 1032, 1530, 3000, 4096, 4224, 20000};
+  const int ks[] = {1, 10, 16, 32, 33, 64, 100, 128};
+  for (int64_t j : js) for (int64_t n : ns) for (int k : ks) {
+    int64_t rows = 0;
+    const int64_t s = plship::small_rank_step_splits(j, n, k, &rows);
+    printf("%ld %ld %d %ld %ld\\n", (long)j, (long)n, k, (long)s, (long)rows);
+  }
+  return 0;
+}
+''')
+    exe = tmp_path / "plan"
+    subprocess.run([hipcc, "-std=c++17", "--offload-arch=gfx950", "-I", os.path.join(root, "projected-langevin-sampling_amd", "csrc"),
+                    "-o", str(exe), str(src)], check=True, capture_output=True, timeout=300)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True, timeout=60).stdout
+    plans = {}
+    for line in out.splitlines():
+        j, n, k, s, rows = (int(v) for v in line.split())
+        plans[(j, n, k)] = (s, rows)
+        ncb = (j + 15) // 16
+        assert s >= 1 and rows >= 64 and rows % 64 == 0, line
+        assert s * rows >= n and (s - 1) * rows < n, f"rows not covered exactly once / an empty slab: {line}"
+        if s > 1:
+            assert ncb * s <= 256, f"more workgroups than CUs: {line}"
+            assert rows >= 128, f"a slab shorter than two rounds: {line}"
+    assert plans[(64, 100, 10)] == (1, 128) and plans[(64, 110, 10)] == (1, 128)  # launch-bound: one slab
+    assert plans[(100, 1000, 32)] == (8, 128)
+    assert plans[(100, 1032, 32)] == (9, 128)  # 1000 data rows + 32 prior rows: one short slab more, not a third round for all
+    assert plans[(512, 4096, 128)] == (8, 512)
+    assert plans[(512, 4224, 128)] == (8, 576)  # (nine slabs would be 288 workgroups)
